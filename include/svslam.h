@@ -1,0 +1,222 @@
+/*
+ * svslam.h — C ABI of libsvslam_hip.so: the MI355X (gfx950) implementation of the
+ * per-frame hot path of farhad-dalirani/StereoVision-SLAM.
+ *
+ * The reference has no FFI layer; its hot path is five third-party library call
+ * sites inside two private C++ members (Frontend::Track, Backend::Optimize).
+ * Each entry point below replaces exactly one of those call sites (cited per
+ * function, file:line into the reference tree).  The ABI is flat: plain
+ * pointers and sizes, caller-owned host buffers, no C++/torch types, int
+ * return codes (0 = ok, <0 = error, see svslam_last_error), never throws.
+ *
+ * Everything is *batched over jobs*: one job = one call site invocation of one
+ * SLAM stream.  A single-stream caller passes njobs = 1; a multi-stream host
+ * (one process per GPU, S streams in lockstep) passes S jobs and gets one
+ * launch sequence for all of them.  Jobs are independent.
+ *
+ * Conventions
+ *   - images: u8, row-major, (width,height) fixed at context creation
+ *   - points: float32 (x,y) interleaved, exactly cv::Point2f
+ *   - SE(3):  double[7] = unit quaternion (x,y,z,w) + translation (x,y,z),
+ *             the memory layout of Sophus::SE3d; T_cw (world -> stereo rig)
+ *   - camera: double[4] = fx, fy, cx, cy ; extrinsic = SE(3) rig -> camera
+ */
+#ifndef SVSLAM_H
+#define SVSLAM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVSLAM_PYR_LEVELS 4      /* maxLevel 3  (src/frontend.cpp:107,355) */
+#define SVSLAM_LK_WIN 11         /* cv::Size(11,11) (src/frontend.cpp:107,355) */
+
+typedef struct svslam_ctx svslam_ctx;
+
+typedef struct svslam_limits {
+    int device;        /* HIP device ordinal                                   */
+    int width, height; /* working resolution (620x188 for KITTI-00, F3)        */
+    int max_slots;     /* resident image pyramids (3 per stream)               */
+    int max_jobs;      /* max jobs per batched call (= streams per GPU)        */
+    int max_pts;       /* max points per job (tracked + new corners)           */
+    int max_corners;   /* max corners returned per GFTT job                    */
+    int max_kf;        /* BA: max keyframes per problem                        */
+    int max_lm;        /* BA: max landmarks per problem                        */
+    int max_obs;       /* BA: max observations (edges) per problem             */
+} svslam_limits;
+
+/* ---- lifetime -------------------------------------------------------- */
+int  svslam_create(const svslam_limits *lim, svslam_ctx **out);
+void svslam_destroy(svslam_ctx *ctx);
+const char *svslam_last_error(const svslam_ctx *ctx);
+/* version / build info string (arch, compiler) */
+const char *svslam_build_info(void);
+
+/* ---- image pyramids ---------------------------------------------------
+ * Replaces cv::buildOpticalFlowPyramid as run inside cv::calcOpticalFlowPyrLK
+ * (src/frontend.cpp:105-109, 353-357).  Builds the 4-level u8 pyramid of each
+ * image into a resident slot; LK and GFTT refer to slots, so the previous
+ * frame's pyramid is reused instead of rebuilt.
+ * src_is_device: imgs[i] are device pointers already in HBM (bench / pipelined
+ * use) instead of host pointers.                                            */
+int svslam_pyramid_batch(svslam_ctx *ctx, int n, const int *slots,
+                         const void *const *imgs, const int *strides,
+                         int src_is_device);
+/* Same, but the source is the full-resolution frame and the 1/2 nearest
+ * decimation of Dataset::NextFrame (src/dataset.cpp:126-129) is fused into the
+ * level-0 write: dst(x,y) = src(2x,2y).  src size = (src_w, src_h); the
+ * context's (width,height) must equal (cvRound(src_w/2), cvRound(src_h/2)). */
+int svslam_pyramid_decimate_batch(svslam_ctx *ctx, int n, const int *slots,
+                                  const void *const *imgs, const int *strides,
+                                  int src_w, int src_h, int src_is_device);
+/* test hook: read one level back (tight rows of *w bytes) */
+int svslam_pyramid_read(svslam_ctx *ctx, int slot, int level, uint8_t *out,
+                        int *w, int *h);
+
+/* ---- pyramidal LK -----------------------------------------------------
+ * Replaces cv::calcOpticalFlowPyrLK(prev, next, prevPts, nextPts, status, err,
+ * Size(11,11), 3, TermCriteria(COUNT+EPS,30,0.01), OPTFLOW_USE_INITIAL_FLOW)
+ * at src/frontend.cpp:353-357 (TrackLastFrame) and :105-109
+ * (FindFeaturesInRight).  next_xy holds the initial guess on entry.          */
+typedef struct svslam_lk_job {
+    int prev_slot, next_slot; /* pyramids built by svslam_pyramid_batch      */
+    int pt_ofs, npts;         /* range in the concatenated point arrays      */
+} svslam_lk_job;
+
+typedef struct svslam_lk_params {
+    int    max_level;   /* 3                                                 */
+    int    max_iter;    /* 30 (clamped to [0,100] like OpenCV)               */
+    double epsilon;     /* 0.01 (squared internally like OpenCV)             */
+    double min_eig_thr; /* 1e-4 (OpenCV default)                             */
+    int    use_initial_flow; /* 1                                            */
+} svslam_lk_params;
+
+int svslam_lk_batch(svslam_ctx *ctx, int njobs, const svslam_lk_job *jobs,
+                    int total_pts, const float *prev_xy, float *next_xy,
+                    uint8_t *status, float *err, const svslam_lk_params *p);
+
+/* ---- GFTT (Shi-Tomasi) --------------------------------------------------
+ * Replaces the mask construction + cv::GFTTDetector::detect at
+ * src/frontend.cpp:42-51 (detector created at :24 with
+ * (num_features, 0.01, 20)).  rect_xy are the positions of the existing left
+ * features; each masks the inclusive square [round(pt-10), round(pt+10)].
+ * Output: up to max_corners integer-valued corners per job, quality-descending,
+ * out_xy laid out [njobs][max_corners][2].                                  */
+typedef struct svslam_gftt_job {
+    int slot;              /* level 0 of this pyramid slot is the image      */
+    int rect_ofs, nrect;   /* range in rect_xy                               */
+} svslam_gftt_job;
+
+int svslam_gftt_batch(svslam_ctx *ctx, int njobs, const svslam_gftt_job *jobs,
+                      int total_rects, const float *rect_xy, int max_corners,
+                      double quality, double min_dist, float *out_xy,
+                      int *out_n);
+/* test hook: min-eigenvalue map of a slot's level-0 image (w*h floats) */
+int svslam_gftt_eigmap(svslam_ctx *ctx, int slot, float *out);
+
+/* ---- stereo triangulation ----------------------------------------------
+ * Replaces slam::triangulation() (include/StereoVisionSLAM/algorithm.h:10-87)
+ * as called from BuildInitMap (src/frontend.cpp:165-174) and
+ * TriangulateNewPoints (:277-295): pixel2camera on both pixels, 4x4 DLT + SVD,
+ * gate sv[3]/sv[2] < 1e-2 && z > 0 && (zmax <= 0 || z <= zmax), then
+ * p_world = T_wc * p.                                                        */
+typedef struct svslam_tri_job {
+    int    pt_ofs, npts;
+    double T_wc[7];     /* current_frame->Pose().inverse(); identity at init */
+    double zmax;        /* max_triangulation_depth, <=0: no upper gate       */
+} svslam_tri_job;
+
+int svslam_triangulate_batch(svslam_ctx *ctx, int njobs,
+                             const svslam_tri_job *jobs, int total_pts,
+                             const double cam_l[4], const double ext_l[7],
+                             const double cam_r[4], const double ext_r[7],
+                             const float *uv_l, const float *uv_r,
+                             double *out_xyz, uint8_t *out_ok);
+
+/* ---- pose-only refinement ------------------------------------------------
+ * Replaces the g2o problem of Frontend::EstimateCurrentPose
+ * (src/frontend.cpp:394-558; VertexPose + EdgeProjectionPoseOnly,
+ * include/StereoVisionSLAM/g2o_types.h:25-65,94-174): 4 rounds x optimize(10)
+ * of Levenberg-Marquardt, estimate reset to the prior each round, chi2 > 5.991
+ * => outlier (excluded next round), Huber(1) in rounds 0-2.                  */
+typedef struct svslam_pose_job {
+    int    pt_ofs, npts;
+    double pose[7];     /* in: prior T_cw; out: refined                      */
+    int    n_inlier;    /* out                                                */
+    int    reserved;
+} svslam_pose_job;
+
+int svslam_pose_only_batch(svslam_ctx *ctx, int njobs, svslam_pose_job *jobs,
+                           int total_pts, const double cam[4],
+                           const double *xyz, const float *uv,
+                           uint8_t *outlier, double chi2_th, int rounds,
+                           int iters);
+
+/* ---- local bundle adjustment ----------------------------------------------
+ * Replaces optimizer.initializeOptimization(); optimizer.optimize(10) of
+ * Backend::Optimize (src/backend.cpp:22-164; VertexPose, VertexXYZ
+ * marginalised, EdgeProjection with Huber(delta = chi2_th),
+ * g2o_types.h:67-92,176-229): LM with Schur complement over the landmarks,
+ * dense solve of the reduced camera system, no vertex fixed.  Returns the
+ * optimised poses / points and the per-edge chi2 the caller thresholds
+ * (src/backend.cpp:167-213).  obs_kf / obs_lm are indices local to the job.  */
+typedef struct svslam_ba_job {
+    int kf_ofs, nkf;
+    int lm_ofs, nlm;
+    int obs_ofs, nobs;
+    int iters_done;     /* out: LM iterations executed                       */
+    int reserved;
+} svslam_ba_job;
+
+int svslam_local_ba_batch(svslam_ctx *ctx, int njobs, svslam_ba_job *jobs,
+                          const double cam_l[4], const double ext_l[7],
+                          const double cam_r[4], const double ext_r[7],
+                          int total_kf, double *poses, int total_lm,
+                          double *pts, int total_obs, const int *obs_kf,
+                          const int *obs_lm, const uint8_t *obs_is_right,
+                          const float *obs_uv, double huber_delta, int iters,
+                          double *edge_chi2);
+
+/* ---- fused per-frame tracking (pyramid + LK + pose-only, one submission) --
+ * The whole data-parallel part of Frontend::Track (src/frontend.cpp:645-663)
+ * without a host round trip between TrackLastFrame and EstimateCurrentPose:
+ * points that fail LK / leave the image are dropped on the device, the rest
+ * that carry a map point (has_mp) become pose-only edges.                    */
+typedef struct svslam_track_job {
+    int    prev_slot, next_slot;
+    int    pt_ofs, npts;
+    double pose[7];     /* in: prior; out: refined                           */
+    int    n_tracked;   /* out: status && in image                           */
+    int    n_inlier;    /* out                                                */
+} svslam_track_job;
+
+int svslam_track_batch(svslam_ctx *ctx, int njobs, svslam_track_job *jobs,
+                       const void *const *next_imgs, const int *strides,
+                       int src_is_device, int total_pts, const double cam[4],
+                       const float *prev_xy, float *next_xy,
+                       const uint8_t *has_mp, const double *xyz,
+                       uint8_t *status, uint8_t *outlier,
+                       const svslam_lk_params *p, double chi2_th);
+
+/* ---- device memory helpers for HBM-resident inputs (bench, pipelining) --- */
+int svslam_dev_alloc(svslam_ctx *ctx, size_t bytes, void **out);
+int svslam_dev_free(svslam_ctx *ctx, void *p);
+int svslam_dev_upload(svslam_ctx *ctx, void *dst, const void *src, size_t bytes);
+int svslam_dev_download(svslam_ctx *ctx, void *dst, const void *src, size_t bytes);
+int svslam_sync(svslam_ctx *ctx);
+
+/* ---- kernel timing (HIP events on the context's stream) -------------------
+ * Accumulated per kernel family since the last reset; used by bench.py for
+ * the roofline entry.  family: 0 pyramid, 1 lk, 2 gftt, 3 triangulate,
+ * 4 pose_only, 5 local_ba.                                                   */
+int svslam_timing_enable(svslam_ctx *ctx, int on);
+int svslam_timing_reset(svslam_ctx *ctx);
+int svslam_timing_get(svslam_ctx *ctx, int family, double *total_ms,
+                      long long *launches, long long *units);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVSLAM_H */
