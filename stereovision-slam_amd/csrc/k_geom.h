@@ -1,0 +1,349 @@
+// k_geom.h — stereo triangulation and pose-only Levenberg-Marquardt (f64).
+// Replaces slam::triangulation() (reference include/StereoVisionSLAM/
+// algorithm.h:10-87, called at src/frontend.cpp:165-174, 277-295) and the g2o
+// problem of Frontend::EstimateCurrentPose (src/frontend.cpp:394-558).
+// Mirrors oracle/orc_geom.c (same formulas, same LM control flow); the f64
+// edge sums use a fixed wave butterfly instead of the oracle's sequential
+// order, so agreement is to rounding (tolerances in tests/).
+#pragma once
+#include "dev_common.h"
+
+// ------------------------------------------------------------------ triangulation
+struct TriJob { int pt_ofs, npts; double T_wc[7]; double zmax; };
+struct TriCams { double cam_l[4], ext_l[7], cam_r[4], ext_r[7]; };
+
+__device__ inline void d_svd4_jacobi(double *A, double *V, double *sv)
+{
+    for (int i = 0; i < 16; ++i) V[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        int rotated = 0;
+        for (int p = 0; p < 3; ++p)
+            for (int q = p + 1; q < 4; ++q) {
+                double al = 0, be = 0, ga = 0;
+                for (int i = 0; i < 4; ++i) {
+                    al += A[i * 4 + p] * A[i * 4 + p];
+                    be += A[i * 4 + q] * A[i * 4 + q];
+                    ga += A[i * 4 + p] * A[i * 4 + q];
+                }
+                if (ga == 0.0 || fabs(ga) <= 1e-300 + 2.3e-16 * sqrt(al * be)) continue;
+                rotated = 1;
+                double zeta = (be - al) / (2.0 * ga);
+                double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                for (int i = 0; i < 4; ++i) {
+                    double ap = A[i * 4 + p], aq = A[i * 4 + q];
+                    A[i * 4 + p] = c * ap - s * aq;
+                    A[i * 4 + q] = s * ap + c * aq;
+                    double vp = V[i * 4 + p], vq = V[i * 4 + q];
+                    V[i * 4 + p] = c * vp - s * vq;
+                    V[i * 4 + q] = s * vp + c * vq;
+                }
+            }
+        if (!rotated) break;
+    }
+    for (int j = 0; j < 4; ++j) {
+        double s = 0;
+        for (int i = 0; i < 4; ++i) s += A[i * 4 + j] * A[i * 4 + j];
+        sv[j] = sqrt(s);
+    }
+    for (int j = 0; j < 3; ++j) {
+        int m = j;
+        for (int k = j + 1; k < 4; ++k) if (sv[k] > sv[m]) m = k;
+        if (m != j) {
+            double t = sv[j]; sv[j] = sv[m]; sv[m] = t;
+            for (int i = 0; i < 4; ++i) { double v = V[i * 4 + j]; V[i * 4 + j] = V[i * 4 + m]; V[i * 4 + m] = v; }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64)
+k_triangulate(const TriJob *jobs, TriCams cams, const float2 *uv_l, const float2 *uv_r,
+              double *out_xyz, uint8_t *out_ok)
+{
+    const TriJob &jb = jobs[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= jb.npts) return;
+    const int pt = jb.pt_ofs + i;
+    const float2 l = uv_l[pt], r = uv_r[pt];
+    // Camera::pixel2camera, depth 1
+    double pl[2] = { ((double)l.x - cams.cam_l[2]) * 1.0 / cams.cam_l[0], ((double)l.y - cams.cam_l[3]) * 1.0 / cams.cam_l[1] };
+    double pr[2] = { ((double)r.x - cams.cam_r[2]) * 1.0 / cams.cam_r[0], ((double)r.y - cams.cam_r[3]) * 1.0 / cams.cam_r[1] };
+    double A[16], V[16], sv[4], R[9];
+    d_quat_to_R(cams.ext_l, R);
+    {
+        double m[12] = { R[0], R[1], R[2], cams.ext_l[4], R[3], R[4], R[5], cams.ext_l[5], R[6], R[7], R[8], cams.ext_l[6] };
+        for (int j = 0; j < 4; ++j) { A[j] = pl[0] * m[8 + j] - m[j]; A[4 + j] = pl[1] * m[8 + j] - m[4 + j]; }
+    }
+    d_quat_to_R(cams.ext_r, R);
+    {
+        double m[12] = { R[0], R[1], R[2], cams.ext_r[4], R[3], R[4], R[5], cams.ext_r[5], R[6], R[7], R[8], cams.ext_r[6] };
+        for (int j = 0; j < 4; ++j) { A[8 + j] = pr[0] * m[8 + j] - m[j]; A[12 + j] = pr[1] * m[8 + j] - m[4 + j]; }
+    }
+    d_svd4_jacobi(A, V, sv);
+    const double w = V[15];
+    double p[3] = { V[3] / w, V[7] / w, V[11] / w };
+    bool ok = (sv[3] / sv[2] < 1e-2) && (p[2] > 0) && (jb.zmax <= 0 || p[2] <= jb.zmax);
+    double pw[3];
+    d_se3_act(jb.T_wc, p, pw);
+    out_xyz[3 * pt] = pw[0]; out_xyz[3 * pt + 1] = pw[1]; out_xyz[3 * pt + 2] = pw[2];
+    out_ok[pt] = ok ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ pose-only LM
+struct PoseJob { int pt_ofs, npts; double pose[7]; int n_inlier; int pad; };
+
+// in-register 6x6 LDLT with diagonal pivoting (Eigen::LDLT semantics);
+// executed redundantly by every lane (wave-uniform data)
+__device__ inline bool d_ldlt6(const double *Hin, const double *b, double *x)
+{
+    double L[36], D[6];
+    int perm[6];
+    for (int i = 0; i < 36; ++i) L[i] = Hin[i];
+    for (int i = 0; i < 6; ++i) perm[i] = i;
+    bool positive = true;
+    for (int k = 0; k < 6; ++k) {
+        int piv = k; double best = fabs(L[k * 7]);
+        for (int i = k + 1; i < 6; ++i) if (fabs(L[i * 7]) > best) { best = fabs(L[i * 7]); piv = i; }
+        if (piv != k) {
+            for (int j = 0; j < 6; ++j) { double t = L[k * 6 + j]; L[k * 6 + j] = L[piv * 6 + j]; L[piv * 6 + j] = t; }
+            for (int i = 0; i < 6; ++i) { double t = L[i * 6 + k]; L[i * 6 + k] = L[i * 6 + piv]; L[i * 6 + piv] = t; }
+            int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t;
+        }
+        double dk = L[k * 7];
+        for (int j = 0; j < k; ++j) dk -= L[k * 6 + j] * L[k * 6 + j] * D[j];
+        D[k] = dk;
+        if (dk < 0) positive = false;
+        for (int i = k + 1; i < 6; ++i) {
+            double v = L[i * 6 + k];
+            for (int j = 0; j < k; ++j) v -= L[i * 6 + j] * L[k * 6 + j] * D[j];
+            L[i * 6 + k] = (dk != 0.0) ? v / dk : 0.0;
+        }
+    }
+    if (!positive) return false;
+    double y[6];
+    for (int i = 0; i < 6; ++i) {
+        double v = b[perm[i]];
+        for (int j = 0; j < i; ++j) v -= L[i * 6 + j] * y[j];
+        y[i] = v;
+    }
+    for (int i = 0; i < 6; ++i) y[i] = (D[i] != 0.0) ? y[i] / D[i] : 0.0;
+    for (int i = 5; i >= 0; --i) {
+        double v = y[i];
+        for (int j = i + 1; j < 6; ++j) v -= L[j * 6 + i] * y[j];
+        y[i] = v;
+    }
+    for (int i = 0; i < 6; ++i) x[perm[i]] = y[i];
+    return true;
+}
+
+#define PO_MAX_PER_LANE 8     // up to 512 edges per job
+
+__device__ __forceinline__ void po_error(const double *cam, const double *T, const double *P,
+                                         double u, double v, double &e0, double &e1)
+{
+    double pc[3];
+    d_se3_act(T, P, pc);
+    double px = cam[0] * pc[0] + cam[2] * pc[2];
+    double py = cam[1] * pc[1] + cam[3] * pc[2];
+    e0 = u - px / pc[2];
+    e1 = v - py / pc[2];
+}
+
+// One wave per job.  Edge e of the job lives in lane e%64, register slot e/64.
+// status_in (optional): edges whose status_in==0 are not part of the problem
+// (used by the fused tracking path: LK failures / points without a map point).
+__global__ void __launch_bounds__(64)
+k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *uv,
+            const uint8_t *edge_valid, uint8_t *outlier, double chi2_th, int rounds, int iters)
+{
+    PoseJob &jb = jobs[blockIdx.x];
+    const int lane = threadIdx.x;
+    const int n = jb.npts;
+    const double cam[4] = { cam4[0], cam4[1], cam4[2], cam4[3] };
+    double T0[7], T[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { T0[i] = jb.pose[i]; T[i] = T0[i]; }
+
+    double P[PO_MAX_PER_LANE][3], mu[PO_MAX_PER_LANE], mv[PO_MAX_PER_LANE];
+    double e0[PO_MAX_PER_LANE], e1[PO_MAX_PER_LANE];
+    bool valid[PO_MAX_PER_LANE], outl[PO_MAX_PER_LANE];
+#pragma unroll
+    for (int s = 0; s < PO_MAX_PER_LANE; ++s) {
+        int e = s * 64 + lane;
+        valid[s] = e < n;
+        outl[s] = false; e0[s] = 0; e1[s] = 0;
+        if (valid[s]) {
+            int pt = jb.pt_ofs + e;
+            if (edge_valid && !edge_valid[pt]) valid[s] = false;
+            P[s][0] = xyz[3 * pt]; P[s][1] = xyz[3 * pt + 1]; P[s][2] = xyz[3 * pt + 2];
+            float2 m = uv[pt];
+            mu[s] = (double)m.x; mv[s] = (double)m.y;
+        } else { P[s][0] = P[s][1] = 0; P[s][2] = 1; mu[s] = mv[s] = 0; }
+    }
+    bool robust = true;
+    int cnt_outlier = 0, n_edges = 0;
+#pragma unroll
+    for (int s = 0; s < PO_MAX_PER_LANE; ++s) n_edges += valid[s] ? 1 : 0;
+    n_edges = wave_sum_i32(n_edges);
+
+    for (int r = 0; r < rounds; ++r) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) T[i] = T0[i];
+        int nact = 0;
+#pragma unroll
+        for (int s = 0; s < PO_MAX_PER_LANE; ++s) nact += (valid[s] && !outl[s]) ? 1 : 0;
+        nact = wave_sum_i32(nact);
+        if (nact > 0) {
+            double lambda = 0, ni = 2;
+            for (int it = 0; it < iters; ++it) {
+                // errors + chi2 + normal equations at T
+                double acc[27];
+#pragma unroll
+                for (int i = 0; i < 27; ++i) acc[i] = 0;
+                double chi = 0;
+#pragma unroll
+                for (int s = 0; s < PO_MAX_PER_LANE; ++s) {
+                    if (!(valid[s] && !outl[s])) continue;
+                    double pc[3];
+                    d_se3_act(T, P[s], pc);
+                    double X = pc[0], Y = pc[1], Z = pc[2];
+                    double px = cam[0] * X + cam[2] * Z, py = cam[1] * Y + cam[3] * Z;
+                    double ex = mu[s] - px / Z, ey = mv[s] - py / Z;
+                    e0[s] = ex; e1[s] = ey;
+                    double e2 = ex * ex + ey * ey, w = 1.0, rho = e2;
+                    if (robust) d_huber(e2, 1.0, rho, w);
+                    chi += rho;
+                    double Zinv = 1.0 / (Z + 1e-18), Zinv2 = Zinv * Zinv;
+                    double fx = cam[0], fy = cam[1];
+                    double J0[6] = { -fx * Zinv, 0, fx * X * Zinv2, fx * X * Y * Zinv2, -fx - fx * X * X * Zinv2, fx * Y * Zinv };
+                    double J1[6] = { 0, -fy * Zinv, fy * Y * Zinv2, fy + fy * Y * Y * Zinv2, -fy * X * Y * Zinv2, -fy * X * Zinv };
+                    int k = 0;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+                        for (int c = a; c < 6; ++c) { acc[k] += w * (J0[a] * J0[c] + J1[a] * J1[c]); ++k; }
+                    }
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) acc[21 + a] -= w * (J0[a] * ex + J1[a] * ey);
+                }
+#pragma unroll
+                for (int i = 0; i < 27; ++i) acc[i] = wave_sum_f64(acc[i]);
+                double currentChi = wave_sum_f64(chi);
+                double H[36], b[6];
+                {
+                    int k = 0;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a)
+#pragma unroll
+                        for (int c = a; c < 6; ++c) { H[a * 6 + c] = acc[k]; H[c * 6 + a] = acc[k]; ++k; }
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) b[a] = acc[21 + a];
+                }
+                if (it == 0) {
+                    double md = 0;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) md = fmax(md, fabs(H[a * 7]));
+                    lambda = 1e-5 * md; ni = 2;
+                }
+                double rho = 0; int qmax = 0;
+                double x[6] = { 0, 0, 0, 0, 0, 0 };
+                do {
+                    double Tb[7];
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) Tb[i] = T[i];
+                    double Hl[36];
+#pragma unroll
+                    for (int i = 0; i < 36; ++i) Hl[i] = H[i];
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) Hl[a * 7] += lambda;
+                    bool ok2 = d_ldlt6(Hl, b, x);
+                    double dT[7], Tn[7];
+                    d_se3_exp(x, dT);
+                    d_se3_mul(dT, T, Tn);
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) T[i] = Tn[i];
+                    double tchi = 0;
+#pragma unroll
+                    for (int s = 0; s < PO_MAX_PER_LANE; ++s) {
+                        if (!(valid[s] && !outl[s])) continue;
+                        po_error(cam, T, P[s], mu[s], mv[s], e0[s], e1[s]);
+                        double e2 = e0[s] * e0[s] + e1[s] * e1[s], w, rr = e2;
+                        if (robust) d_huber(e2, 1.0, rr, w);
+                        tchi += rr;
+                    }
+                    double tempChi = wave_sum_f64(tchi);
+                    if (!ok2) tempChi = 1.7976931348623157e308;
+                    rho = currentChi - tempChi;
+                    double scale = 0;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) scale += x[a] * (lambda * x[a] + b[a]);
+                    scale += 1e-3;
+                    rho /= scale;
+                    if (rho > 0 && isfinite(tempChi)) {
+                        double t = 2 * rho - 1;
+                        double alpha = 1. - t * t * t;
+                        alpha = fmin(alpha, 2. / 3.);
+                        double sf = fmax(1. / 3., alpha);
+                        lambda *= sf; ni = 2; currentChi = tempChi;
+                    } else {
+                        lambda *= ni; ni *= 2;
+#pragma unroll
+                        for (int i = 0; i < 7; ++i) T[i] = Tb[i];
+                        if (!isfinite(lambda)) break;
+                    }
+                    ++qmax;
+                } while (rho < 0 && qmax < 10);
+                if (qmax == 10 || rho == 0 || !isfinite(lambda)) break;
+            }
+        }
+        // classify (src/frontend.cpp:495-525)
+        int co = 0;
+#pragma unroll
+        for (int s = 0; s < PO_MAX_PER_LANE; ++s) {
+            if (!valid[s]) continue;
+            if (outl[s]) po_error(cam, T, P[s], mu[s], mv[s], e0[s], e1[s]);
+            double chi2 = e0[s] * e0[s] + e1[s] * e1[s];
+            outl[s] = chi2 > chi2_th;
+            co += outl[s] ? 1 : 0;
+        }
+        cnt_outlier = wave_sum_i32(co);
+        if (r == 2) robust = false;
+    }
+#pragma unroll
+    for (int s = 0; s < PO_MAX_PER_LANE; ++s) {
+        int e = s * 64 + lane;
+        if (e < n) outlier[jb.pt_ofs + e] = (valid[s] && outl[s]) ? 1 : 0;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) jb.pose[i] = T[i];
+        jb.n_inlier = n_edges - cnt_outlier;
+    }
+}
+
+// ------------------------------------------------------------------ fused-track filter
+// After LK: a point survives TrackLastFrame iff status && inside the image
+// (src/frontend.cpp:361-371); it becomes a pose-only edge iff it also carries a
+// map point (:443-444).  One block per job; writes the per-job survivor count.
+struct LkJobView { int prev_slot, next_slot, pt_ofs, npts; };
+__global__ void __launch_bounds__(256)
+k_track_filter(const LkJobView *jobs, const float2 *next_xy, uint8_t *status, const uint8_t *has_mp,
+               uint8_t *edge_valid, int *n_tracked, int w, int h)
+{
+    __shared__ int scnt[4];
+    const LkJobView jb = jobs[blockIdx.x];
+    int cnt = 0;
+    for (int i = threadIdx.x; i < jb.npts; i += 256) {
+        const int pt = jb.pt_ofs + i;
+        const float2 p = next_xy[pt];
+        bool ok = status[pt] != 0;
+        if (p.y < 0.f || p.y >= (float)h || p.x < 0.f || p.x >= (float)w) ok = false;
+        status[pt] = ok ? 1 : 0;
+        edge_valid[pt] = (ok && has_mp[pt]) ? 1 : 0;
+        cnt += ok ? 1 : 0;
+    }
+    cnt = wave_sum_i32(cnt);
+    if ((threadIdx.x & 63) == 0) scnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) n_tracked[blockIdx.x] = scnt[0] + scnt[1] + scnt[2] + scnt[3];
+}

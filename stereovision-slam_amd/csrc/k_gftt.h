@@ -1,0 +1,288 @@
+// k_gftt.h — Shi-Tomasi corner detection with the reference's feature mask.
+// Replaces Frontend::DetectFeatures' mask construction + cv::GFTTDetector
+// (OpenCV goodFeaturesToTrack: cornerMinEigenVal -> masked max -> threshold ->
+// 3x3 NMS -> sort -> greedy min-distance) at reference src/frontend.cpp:42-51.
+// Mirrors oracle/orc_gftt.c; the f32 operation order is the declared one
+// (-ffp-contract=off, IEEE sqrt), the 3x3 box sums are exact in f64, so the
+// corner list (coordinates, order, count) is bit-exact against the oracle.
+//
+// Kernels (all batched over jobs in grid.z / grid.y):
+//   k_gftt_mask   rasterise the 21x21 exclusion squares of the existing features
+//   k_gftt_eig    fused Sobel -> covariance -> 3x3 box -> min-eigenvalue tile
+//                 kernel (image tile + halo 2 staged in LDS, covariance tile +
+//                 halo 1 kept in LDS; the reference makes ~10 unfused passes),
+//                 plus the masked global maximum (wave reduce + 1 atomic/block)
+//   k_gftt_cand   threshold + 3x3 non-max suppression + mask -> compacted
+//                 64-bit keys (ordered value << 32 | pixel index)
+//   k_gftt_select one workgroup per job: bitonic sort of the keys (LDS, or
+//                 global memory when they do not fit) then the order-dependent
+//                 greedy min-distance pass, 64 candidates per step
+#pragma once
+#include "dev_common.h"
+
+struct GfttJob { int slot, rect_ofs, nrect; };
+
+struct GfttWork {            // per-job scratch in HBM
+    float *eig;              // [jobs][w*h]
+    uint8_t *mask;           // [jobs][w*h]
+    unsigned long long *keys;// [jobs][cap]
+    unsigned int *counters;  // [jobs][4]: 0 = ordered max, 1 = ncand
+    int cap;                 // key capacity per job (power of two >= w*h)
+};
+
+__device__ __forceinline__ unsigned int f32_ordered(float v)
+{
+    unsigned int b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float f32_from_ordered(unsigned int k)
+{
+    unsigned int b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(b);
+}
+
+__global__ void k_gftt_init(GfttWork wk, int w, int h, int njobs)
+{
+    // mask = 255, counters = 0
+    const int job = blockIdx.y;
+    const size_t P = (size_t)w * h;
+    uint32_t *m = reinterpret_cast<uint32_t *>(wk.mask + (size_t)job * ((P + 3) & ~(size_t)3));
+    const size_t n4 = (P + 3) >> 2;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+        m[i] = 0xffffffffu;
+    if (blockIdx.x == 0 && threadIdx.x < 4) wk.counters[job * 4 + threadIdx.x] = 0;
+}
+
+// one block per rectangle (grid.x = max nrect over jobs, grid.y = job)
+__global__ void k_gftt_mask(const GfttJob *jobs, GfttWork wk, const float2 *rect_xy, int w, int h)
+{
+    const GfttJob jb = jobs[blockIdx.y];
+    if ((int)blockIdx.x >= jb.nrect) return;
+    const size_t P = (size_t)w * h;
+    uint8_t *m = wk.mask + (size_t)blockIdx.y * ((P + 3) & ~(size_t)3);
+    const float2 c = rect_xy[jb.rect_ofs + blockIdx.x];
+    // cv::rectangle(mask, pt-(10,10), pt+(10,10), 0, FILLED); Point2f->Point = cvRound
+    int x1 = (int)rintf(c.x - 10.f), y1 = (int)rintf(c.y - 10.f);
+    int x2 = (int)rintf(c.x + 10.f), y2 = (int)rintf(c.y + 10.f);
+    x1 = max(x1, 0); y1 = max(y1, 0); x2 = min(x2, w - 1); y2 = min(y2, h - 1);
+    const int rw = x2 - x1 + 1, rh = y2 - y1 + 1;
+    if (rw <= 0 || rh <= 0) return;
+    for (int i = threadIdx.x; i < rw * rh; i += blockDim.x) {
+        int yy = i / rw, xx = i - yy * rw;
+        m[(size_t)(y1 + yy) * w + x1 + xx] = 0;
+    }
+}
+
+#define GF_TW 32
+#define GF_TH 16
+#define GF_IW (GF_TW + 4)   // image tile with halo 2
+#define GF_IH (GF_TH + 4)
+#define GF_CW (GF_TW + 2)   // covariance tile with halo 1
+#define GF_CH (GF_TH + 2)
+
+__global__ void __launch_bounds__(256)
+k_gftt_eig(const GfttJob *jobs, const uint8_t *pyr, PyrGeom g, GfttWork wk)
+{
+    __shared__ uint8_t sImg[GF_IH][GF_IW + 4];
+    __shared__ float sXX[GF_CH][GF_CW + 1], sXY[GF_CH][GF_CW + 1], sYY[GF_CH][GF_CW + 1];
+    __shared__ unsigned int sMax[4];
+
+    const int job = blockIdx.z;
+    const GfttJob jb = jobs[job];
+    const int w = g.w[0], h = g.h[0], pitch = g.pitch[0];
+    const uint8_t *img = lvl_origin(pyr + (size_t)jb.slot * g.slot_bytes, g, 0);
+    const size_t P = (size_t)w * h;
+    float *eig = wk.eig + (size_t)job * P;
+    const uint8_t *mask = wk.mask + (size_t)job * ((P + 3) & ~(size_t)3);
+    const int x0 = blockIdx.x * GF_TW, y0 = blockIdx.y * GF_TH;
+    const int tid = threadIdx.x;
+
+    // image tile: coordinates x0-2 .. x0+TW+1 (stored border supplies REFLECT_101;
+    // clamp only guards the far side of partial tiles, whose values are unused)
+    for (int i = tid; i < GF_IH * GF_IW; i += 256) {
+        int r = i / GF_IW, c = i - r * GF_IW;
+        int gx = min(x0 - 2 + c, w + SVS_BORDER - 1), gy = min(y0 - 2 + r, h + SVS_BORDER - 1);
+        sImg[r][c] = img[(ptrdiff_t)gy * pitch + gx];
+    }
+    __syncthreads();
+
+    const float s1 = (float)(1.0 / 3060.0);
+    const float s2 = (float)(2.0 * (1.0 / 3060.0));
+    // covariance at positions x0-1 .. x0+TW (REFLECT_101 of the *covariance map*:
+    // evaluate the gradient at the reflected pixel)
+    for (int i = tid; i < GF_CH * GF_CW; i += 256) {
+        int r = i / GF_CW, c = i - r * GF_CW;
+        int gx = x0 - 1 + c, gy = y0 - 1 + r;
+        float xx = 0.f, xy = 0.f, yy = 0.f;
+        if (gx <= w && gy <= h) {
+            int rx = reflect101(gx, w), ry = reflect101(gy, h);
+            // centre in tile coordinates; neighbours are in range
+            int cx = rx - (x0 - 2), cy = ry - (y0 - 2);
+            float p00 = sImg[cy - 1][cx - 1], p01 = sImg[cy - 1][cx], p02 = sImg[cy - 1][cx + 1];
+            float p10 = sImg[cy][cx - 1], p12 = sImg[cy][cx + 1];
+            float p20 = sImg[cy + 1][cx - 1], p21 = sImg[cy + 1][cx], p22 = sImg[cy + 1][cx + 1];
+            float d0 = p02 - p00, d1 = p12 - p10, d2 = p22 - p20;
+            float dx = (d0 + d2) * s1 + d1 * s2;
+            float c0 = (s1 * p00 + s2 * p01) + s1 * p02;
+            float c2 = (s1 * p20 + s2 * p21) + s1 * p22;
+            float dy = c2 - c0;
+            xx = dx * dx; xy = dx * dy; yy = dy * dy;
+        }
+        sXX[r][c] = xx; sXY[r][c] = xy; sYY[r][c] = yy;
+    }
+    __syncthreads();
+
+    unsigned int best = 0; // ordered key, 0 = nothing
+    for (int i = tid; i < GF_TH * GF_TW; i += 256) {
+        int r = i / GF_TW, c = i - r * GF_TW;
+        int gx = x0 + c, gy = y0 + r;
+        if (gx >= w || gy >= h) continue;
+        double sxx = 0, sxy = 0, syy = 0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                sxx += (double)sXX[r + j][c + k];
+                sxy += (double)sXY[r + j][c + k];
+                syy += (double)sYY[r + j][c + k];
+            }
+        float a = (float)sxx * 0.5f, b = (float)sxy, cc = (float)syy * 0.5f;
+        float t = a - cc;
+        float e = (a + cc) - sqrtf(t * t + b * b);
+        size_t pi = (size_t)gy * w + gx;
+        eig[pi] = e;
+        if (mask[pi]) best = max(best, f32_ordered(e));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) best = max(best, (unsigned int)__shfl_xor((int)best, o, 64));
+    if ((tid & 63) == 0) sMax[tid >> 6] = best;
+    __syncthreads();
+    if (tid == 0) {
+        best = max(max(sMax[0], sMax[1]), max(sMax[2], sMax[3]));
+        if (best) atomicMax(&wk.counters[job * 4 + 0], best);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_gftt_cand(GfttWork wk, int w, int h, double quality)
+{
+    const int job = blockIdx.z;
+    const size_t P = (size_t)w * h;
+    const float *eig = wk.eig + (size_t)job * P;
+    const uint8_t *mask = wk.mask + (size_t)job * ((P + 3) & ~(size_t)3);
+    const unsigned int mk = wk.counters[job * 4 + 0];
+    const double maxVal = mk ? (double)f32_from_ordered(mk) : 0.0;
+    const float thr = (float)(maxVal * quality);
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1) return;
+    const size_t i = (size_t)y * w + x;
+    const float v = eig[i];
+    if (!(v > thr) || v == 0.f || !mask[i]) return;
+#pragma unroll
+    for (int j = -1; j <= 1; ++j)
+#pragma unroll
+        for (int k = -1; k <= 1; ++k) {
+            float u = eig[i + (ptrdiff_t)j * w + k];
+            float ut = u > thr ? u : 0.f;
+            if (ut > v) return;
+        }
+    unsigned int slot = atomicAdd(&wk.counters[job * 4 + 1], 1u);
+    if (slot < (unsigned int)wk.cap)
+        wk.keys[(size_t)job * wk.cap + slot] = ((unsigned long long)f32_ordered(v) << 32) | (unsigned int)i;
+}
+
+#define GF_SEL_THREADS 1024
+#define GF_LDS_KEYS 16384
+#define GF_MAX_CORNERS 1024
+#define GF_SEL_LDS_BYTES (GF_LDS_KEYS * 8 + GF_MAX_CORNERS * 8)
+
+__device__ __forceinline__ void bitonic_desc(unsigned long long *a, int n2, int tid, int nthreads)
+{
+    // sort n2 (power of two) keys descending; a may be LDS or global
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < n2; i += nthreads) {
+                int ixj = i ^ j;
+                if (ixj > i) {
+                    unsigned long long x = a[i], y = a[ixj];
+                    bool desc = ((i & k) == 0);
+                    if (desc ? (x < y) : (x > y)) { a[i] = y; a[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void __launch_bounds__(GF_SEL_THREADS)
+k_gftt_select(GfttWork wk, int w, int max_corners, double min_dist, float2 *out_xy, int *out_n,
+              int out_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // all LDS scratch lives in the dynamic region (keeps the base 16-B aligned)
+    unsigned long long *skeys = reinterpret_cast<unsigned long long *>(smem);
+    float *accx = reinterpret_cast<float *>(smem + (size_t)GF_LDS_KEYS * 8);
+    float *accy = accx + GF_MAX_CORNERS;
+
+    const int job = blockIdx.x;
+    const int tid = threadIdx.x;
+    unsigned int n = wk.counters[job * 4 + 1];
+    if (n > (unsigned int)wk.cap) n = wk.cap;
+    unsigned long long *gkeys = wk.keys + (size_t)job * wk.cap;
+    float2 *out = out_xy + (size_t)job * out_stride;
+    if (n == 0) { if (tid == 0) out_n[job] = 0; return; }
+    int n2 = 1;
+    while (n2 < (int)n) n2 <<= 1;
+    unsigned long long *keys;
+    if (n2 <= GF_LDS_KEYS) {
+        for (int i = tid; i < n2; i += GF_SEL_THREADS) skeys[i] = i < (int)n ? gkeys[i] : 0ull;
+        keys = skeys;
+    } else {
+        for (int i = n + tid; i < n2; i += GF_SEL_THREADS) gkeys[i] = 0ull;
+        keys = gkeys;
+    }
+    __syncthreads();
+    bitonic_desc(keys, n2, tid, GF_SEL_THREADS);
+
+    // greedy min-distance selection (order dependent): wave 0 only
+    if (tid < 64) {
+        const int lane = tid;
+        const bool use_dist = min_dist >= 1.0;
+        const double md2 = min_dist * min_dist;
+        int nacc = 0;
+        bool done = false;
+        for (int base = 0; base < (int)n && !done; base += 64) {
+            const int c = base + lane;
+            bool alive = c < (int)n;
+            float x = 0.f, y = 0.f;
+            if (alive) {
+                unsigned int idx = (unsigned int)(keys[c] & 0xffffffffull);
+                int yi = idx / w, xi = idx - yi * w;
+                x = (float)xi; y = (float)yi;
+            }
+            if (use_dist) {
+                for (int j = 0; j < nacc; ++j) {
+                    float dx = x - accx[j], dy = y - accy[j];
+                    if ((double)(dx * dx + dy * dy) < md2) alive = false;
+                }
+            }
+            unsigned long long m = __ballot(alive);
+            while (m) {
+                const int l = __ffsll((long long)m) - 1;
+                const float bx = __shfl(x, l, 64), by = __shfl(y, l, 64);
+                if (lane == 0) { accx[nacc] = bx; accy[nacc] = by; out[nacc] = make_float2(bx, by); }
+                ++nacc;
+                if (max_corners > 0 && nacc == max_corners) { done = true; break; }
+                if (lane == l) alive = false;
+                else if (alive && use_dist) {
+                    float dx = x - bx, dy = y - by;
+                    if ((double)(dx * dx + dy * dy) < md2) alive = false;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                m = __ballot(alive);
+            }
+        }
+        if (lane == 0) out_n[job] = nacc;
+    }
+}

@@ -1,0 +1,756 @@
+// svslam_hip.hip — C-ABI entry points of libsvslam_hip.so (see include/svslam.h).
+// Host side: context, HBM-resident pyramid slots, one pinned staging arena
+// (one H2D + one D2H per batched call), launches on the context's own stream.
+// No CPU fallback exists: if no HIP device is usable svslam_create fails.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/svslam.h"
+#include "dev_common.h"
+#include "k_pyramid.h"
+#include "k_lk.h"
+#include "k_gftt.h"
+#include "k_geom.h"
+#include "k_ba.h"
+
+namespace {
+
+enum { FAM_PYR = 0, FAM_LK, FAM_GFTT, FAM_TRI, FAM_POSE, FAM_BA, FAM_COUNT };
+
+struct Timing {
+    double ms[FAM_COUNT] = { 0 };
+    long long launches[FAM_COUNT] = { 0 };
+    long long units[FAM_COUNT] = { 0 };
+};
+
+struct Arena {
+    unsigned char *h = nullptr; // pinned host
+    unsigned char *d = nullptr; // device mirror
+    size_t cap = 0, off = 0;
+    void reset() { off = 0; }
+    size_t take(size_t bytes)
+    {
+        size_t o = (off + 255) & ~(size_t)255;
+        off = o + bytes;
+        return o;
+    }
+};
+
+} // namespace
+
+struct svslam_ctx {
+    svslam_limits lim;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    PyrGeom geom;
+    uint8_t *d_pyr = nullptr;
+    Arena ar;
+    // image upload area (host-pointer sources)
+    uint8_t *d_img = nullptr;
+    size_t d_img_cap = 0;
+    uint8_t *h_img = nullptr;
+    size_t h_img_cap = 0;
+    // GFTT scratch
+    GfttWork gw;
+    // BA scratch
+    BaWork bw;
+    // timing
+    bool timing = false;
+    Timing tm;
+    hipEvent_t ev[2 * 8];
+    int nev = 0;
+    int ev_fam[8];
+    long long ev_units[8];
+};
+
+namespace {
+
+int fail(svslam_ctx *c, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return -1;
+}
+
+#define HIPCHK(c, call)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) return fail((c), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+void make_geom(PyrGeom &g, int w, int h)
+{
+    memset(&g, 0, sizeof(g));
+    size_t off = 0;
+    int lw = w, lh = h, n = 0;
+    for (int l = 0; l < SVS_LEVELS; ++l) {
+        g.w[l] = lw; g.h[l] = lh;
+        g.pitch[l] = (lw + 2 * SVS_BORDER + 63) & ~63;
+        g.ofs[l] = off;
+        off += (size_t)g.pitch[l] * (lh + 2 * SVS_BORDER);
+        off = (off + 255) & ~(size_t)255;
+        n = l + 1;
+        lw = (lw + 1) / 2; lh = (lh + 1) / 2;
+        // buildOpticalFlowPyramid stops when the next level is not larger than the window
+        if (lw <= SVSLAM_LK_WIN || lh <= SVSLAM_LK_WIN) break;
+    }
+    g.nlevels = n;
+    g.slot_bytes = off;
+}
+
+void tm_begin(svslam_ctx *c, int fam, long long units)
+{
+    if (!c->timing || c->nev >= 8) return;
+    c->ev_fam[c->nev] = fam;
+    c->ev_units[c->nev] = units;
+    (void)hipEventRecord(c->ev[2 * c->nev], c->stream);
+}
+void tm_end(svslam_ctx *c)
+{
+    if (!c->timing || c->nev >= 8) return;
+    (void)hipEventRecord(c->ev[2 * c->nev + 1], c->stream);
+    c->nev++;
+}
+void tm_collect(svslam_ctx *c)
+{
+    // call after the stream has been synchronised
+    for (int i = 0; i < c->nev; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev[2 * i], c->ev[2 * i + 1]) == hipSuccess) {
+            c->tm.ms[c->ev_fam[i]] += ms;
+            c->tm.launches[c->ev_fam[i]] += 1;
+            c->tm.units[c->ev_fam[i]] += c->ev_units[i];
+        }
+    }
+    c->nev = 0;
+}
+
+int h2d(svslam_ctx *c, size_t from, size_t to)
+{
+    if (to > from) HIPCHK(c, hipMemcpyAsync(c->ar.d + from, c->ar.h + from, to - from, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+int d2h_sync(svslam_ctx *c, size_t from, size_t to)
+{
+    if (to > from) HIPCHK(c, hipMemcpyAsync(c->ar.h + from, c->ar.d + from, to - from, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    tm_collect(c);
+    return 0;
+}
+
+template <typename T> T *hp(svslam_ctx *c, size_t off) { return reinterpret_cast<T *>(c->ar.h + off); }
+template <typename T> T *dp(svslam_ctx *c, size_t off) { return reinterpret_cast<T *>(c->ar.d + off); }
+
+int check_slot(svslam_ctx *c, int s)
+{
+    if (s < 0 || s >= c->lim.max_slots) return fail(c, "slot %d out of range [0,%d)", s, c->lim.max_slots);
+    return 0;
+}
+
+// enqueue pyramid construction for n jobs whose PyrJob array is at device offset djobs
+int launch_pyramid(svslam_ctx *c, const PyrJob *djobs, int n, bool decimate, int src_w, int src_h)
+{
+    const PyrGeom &g = c->geom;
+    tm_begin(c, FAM_PYR, n);
+    {
+        dim3 blk(64, 4);
+        dim3 grd(cdiv((g.w[0] + 2 * SVS_BORDER + 3) / 4, 64), cdiv(g.h[0] + 2 * SVS_BORDER, 4), n);
+        if (decimate) hipLaunchKernelGGL(k_pyr_level0<true>, grd, blk, 0, c->stream, djobs, c->d_pyr, g, src_w, src_h);
+        else hipLaunchKernelGGL(k_pyr_level0<false>, grd, blk, 0, c->stream, djobs, c->d_pyr, g, src_w, src_h);
+    }
+    for (int l = 1; l < g.nlevels; ++l) {
+        dim3 blk(64, 4);
+        dim3 grd(cdiv(g.w[l] + 2 * SVS_BORDER, 64), cdiv(g.h[l] + 2 * SVS_BORDER, 4), n);
+        hipLaunchKernelGGL(k_pyr_down, grd, blk, 0, c->stream, djobs, c->d_pyr, g, l);
+    }
+    tm_end(c);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int pyramid_common(svslam_ctx *c, int n, const int *slots, const void *const *imgs, const int *strides,
+                   int src_is_device, bool decimate, int src_w, int src_h, bool sync)
+{
+    if (n <= 0) return 0;
+    if (n > c->lim.max_jobs) return fail(c, "pyramid: %d jobs > max_jobs %d", n, c->lim.max_jobs);
+    for (int i = 0; i < n; ++i) if (check_slot(c, slots[i])) return -1;
+    const int iw = decimate ? src_w : c->geom.w[0], ih = decimate ? src_h : c->geom.h[0];
+    c->ar.reset();
+    size_t ojobs = c->ar.take(sizeof(PyrJob) * n);
+    PyrJob *hj = hp<PyrJob>(c, ojobs);
+    if (!src_is_device) {
+        size_t per = ((size_t)iw * ih + 255) & ~(size_t)255;
+        size_t need = per * n;
+        if (need > c->d_img_cap) {
+            if (c->d_img) (void)hipFree(c->d_img);
+            if (c->h_img) (void)hipHostFree(c->h_img);
+            c->d_img = nullptr; c->h_img = nullptr; c->d_img_cap = 0;
+            HIPCHK(c, hipMalloc(&c->d_img, need));
+            HIPCHK(c, hipHostMalloc(&c->h_img, need));
+            c->d_img_cap = need;
+        }
+        for (int i = 0; i < n; ++i) {
+            const uint8_t *s = static_cast<const uint8_t *>(imgs[i]);
+            uint8_t *d = c->h_img + per * i;
+            for (int y = 0; y < ih; ++y) memcpy(d + (size_t)y * iw, s + (size_t)y * strides[i], iw);
+            hj[i].src = c->d_img + per * i;
+            hj[i].src_stride = iw;
+            hj[i].slot = slots[i];
+        }
+        HIPCHK(c, hipMemcpyAsync(c->d_img, c->h_img, need, hipMemcpyHostToDevice, c->stream));
+    } else {
+        for (int i = 0; i < n; ++i) {
+            hj[i].src = static_cast<const uint8_t *>(imgs[i]);
+            hj[i].src_stride = strides[i];
+            hj[i].slot = slots[i];
+        }
+    }
+    if (h2d(c, ojobs, c->ar.off)) return -1;
+    if (launch_pyramid(c, dp<PyrJob>(c, ojobs), n, decimate, src_w, src_h)) return -1;
+    if (sync) return d2h_sync(c, 0, 0);
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *svslam_build_info(void)
+{
+    return "libsvslam_hip gfx950 (hipcc " __VERSION__ "), -ffp-contract=off";
+}
+
+const char *svslam_last_error(const svslam_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int svslam_create(const svslam_limits *lim, svslam_ctx **out)
+{
+    if (!lim || !out) return -1;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        fprintf(stderr, "svslam_create: no HIP device available (this library has no CPU path)\n");
+        return -2;
+    }
+    if (lim->device < 0 || lim->device >= ndev) return -3;
+    if (lim->width < 16 || lim->height < 16 || lim->max_slots < 1 || lim->max_jobs < 1 || lim->max_pts < 1)
+        return -4;
+    if (lim->max_pts > 64 * PO_MAX_PER_LANE) return -5;
+    if (lim->max_corners < 1 || lim->max_corners > GF_MAX_CORNERS) return -6;
+    svslam_ctx *c = new (std::nothrow) svslam_ctx();
+    if (!c) return -7;
+    c->lim = *lim;
+    c->device = lim->device;
+    *out = c; // returned even on failure so the caller can read the error
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 16; ++i) HIPCHK(c, hipEventCreate(&c->ev[i]));
+    make_geom(c->geom, lim->width, lim->height);
+    HIPCHK(c, hipMalloc(&c->d_pyr, c->geom.slot_bytes * (size_t)lim->max_slots));
+    HIPCHK(c, hipMemsetAsync(c->d_pyr, 0, c->geom.slot_bytes * (size_t)lim->max_slots, c->stream));
+
+    // staging arena: the largest batched call decides
+    const size_t J = lim->max_jobs, N = lim->max_pts;
+    size_t per_job_pts = N * (8 + 8 + 1 + 4 + 24 + 8 + 1 + 1 + 8) + 1024;
+    size_t per_job_ba = (size_t)lim->max_kf * 56 + (size_t)lim->max_lm * 24 +
+                        (size_t)lim->max_obs * (4 + 4 + 1 + 8 + 8 + 16 + 16) + (size_t)lim->max_lm * 8 + 1024;
+    size_t per_job = std::max(per_job_pts, per_job_ba) + (size_t)lim->max_corners * 8 + 4096;
+    c->ar.cap = per_job * J + (1 << 20);
+    HIPCHK(c, hipHostMalloc(&c->ar.h, c->ar.cap));
+    HIPCHK(c, hipMalloc(&c->ar.d, c->ar.cap));
+
+    // GFTT scratch
+    const size_t P = (size_t)lim->width * lim->height;
+    int cap = 1;
+    while ((size_t)cap < P) cap <<= 1;
+    c->gw.cap = cap;
+    HIPCHK(c, hipMalloc(&c->gw.eig, sizeof(float) * P * J));
+    HIPCHK(c, hipMalloc(&c->gw.mask, ((P + 3) & ~(size_t)3) * J));
+    HIPCHK(c, hipMalloc(&c->gw.keys, sizeof(unsigned long long) * (size_t)cap * J));
+    HIPCHK(c, hipMalloc(&c->gw.counters, sizeof(unsigned int) * 4 * J));
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_gftt_select),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, GF_SEL_LDS_BYTES));
+    // BA scratch
+    if (lim->max_kf > 0) {
+        if (6 * lim->max_kf > BA_MAX_NP) return fail(c, "max_kf %d too large (<= %d)", lim->max_kf, BA_MAX_NP / 6);
+        if (ba_lds_bytes(lim->max_kf) > 160 * 1024) return fail(c, "max_kf %d: reduced system does not fit LDS", lim->max_kf);
+        if (ba_work_alloc(c->bw, lim->max_jobs, lim->max_kf, lim->max_lm, lim->max_obs) != hipSuccess)
+            return fail(c, "BA workspace allocation failed");
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_local_ba),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ba_lds_bytes(lim->max_kf)));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+void svslam_destroy(svslam_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->d_pyr);
+    (void)hipFree(c->ar.d);
+    if (c->ar.h) (void)hipHostFree(c->ar.h);
+    (void)hipFree(c->d_img);
+    if (c->h_img) (void)(void)hipHostFree(c->h_img);
+    (void)hipFree(c->gw.eig); (void)hipFree(c->gw.mask); (void)hipFree(c->gw.keys); (void)hipFree(c->gw.counters);
+    ba_work_free(c->bw);
+    for (int i = 0; i < 16; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int svslam_sync(svslam_ctx *c)
+{
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    tm_collect(c);
+    return 0;
+}
+
+int svslam_dev_alloc(svslam_ctx *c, size_t bytes, void **out) { HIPCHK(c, hipMalloc(out, bytes)); return 0; }
+int svslam_dev_free(svslam_ctx *c, void *p) { HIPCHK(c, hipFree(p)); return 0; }
+int svslam_dev_upload(svslam_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    HIPCHK(c, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+int svslam_dev_download(svslam_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    HIPCHK(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int svslam_timing_enable(svslam_ctx *c, int on) { c->timing = on != 0; return 0; }
+int svslam_timing_reset(svslam_ctx *c) { c->tm = Timing(); return 0; }
+int svslam_timing_get(svslam_ctx *c, int family, double *total_ms, long long *launches, long long *units)
+{
+    if (family < 0 || family >= FAM_COUNT) return fail(c, "bad timing family %d", family);
+    if (total_ms) *total_ms = c->tm.ms[family];
+    if (launches) *launches = c->tm.launches[family];
+    if (units) *units = c->tm.units[family];
+    return 0;
+}
+
+// ------------------------------------------------------------------ pyramids
+int svslam_pyramid_batch(svslam_ctx *c, int n, const int *slots, const void *const *imgs,
+                         const int *strides, int src_is_device)
+{
+    return pyramid_common(c, n, slots, imgs, strides, src_is_device, false, c->geom.w[0], c->geom.h[0], true);
+}
+
+int svslam_pyramid_decimate_batch(svslam_ctx *c, int n, const int *slots, const void *const *imgs,
+                                  const int *strides, int src_w, int src_h, int src_is_device)
+{
+    // cvRound(src*0.5): round half to even
+    int dw = (int)std::nearbyint(src_w * 0.5), dh = (int)std::nearbyint(src_h * 0.5);
+    if (dw != c->geom.w[0] || dh != c->geom.h[0])
+        return fail(c, "decimate: source %dx%d halves to %dx%d, context is %dx%d", src_w, src_h, dw, dh,
+                    c->geom.w[0], c->geom.h[0]);
+    return pyramid_common(c, n, slots, imgs, strides, src_is_device, true, src_w, src_h, true);
+}
+
+int svslam_pyramid_read(svslam_ctx *c, int slot, int level, uint8_t *out, int *w, int *h)
+{
+    if (check_slot(c, slot)) return -1;
+    if (level < 0 || level >= c->geom.nlevels) return fail(c, "level %d out of range", level);
+    const PyrGeom &g = c->geom;
+    if (w) *w = g.w[level];
+    if (h) *h = g.h[level];
+    if (!out) return 0;
+    const uint8_t *src = c->d_pyr + (size_t)slot * g.slot_bytes + g.ofs[level] + (size_t)SVS_BORDER * g.pitch[level] + SVS_BORDER;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy2D(out, g.w[level], src, g.pitch[level], g.w[level], g.h[level], hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ------------------------------------------------------------------ LK
+static LkParams make_lk_params(const svslam_lk_params *p)
+{
+    LkParams k;
+    k.max_level = p ? p->max_level : 3;
+    int mc = p ? p->max_iter : 30;
+    k.max_count = std::min(std::max(mc, 0), 100);
+    double eps = p ? p->epsilon : 0.01;
+    eps = std::min(std::max(eps, 0.), 10.);
+    k.eps2 = eps * eps;
+    k.min_eig_thr = p ? p->min_eig_thr : 1e-4;
+    k.use_initial_flow = p ? p->use_initial_flow : 1;
+    return k;
+}
+
+int svslam_lk_batch(svslam_ctx *c, int njobs, const svslam_lk_job *jobs, int total_pts,
+                    const float *prev_xy, float *next_xy, uint8_t *status, float *err,
+                    const svslam_lk_params *p)
+{
+    if (njobs <= 0) return 0;
+    if (njobs > c->lim.max_jobs) return fail(c, "lk: %d jobs > max_jobs", njobs);
+    if (total_pts > c->lim.max_jobs * c->lim.max_pts) return fail(c, "lk: too many points");
+    int maxn = 0;
+    for (int i = 0; i < njobs; ++i) {
+        if (check_slot(c, jobs[i].prev_slot) || check_slot(c, jobs[i].next_slot)) return -1;
+        if (jobs[i].npts < 0 || jobs[i].pt_ofs < 0 || jobs[i].pt_ofs + jobs[i].npts > total_pts)
+            return fail(c, "lk: job %d point range out of bounds", i);
+        maxn = std::max(maxn, jobs[i].npts);
+    }
+    c->ar.reset();
+    size_t ojobs = c->ar.take(sizeof(LkJob) * njobs);
+    size_t oprev = c->ar.take(sizeof(float) * 2 * total_pts);
+    size_t onext = c->ar.take(sizeof(float) * 2 * total_pts);
+    size_t in_end = c->ar.off;
+    size_t ostat = c->ar.take(total_pts);
+    size_t oerr = c->ar.take(sizeof(float) * total_pts);
+    static_assert(sizeof(LkJob) == sizeof(svslam_lk_job), "job layout");
+    memcpy(hp<void>(c, ojobs), jobs, sizeof(LkJob) * njobs);
+    memcpy(hp<void>(c, oprev), prev_xy, sizeof(float) * 2 * total_pts);
+    memcpy(hp<void>(c, onext), next_xy, sizeof(float) * 2 * total_pts);
+    if (h2d(c, 0, in_end)) return -1;
+    if (maxn > 0) {
+        tm_begin(c, FAM_LK, total_pts);
+        dim3 grd(cdiv(maxn, LK_WAVES_PER_BLOCK), njobs);
+        hipLaunchKernelGGL(k_lk, grd, dim3(64 * LK_WAVES_PER_BLOCK), 0, c->stream, dp<LkJob>(c, ojobs), c->d_pyr,
+                           c->geom, dp<float2>(c, oprev), dp<float2>(c, onext), dp<uint8_t>(c, ostat),
+                           dp<float>(c, oerr), make_lk_params(p));
+        tm_end(c);
+        HIPCHK(c, hipGetLastError());
+    }
+    if (d2h_sync(c, onext, c->ar.off)) return -1;
+    memcpy(next_xy, hp<void>(c, onext), sizeof(float) * 2 * total_pts);
+    memcpy(status, hp<void>(c, ostat), total_pts);
+    if (err) memcpy(err, hp<void>(c, oerr), sizeof(float) * total_pts);
+    return 0;
+}
+
+// ------------------------------------------------------------------ GFTT
+static int launch_gftt(svslam_ctx *c, int njobs, const GfttJob *djobs, int max_nrect, const float2 *drects,
+                       int max_corners, double quality, double min_dist, float2 *dout, int *dn)
+{
+    const int w = c->geom.w[0], h = c->geom.h[0];
+    tm_begin(c, FAM_GFTT, njobs);
+    hipLaunchKernelGGL(k_gftt_init, dim3(32, njobs), dim3(256), 0, c->stream, c->gw, w, h, njobs);
+    if (max_nrect > 0)
+        hipLaunchKernelGGL(k_gftt_mask, dim3(max_nrect, njobs), dim3(256), 0, c->stream, djobs, c->gw, drects, w, h);
+    hipLaunchKernelGGL(k_gftt_eig, dim3(cdiv(w, GF_TW), cdiv(h, GF_TH), njobs), dim3(256), 0, c->stream, djobs,
+                       c->d_pyr, c->geom, c->gw);
+    hipLaunchKernelGGL(k_gftt_cand, dim3(cdiv(w, 64), cdiv(h, 4), njobs), dim3(64, 4), 0, c->stream, c->gw, w, h,
+                       quality);
+    hipLaunchKernelGGL(k_gftt_select, dim3(njobs), dim3(GF_SEL_THREADS), GF_SEL_LDS_BYTES, c->stream, c->gw, w,
+                       max_corners, min_dist, dout, dn, max_corners);
+    tm_end(c);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int svslam_gftt_batch(svslam_ctx *c, int njobs, const svslam_gftt_job *jobs, int total_rects,
+                      const float *rect_xy, int max_corners, double quality, double min_dist,
+                      float *out_xy, int *out_n)
+{
+    if (njobs <= 0) return 0;
+    if (njobs > c->lim.max_jobs) return fail(c, "gftt: %d jobs > max_jobs", njobs);
+    if (max_corners < 1 || max_corners > c->lim.max_corners) return fail(c, "gftt: max_corners %d out of [1,%d]", max_corners, c->lim.max_corners);
+    if (total_rects > c->lim.max_jobs * c->lim.max_pts) return fail(c, "gftt: too many mask rects");
+    int max_nrect = 0;
+    for (int i = 0; i < njobs; ++i) {
+        if (check_slot(c, jobs[i].slot)) return -1;
+        if (jobs[i].nrect < 0 || jobs[i].rect_ofs < 0 || jobs[i].rect_ofs + jobs[i].nrect > total_rects)
+            return fail(c, "gftt: job %d rect range out of bounds", i);
+        max_nrect = std::max(max_nrect, jobs[i].nrect);
+    }
+    c->ar.reset();
+    size_t ojobs = c->ar.take(sizeof(GfttJob) * njobs);
+    size_t orect = c->ar.take(sizeof(float) * 2 * std::max(total_rects, 1));
+    size_t in_end = c->ar.off;
+    size_t oout = c->ar.take(sizeof(float) * 2 * (size_t)max_corners * njobs);
+    size_t on = c->ar.take(sizeof(int) * njobs);
+    static_assert(sizeof(GfttJob) == sizeof(svslam_gftt_job), "job layout");
+    memcpy(hp<void>(c, ojobs), jobs, sizeof(GfttJob) * njobs);
+    if (total_rects > 0) memcpy(hp<void>(c, orect), rect_xy, sizeof(float) * 2 * total_rects);
+    if (h2d(c, 0, in_end)) return -1;
+    if (launch_gftt(c, njobs, dp<GfttJob>(c, ojobs), max_nrect, dp<float2>(c, orect), max_corners, quality,
+                    min_dist, dp<float2>(c, oout), dp<int>(c, on))) return -1;
+    if (d2h_sync(c, oout, c->ar.off)) return -1;
+    memcpy(out_n, hp<void>(c, on), sizeof(int) * njobs);
+    memcpy(out_xy, hp<void>(c, oout), sizeof(float) * 2 * (size_t)max_corners * njobs);
+    return 0;
+}
+
+int svslam_gftt_eigmap(svslam_ctx *c, int slot, float *out)
+{
+    if (check_slot(c, slot)) return -1;
+    c->ar.reset();
+    size_t ojobs = c->ar.take(sizeof(GfttJob));
+    GfttJob *j = hp<GfttJob>(c, ojobs);
+    j->slot = slot; j->rect_ofs = 0; j->nrect = 0;
+    if (h2d(c, 0, c->ar.off)) return -1;
+    const int w = c->geom.w[0], h = c->geom.h[0];
+    hipLaunchKernelGGL(k_gftt_init, dim3(32, 1), dim3(256), 0, c->stream, c->gw, w, h, 1);
+    hipLaunchKernelGGL(k_gftt_eig, dim3(cdiv(w, GF_TW), cdiv(h, GF_TH), 1), dim3(256), 0, c->stream,
+                       dp<GfttJob>(c, ojobs), c->d_pyr, c->geom, c->gw);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, c->gw.eig, sizeof(float) * (size_t)w * h, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ------------------------------------------------------------------ triangulation
+int svslam_triangulate_batch(svslam_ctx *c, int njobs, const svslam_tri_job *jobs, int total_pts,
+                             const double cam_l[4], const double ext_l[7], const double cam_r[4],
+                             const double ext_r[7], const float *uv_l, const float *uv_r,
+                             double *out_xyz, uint8_t *out_ok)
+{
+    if (njobs <= 0 || total_pts <= 0) return 0;
+    if (njobs > c->lim.max_jobs) return fail(c, "triangulate: %d jobs > max_jobs", njobs);
+    if (total_pts > c->lim.max_jobs * c->lim.max_pts) return fail(c, "triangulate: too many points");
+    int maxn = 0;
+    for (int i = 0; i < njobs; ++i) {
+        if (jobs[i].npts < 0 || jobs[i].pt_ofs < 0 || jobs[i].pt_ofs + jobs[i].npts > total_pts)
+            return fail(c, "triangulate: job %d point range out of bounds", i);
+        maxn = std::max(maxn, jobs[i].npts);
+    }
+    c->ar.reset();
+    static_assert(sizeof(TriJob) == sizeof(svslam_tri_job), "job layout");
+    size_t ojobs = c->ar.take(sizeof(TriJob) * njobs);
+    size_t ol = c->ar.take(sizeof(float) * 2 * total_pts);
+    size_t orr = c->ar.take(sizeof(float) * 2 * total_pts);
+    size_t in_end = c->ar.off;
+    size_t oxyz = c->ar.take(sizeof(double) * 3 * total_pts);
+    size_t ook = c->ar.take(total_pts);
+    memcpy(hp<void>(c, ojobs), jobs, sizeof(TriJob) * njobs);
+    memcpy(hp<void>(c, ol), uv_l, sizeof(float) * 2 * total_pts);
+    memcpy(hp<void>(c, orr), uv_r, sizeof(float) * 2 * total_pts);
+    TriCams cams;
+    memcpy(cams.cam_l, cam_l, 32); memcpy(cams.ext_l, ext_l, 56);
+    memcpy(cams.cam_r, cam_r, 32); memcpy(cams.ext_r, ext_r, 56);
+    if (h2d(c, 0, in_end)) return -1;
+    if (maxn > 0) {
+        tm_begin(c, FAM_TRI, total_pts);
+        hipLaunchKernelGGL(k_triangulate, dim3(cdiv(maxn, 64), njobs), dim3(64), 0, c->stream, dp<TriJob>(c, ojobs),
+                           cams, dp<float2>(c, ol), dp<float2>(c, orr), dp<double>(c, oxyz), dp<uint8_t>(c, ook));
+        tm_end(c);
+        HIPCHK(c, hipGetLastError());
+    }
+    if (d2h_sync(c, oxyz, c->ar.off)) return -1;
+    memcpy(out_xyz, hp<void>(c, oxyz), sizeof(double) * 3 * total_pts);
+    memcpy(out_ok, hp<void>(c, ook), total_pts);
+    return 0;
+}
+
+// ------------------------------------------------------------------ pose-only
+int svslam_pose_only_batch(svslam_ctx *c, int njobs, svslam_pose_job *jobs, int total_pts,
+                           const double cam[4], const double *xyz, const float *uv,
+                           uint8_t *outlier, double chi2_th, int rounds, int iters)
+{
+    if (njobs <= 0) return 0;
+    if (njobs > c->lim.max_jobs) return fail(c, "pose_only: %d jobs > max_jobs", njobs);
+    if (total_pts > c->lim.max_jobs * c->lim.max_pts) return fail(c, "pose_only: too many points");
+    for (int i = 0; i < njobs; ++i) {
+        if (jobs[i].npts < 0 || jobs[i].npts > c->lim.max_pts || jobs[i].pt_ofs < 0 ||
+            jobs[i].pt_ofs + jobs[i].npts > total_pts)
+            return fail(c, "pose_only: job %d point range out of bounds", i);
+    }
+    c->ar.reset();
+    static_assert(sizeof(PoseJob) == sizeof(svslam_pose_job), "job layout");
+    size_t ocam = c->ar.take(32);
+    size_t oxyz = c->ar.take(sizeof(double) * 3 * std::max(total_pts, 1));
+    size_t ouv = c->ar.take(sizeof(float) * 2 * std::max(total_pts, 1));
+    size_t ojobs = c->ar.take(sizeof(PoseJob) * njobs);
+    size_t in_end = c->ar.off;
+    size_t oout = c->ar.take(std::max(total_pts, 1));
+    memcpy(hp<void>(c, ocam), cam, 32);
+    if (total_pts > 0) {
+        memcpy(hp<void>(c, oxyz), xyz, sizeof(double) * 3 * total_pts);
+        memcpy(hp<void>(c, ouv), uv, sizeof(float) * 2 * total_pts);
+    }
+    memcpy(hp<void>(c, ojobs), jobs, sizeof(PoseJob) * njobs);
+    if (h2d(c, 0, in_end)) return -1;
+    tm_begin(c, FAM_POSE, njobs);
+    hipLaunchKernelGGL(k_pose_only, dim3(njobs), dim3(64), 0, c->stream, dp<PoseJob>(c, ojobs), dp<double>(c, ocam),
+                       dp<double>(c, oxyz), dp<float2>(c, ouv), (const uint8_t *)nullptr, dp<uint8_t>(c, oout),
+                       chi2_th, rounds, iters);
+    tm_end(c);
+    HIPCHK(c, hipGetLastError());
+    if (d2h_sync(c, ojobs, c->ar.off)) return -1;
+    memcpy(jobs, hp<void>(c, ojobs), sizeof(PoseJob) * njobs);
+    if (total_pts > 0) memcpy(outlier, hp<void>(c, oout), total_pts);
+    return 0;
+}
+
+// ------------------------------------------------------------------ local BA
+int svslam_local_ba_batch(svslam_ctx *c, int njobs, svslam_ba_job *jobs, const double cam_l[4],
+                          const double ext_l[7], const double cam_r[4], const double ext_r[7],
+                          int total_kf, double *poses, int total_lm, double *pts, int total_obs,
+                          const int *obs_kf, const int *obs_lm, const uint8_t *obs_is_right,
+                          const float *obs_uv, double huber_delta, int iters, double *edge_chi2)
+{
+    if (njobs <= 0) return 0;
+    if (njobs > c->lim.max_jobs) return fail(c, "local_ba: %d jobs > max_jobs", njobs);
+    for (int i = 0; i < njobs; ++i) {
+        const svslam_ba_job &j = jobs[i];
+        if (j.nkf < 0 || j.nkf > c->lim.max_kf || j.nlm < 0 || j.nlm > c->lim.max_lm || j.nobs < 0 ||
+            j.nobs > c->lim.max_obs || j.kf_ofs < 0 || j.kf_ofs + j.nkf > total_kf || j.lm_ofs < 0 ||
+            j.lm_ofs + j.nlm > total_lm || j.obs_ofs < 0 || j.obs_ofs + j.nobs > total_obs)
+            return fail(c, "local_ba: job %d exceeds limits (kf %d/%d lm %d/%d obs %d/%d)", i, j.nkf,
+                        c->lim.max_kf, j.nlm, c->lim.max_lm, j.nobs, c->lim.max_obs);
+        for (int e = 0; e < j.nobs; ++e) {
+            int k = obs_kf[j.obs_ofs + e], l = obs_lm[j.obs_ofs + e];
+            if (k < 0 || k >= j.nkf || l < 0 || l >= j.nlm) return fail(c, "local_ba: job %d edge %d index out of range", i, e);
+        }
+    }
+    c->ar.reset();
+    static_assert(sizeof(BaJob) == sizeof(svslam_ba_job), "job layout");
+    size_t aux_total = 0;
+    for (int i = 0; i < njobs; ++i) aux_total += ba_aux_ints(jobs[i].nkf, jobs[i].nlm, jobs[i].nobs);
+    size_t ocams = c->ar.take(sizeof(BaCams));
+    size_t okf = c->ar.take(sizeof(int) * std::max(total_obs, 1));
+    size_t olm = c->ar.take(sizeof(int) * std::max(total_obs, 1));
+    size_t oright = c->ar.take(std::max(total_obs, 1));
+    size_t ouv = c->ar.take(sizeof(float) * 2 * std::max(total_obs, 1));
+    size_t oaux = c->ar.take(sizeof(int) * std::max(aux_total, (size_t)1));
+    size_t ojobs = c->ar.take(sizeof(BaDev) * njobs);
+    size_t oposes = c->ar.take(sizeof(double) * 7 * std::max(total_kf, 1));
+    size_t opts = c->ar.take(sizeof(double) * 3 * std::max(total_lm, 1));
+    size_t in_end = c->ar.off;
+    size_t ochi = c->ar.take(sizeof(double) * std::max(total_obs, 1));
+    if (c->ar.off > c->ar.cap) return fail(c, "local_ba: staging arena too small");
+    BaCams *cams = hp<BaCams>(c, ocams);
+    memcpy(cams->cam[0], cam_l, 32); memcpy(cams->cam[1], cam_r, 32);
+    memcpy(cams->ext[0], ext_l, 56); memcpy(cams->ext[1], ext_r, 56);
+    if (total_obs > 0) {
+        memcpy(hp<void>(c, okf), obs_kf, sizeof(int) * total_obs);
+        memcpy(hp<void>(c, olm), obs_lm, sizeof(int) * total_obs);
+        memcpy(hp<void>(c, oright), obs_is_right, total_obs);
+        memcpy(hp<void>(c, ouv), obs_uv, sizeof(float) * 2 * total_obs);
+    }
+    BaDev *dj = hp<BaDev>(c, ojobs);
+    {
+        size_t aofs = 0;
+        int *aux = hp<int>(c, oaux);
+        for (int i = 0; i < njobs; ++i) {
+            BaJob bj;
+            memcpy(&bj, &jobs[i], sizeof(bj));
+            ba_build_aux(bj, obs_kf, obs_lm, aux + aofs, dj[i]);
+            dj[i].aux_ofs = (int)aofs;
+            aofs += ba_aux_ints(bj.nkf, bj.nlm, bj.nobs);
+        }
+    }
+    if (total_kf > 0) memcpy(hp<void>(c, oposes), poses, sizeof(double) * 7 * total_kf);
+    if (total_lm > 0) memcpy(hp<void>(c, opts), pts, sizeof(double) * 3 * total_lm);
+    if (h2d(c, 0, in_end)) return -1;
+    tm_begin(c, FAM_BA, njobs);
+    hipLaunchKernelGGL(k_local_ba, dim3(njobs), dim3(BA_THREADS), ba_lds_bytes(c->lim.max_kf), c->stream,
+                       dp<BaDev>(c, ojobs), dp<BaCams>(c, ocams), dp<double>(c, oposes), dp<double>(c, opts),
+                       dp<int>(c, okf), dp<int>(c, olm), dp<uint8_t>(c, oright), dp<float2>(c, ouv),
+                       dp<int>(c, oaux), c->bw, huber_delta, iters, dp<double>(c, ochi));
+    tm_end(c);
+    HIPCHK(c, hipGetLastError());
+    if (d2h_sync(c, ojobs, c->ar.off)) return -1;
+    for (int i = 0; i < njobs; ++i) jobs[i].iters_done = dj[i].iters_done;
+    if (total_kf > 0) memcpy(poses, hp<void>(c, oposes), sizeof(double) * 7 * total_kf);
+    if (total_lm > 0) memcpy(pts, hp<void>(c, opts), sizeof(double) * 3 * total_lm);
+    if (total_obs > 0) memcpy(edge_chi2, hp<void>(c, ochi), sizeof(double) * total_obs);
+    return 0;
+}
+
+// ------------------------------------------------------------------ fused tracking
+int svslam_track_batch(svslam_ctx *c, int njobs, svslam_track_job *jobs, const void *const *next_imgs,
+                       const int *strides, int src_is_device, int total_pts, const double cam[4],
+                       const float *prev_xy, float *next_xy, const uint8_t *has_mp, const double *xyz,
+                       uint8_t *status, uint8_t *outlier, const svslam_lk_params *p, double chi2_th)
+{
+    if (njobs <= 0) return 0;
+    if (njobs > c->lim.max_jobs) return fail(c, "track: %d jobs > max_jobs", njobs);
+    if (total_pts > c->lim.max_jobs * c->lim.max_pts) return fail(c, "track: too many points");
+    std::vector<int> slots(njobs);
+    for (int i = 0; i < njobs; ++i) {
+        if (check_slot(c, jobs[i].prev_slot) || check_slot(c, jobs[i].next_slot)) return -1;
+        if (jobs[i].npts < 0 || jobs[i].npts > c->lim.max_pts || jobs[i].pt_ofs < 0 ||
+            jobs[i].pt_ofs + jobs[i].npts > total_pts)
+            return fail(c, "track: job %d point range out of bounds", i);
+        slots[i] = jobs[i].next_slot;
+    }
+    // 1. pyramids of the new left images (enqueue only)
+    if (pyramid_common(c, njobs, slots.data(), next_imgs, strides, src_is_device, false, c->geom.w[0],
+                       c->geom.h[0], false)) return -1;
+    // 2. LK + pose-only back to back, single readback.  The arena region used by the
+    //    pyramid job array stays live until the stream drains, so continue after it.
+    int maxn = 0;
+    for (int i = 0; i < njobs; ++i) maxn = std::max(maxn, jobs[i].npts);
+    size_t base = c->ar.off;
+    size_t olk = c->ar.take(sizeof(LkJob) * njobs);
+    size_t ocam = c->ar.take(32);
+    size_t oprev = c->ar.take(sizeof(float) * 2 * std::max(total_pts, 1));
+    size_t omp = c->ar.take(std::max(total_pts, 1));
+    size_t oxyz = c->ar.take(sizeof(double) * 3 * std::max(total_pts, 1));
+    size_t opj = c->ar.take(sizeof(PoseJob) * njobs);
+    size_t onext = c->ar.take(sizeof(float) * 2 * std::max(total_pts, 1));
+    size_t in_end = c->ar.off;
+    size_t ostat = c->ar.take(std::max(total_pts, 1));
+    size_t oerr = c->ar.take(sizeof(float) * std::max(total_pts, 1));
+    size_t oval = c->ar.take(std::max(total_pts, 1));
+    size_t oout = c->ar.take(std::max(total_pts, 1));
+    size_t ontr = c->ar.take(sizeof(int) * njobs);
+    LkJob *lj = hp<LkJob>(c, olk);
+    PoseJob *pj = hp<PoseJob>(c, opj);
+    for (int i = 0; i < njobs; ++i) {
+        lj[i].prev_slot = jobs[i].prev_slot; lj[i].next_slot = jobs[i].next_slot;
+        lj[i].pt_ofs = jobs[i].pt_ofs; lj[i].npts = jobs[i].npts;
+        pj[i].pt_ofs = jobs[i].pt_ofs; pj[i].npts = jobs[i].npts;
+        memcpy(pj[i].pose, jobs[i].pose, 56);
+        pj[i].n_inlier = 0; pj[i].pad = 0;
+    }
+    memcpy(hp<void>(c, ocam), cam, 32);
+    if (total_pts > 0) {
+        memcpy(hp<void>(c, oprev), prev_xy, sizeof(float) * 2 * total_pts);
+        memcpy(hp<void>(c, onext), next_xy, sizeof(float) * 2 * total_pts);
+        memcpy(hp<void>(c, omp), has_mp, total_pts);
+        memcpy(hp<void>(c, oxyz), xyz, sizeof(double) * 3 * total_pts);
+    }
+    if (h2d(c, base, in_end)) return -1;
+    if (maxn > 0) {
+        tm_begin(c, FAM_LK, total_pts);
+        hipLaunchKernelGGL(k_lk, dim3(cdiv(maxn, LK_WAVES_PER_BLOCK), njobs), dim3(64 * LK_WAVES_PER_BLOCK), 0,
+                           c->stream, dp<LkJob>(c, olk), c->d_pyr, c->geom, dp<float2>(c, oprev),
+                           dp<float2>(c, onext), dp<uint8_t>(c, ostat), dp<float>(c, oerr), make_lk_params(p));
+        tm_end(c);
+        // status && in image && has map point -> pose-only edge (src/frontend.cpp:361-371, 443-444)
+        hipLaunchKernelGGL(k_track_filter, dim3(njobs), dim3(256), 0, c->stream,
+                           reinterpret_cast<const LkJobView *>(dp<LkJob>(c, olk)), dp<float2>(c, onext),
+                           dp<uint8_t>(c, ostat), dp<uint8_t>(c, omp), dp<uint8_t>(c, oval), dp<int>(c, ontr),
+                           c->geom.w[0], c->geom.h[0]);
+    }
+    tm_begin(c, FAM_POSE, njobs);
+    hipLaunchKernelGGL(k_pose_only, dim3(njobs), dim3(64), 0, c->stream, dp<PoseJob>(c, opj), dp<double>(c, ocam),
+                       dp<double>(c, oxyz), dp<float2>(c, onext), dp<uint8_t>(c, oval), dp<uint8_t>(c, oout),
+                       chi2_th, 4, 10);
+    tm_end(c);
+    HIPCHK(c, hipGetLastError());
+    // readback: pose jobs .. n_tracked (next_xy sits between; one contiguous copy)
+    if (d2h_sync(c, opj, c->ar.off)) return -1;
+    const int *ntr = hp<int>(c, ontr);
+    for (int i = 0; i < njobs; ++i) {
+        memcpy(jobs[i].pose, pj[i].pose, 56);
+        jobs[i].n_inlier = pj[i].n_inlier;
+        jobs[i].n_tracked = maxn > 0 ? ntr[i] : 0;
+    }
+    if (total_pts > 0) {
+        memcpy(next_xy, hp<void>(c, onext), sizeof(float) * 2 * total_pts);
+        memcpy(status, hp<void>(c, ostat), total_pts);
+        memcpy(outlier, hp<void>(c, oout), total_pts);
+    }
+    return 0;
+}
+
+} // extern "C"

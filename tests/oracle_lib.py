@@ -64,9 +64,9 @@ def pyramid(img, max_level=3, win=11):
     for _ in range(max_level):
         h, w = levels[-1].shape
         nw, nh = (w + 1) // 2, (h + 1) // 2
-        levels.append(pyrdown(levels[-1]))
-        if nw <= win or nh <= win:
+        if nw <= win or nh <= win:   # buildOpticalFlowPyramid stops before this level
             break
+        levels.append(pyrdown(levels[-1]))
     return levels
 
 

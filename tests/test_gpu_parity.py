@@ -1,0 +1,246 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the
+same seeded inputs.  Integer / index / f32-declared-order results are bit-exact;
+f64 LM results carry the tolerance written in each test."""
+import numpy as np
+import pytest
+
+import common as cm
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(svs):
+    c = svs.Context(cm.W, cm.H, max_slots=8, max_jobs=8, max_pts=512, max_corners=200, max_kf=10,
+                    max_lm=2048, max_obs=20000)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def frames(svs):
+    return [svs.synth_pair(7, f) for f in range(3)]
+
+
+def test_pyramid_bit_exact(ctx, orc, frames):
+    l0, r0 = frames[0]
+    ctx.pyramid([0, 1], [l0, r0])
+    for slot, img in ((0, l0), (1, r0)):
+        ref = orc.pyramid(img)
+        assert len(ref) == 4
+        for lvl, r in enumerate(ref):
+            got = ctx.pyramid_read(slot, lvl)
+            assert got.shape == r.shape
+            assert np.array_equal(got, r), "level %d differs" % lvl
+
+
+def test_pyramid_decimate_fused(svs, orc):
+    rng = np.random.default_rng(3)
+    full = rng.integers(0, 256, (376, 1241), dtype=np.uint8)
+    c = svs.Context(620, 188, max_slots=2, max_jobs=2, max_kf=0, max_lm=0, max_obs=0)
+    c.pyramid([0], [full], decimate_from=(1241, 376))
+    dec = orc.decimate(full)
+    assert dec.shape == (188, 620)
+    for lvl, r in enumerate(orc.pyramid(dec)):
+        assert np.array_equal(c.pyramid_read(0, lvl), r)
+    c.close()
+
+
+def test_pyramid_small_odd_sizes(svs, orc):
+    rng = np.random.default_rng(4)
+    for (w, h) in ((97, 53), (64, 48), (155, 47)):
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        c = svs.Context(w, h, max_slots=1, max_jobs=1, max_kf=0, max_lm=0, max_obs=0)
+        c.pyramid([0], [img])
+        ref = orc.pyramid(img)
+        for lvl, r in enumerate(ref):
+            assert np.array_equal(c.pyramid_read(0, lvl), r), (w, h, lvl)
+        c.close()
+
+
+def test_lk_stereo_bit_exact(ctx, orc, frames):
+    l0, r0 = frames[0]
+    pts = orc.gftt(l0)
+    assert len(pts) > 100
+    ctx.pyramid([0, 1], [l0, r0])
+    (q, st, err), = ctx.lk([(0, 1, pts, pts)])
+    q_ref, st_ref, err_ref = orc.lk(l0, r0, pts, pts)
+    assert np.array_equal(st, st_ref)
+    assert st.sum() > 100
+    assert np.array_equal(q.view(np.uint32), q_ref.view(np.uint32)), np.abs(q - q_ref).max()
+    assert np.array_equal(err.view(np.uint32), err_ref.view(np.uint32))
+
+
+def test_lk_temporal_random_points_and_borders(ctx, orc, frames):
+    l0, _ = frames[0]
+    l1, _ = frames[1]
+    rng = np.random.default_rng(11)
+    n = 400
+    p = np.stack([rng.uniform(-3, cm.W + 3, n), rng.uniform(-3, cm.H + 3, n)], 1).astype(np.float32)
+    # include exact border / corner points and far-out points (status must be 0, like the oracle)
+    p[:8] = [[0, 0], [cm.W - 1, cm.H - 1], [0.5, 187.5], [619.5, 0.5], [-20, 50], [700, 50], [300, -30], [300, 230]]
+    g = p + rng.normal(0, 3, p.shape).astype(np.float32)
+    ctx.pyramid([2, 3], [l0, l1])
+    (q, st, err), = ctx.lk([(2, 3, p, g)])
+    q_ref, st_ref, err_ref = orc.lk(l0, l1, p, g)
+    assert np.array_equal(st, st_ref)
+    assert np.array_equal(q.view(np.uint32), q_ref.view(np.uint32)), np.abs(q - q_ref).max()
+    assert np.array_equal(err.view(np.uint32), err_ref.view(np.uint32))
+    assert 0 < st.sum() < n
+
+
+def test_lk_batched_jobs_and_empty_job(ctx, orc, frames):
+    l0, r0 = frames[0]
+    l1, r1 = frames[1]
+    ctx.pyramid([0, 1, 2, 3], [l0, r0, l1, r1])
+    a = orc.gftt(l0); b = orc.gftt(l1, max_corners=77)
+    res = ctx.lk([(0, 1, a, a), (2, 3, np.zeros((0, 2), np.float32), np.zeros((0, 2), np.float32)),
+                  (2, 3, b, b), (0, 2, a, a)])
+    for (q, st, err), case in zip(res, ((l0, r0, a), None, (l1, r1, b), (l0, l1, a))):
+        if case is None:
+            assert q.shape[0] == 0
+            continue
+        I, J, pts = case
+        q_ref, st_ref, err_ref = orc.lk(I, J, pts, pts)
+        assert np.array_equal(st, st_ref)
+        assert np.array_equal(q.view(np.uint32), q_ref.view(np.uint32))
+
+
+def test_lk_no_initial_flow_and_params(ctx, orc, svs, frames):
+    l0, _ = frames[0]
+    l1, _ = frames[1]
+    pts = orc.gftt(l0, max_corners=60)
+    ctx.pyramid([0, 1], [l0, l1])
+    for (lvl, it, eps, use) in ((3, 30, 0.01, 0), (2, 5, 0.03, 1), (0, 10, 0.01, 1), (3, 0, 0.01, 1)):
+        (q, st, err), = ctx.lk([(0, 1, pts, pts + 1.5)], params=svs.LkParams(lvl, it, eps, 1e-4, use))
+        q_ref, st_ref, err_ref = orc.lk(l0, l1, pts, pts + 1.5, params=orc.lk_params(lvl, it, eps, 1e-4, use))
+        assert np.array_equal(st, st_ref), (lvl, it, eps, use)
+        assert np.array_equal(q.view(np.uint32), q_ref.view(np.uint32)), (lvl, it, eps, use)
+
+
+def test_gftt_eigmap_bit_exact(ctx, orc, frames):
+    l0, _ = frames[0]
+    ctx.pyramid([0], [l0])
+    e = ctx.gftt_eigmap(0)
+    e_ref = orc.min_eig_map(l0)
+    assert np.array_equal(e.view(np.uint32), e_ref.view(np.uint32)), np.abs(e - e_ref).max()
+
+
+def test_gftt_corners_exact(ctx, orc, frames):
+    l0, _ = frames[0]
+    l1, _ = frames[1]
+    ctx.pyramid([0, 1], [l0, l1])
+    c_ref0 = orc.gftt(l0)
+    # mask around tracked points like DetectFeatures does; float positions, some off-image
+    rng = np.random.default_rng(5)
+    rect = c_ref0[:80] + rng.normal(0, 2, (80, 2)).astype(np.float32)
+    rect[:3] = [[-4.5, 10.5], [cm.W + 3, 100.49], [310.5, cm.H - 0.5]]
+    res = ctx.gftt([(0, None), (1, rect), (0, rect)], max_corners=150)
+    ref = [c_ref0, orc.gftt(l1, rect), orc.gftt(l0, rect)]
+    for got, r in zip(res, ref):
+        assert got.shape == r.shape, (got.shape, r.shape)
+        assert np.array_equal(got, r)
+    # min-distance / count properties
+    d = np.linalg.norm(res[0][:, None] - res[0][None], axis=2) + 1e9 * np.eye(len(res[0]))
+    assert d.min() >= 20 and len(res[0]) <= 150
+
+
+def test_gftt_params_and_flat_image(svs, orc):
+    rng = np.random.default_rng(9)
+    img = cm.textured(rng, 96, 128)
+    c = svs.Context(128, 96, max_slots=2, max_jobs=2, max_corners=1024, max_kf=0, max_lm=0, max_obs=0)
+    flat = np.full((96, 128), 77, np.uint8)
+    c.pyramid([0, 1], [img, flat])
+    for (mc, q, md) in ((50, 0.01, 10.0), (1024, 0.001, 3.0), (300, 0.05, 1.0), (40, 0.01, 0.0)):
+        got, got_flat = c.gftt([(0, None), (1, None)], max_corners=mc, quality=q, min_dist=md)
+        assert np.array_equal(got, orc.gftt(img, None, mc, q, md)), (mc, q, md)
+        assert len(got_flat) == 0
+    c.close()
+
+
+def test_triangulate(ctx, orc, frames):
+    l0, r0 = frames[0]
+    pts = orc.gftt(l0)
+    q, st, _ = orc.lk(l0, r0, pts, pts)
+    m = st > 0
+    T = cm.random_pose(np.random.default_rng(1))
+    jobs = [(pts[m], q[m], None, 0.0), (pts[m][:50], q[m][:50], T, 30.0)]
+    res = ctx.triangulate(jobs, cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R)
+    for (xyz, ok), (ul, ur, Tj, zmax) in zip(res, jobs):
+        xyz_ref, ok_ref = orc.triangulate(cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R, ul, ur, Tj, zmax)
+        assert np.array_equal(ok, ok_ref)
+        # f64, same algorithm: relative 1e-9
+        assert np.allclose(xyz, xyz_ref, rtol=1e-9, atol=1e-9)
+    assert res[0][1].sum() > 80
+
+
+def _pose_problem(rng, n, noise=0.5, outliers=0.1):
+    P = np.stack([rng.uniform(-8, 8, n), rng.uniform(-3, 1.5, n), rng.uniform(5, 50, n)], 1)
+    T_true = cm.random_pose(rng, 0.6, 0.03)
+    uv, _ = cm.project(cm.CAM, T_true, cm.EXT_L, P)
+    uv += rng.normal(0, noise, uv.shape)
+    k = rng.random(n) < outliers
+    uv[k] += rng.normal(0, 30, (int(k.sum()), 2))
+    return T_true, P, uv.astype(np.float32)
+
+
+def test_pose_only(ctx, orc):
+    rng = np.random.default_rng(21)
+    jobs, truths = [], []
+    for n in (230, 64, 5, 0, 400):
+        T_true, P, uv = _pose_problem(rng, n)
+        jobs.append((cm.EXT_L.copy(), P, uv)); truths.append(T_true)
+    res = ctx.pose_only(jobs, cm.CAM)
+    for (T, outl, ninl), (T0, P, uv), T_true in zip(res, jobs, truths):
+        T_ref, outl_ref, ninl_ref = orc.pose_only(cm.CAM, T0, P, uv)
+        # tolerance: translation 1e-6 m, rotation 1e-7 rad vs the oracle
+        assert np.allclose(T[4:], T_ref[4:], atol=1e-6), np.abs(T - T_ref).max()
+        assert np.allclose(T[:4], T_ref[:4], atol=1e-7)
+        assert np.array_equal(outl, outl_ref)
+        assert ninl == ninl_ref
+        if len(P) >= 64:
+            assert np.linalg.norm(T[4:] - T_true[4:]) < 0.05
+
+
+def test_local_ba(ctx, orc):
+    rng = np.random.default_rng(33)
+    probs = [cm.make_ba_problem(rng, 7, 300), cm.make_ba_problem(rng, 10, 1200), cm.make_ba_problem(rng, 3, 40)]
+    jobs = [(p["poses0"], p["pts0"], p["okf"], p["olm"], p["ori"], p["ouv"]) for p in probs]
+    res = ctx.local_ba(jobs, cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R)
+    for (poses, pts, chi2, it), p, job in zip(res, probs, jobs):
+        poses_a, pts_a, chi2_a, it_a = orc.local_ba(cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R, *job, jac_mode=0)
+        # vs the oracle with analytic Jacobians: 1e-6 m / 1e-7 rad / rel 1e-6
+        assert it == it_a
+        assert np.allclose(poses[:, 4:], poses_a[:, 4:], atol=1e-6), np.abs(poses - poses_a).max()
+        assert np.allclose(poses[:, :4], poses_a[:, :4], atol=1e-7)
+        assert np.allclose(pts, pts_a, rtol=1e-6, atol=1e-6)
+        assert np.allclose(chi2, chi2_a, rtol=1e-5, atol=1e-6)
+        # vs the reference-faithful numeric-Jacobian oracle (g2o central differences): 1e-4 rel
+        poses_n, pts_n, chi2_n, _ = orc.local_ba(cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R, *job, jac_mode=1)
+        assert np.allclose(poses, poses_n, atol=1e-4)
+        assert np.allclose(pts, pts_n, rtol=1e-4, atol=1e-4)
+        # the optimisation actually reduced the error
+        inl = chi2 < 5.991
+        assert inl.mean() > 0.85
+
+
+def test_track_fused_matches_separate_calls(ctx, orc, frames):
+    l0, r0 = frames[0]
+    l1, _ = frames[1]
+    pts = orc.gftt(l0)
+    q, st, _ = orc.lk(l0, r0, pts, pts)
+    xyz, ok = orc.triangulate(cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R, pts, q)
+    has_mp = ((st > 0) & (ok > 0)).astype(np.uint8)
+    ctx.pyramid([0], [l0])
+    (r,) = ctx.track([(0, 1, l1, cm.EXT_L.copy(), pts, pts, has_mp, xyz)], cm.CAM)
+    q1, st1, _ = orc.lk(l0, l1, pts, pts)
+    inb = (q1[:, 0] >= 0) & (q1[:, 0] < cm.W) & (q1[:, 1] >= 0) & (q1[:, 1] < cm.H)
+    keep = (st1 > 0) & inb
+    assert np.array_equal(r["status"], keep.astype(np.uint8))
+    assert np.array_equal(r["next_xy"].view(np.uint32), q1.view(np.uint32))
+    e = keep & (has_mp > 0)
+    T_ref, outl_ref, ninl_ref = orc.pose_only(cm.CAM, cm.EXT_L, xyz[e], q1[e])
+    assert r["n_tracked"] == keep.sum()
+    assert r["n_inlier"] == ninl_ref
+    assert np.allclose(r["pose"], T_ref, atol=1e-6)
+    assert np.array_equal(r["outlier"][e], outl_ref)
