@@ -1,0 +1,55 @@
+// kernels_hip.h — kernel provider of the product build: every call goes straight
+// through the C ABI of libsvslam_hip.so (include/svslam.h).  No CPU path.
+#pragma once
+#include <stdexcept>
+#include <string>
+#include "../../include/svslam.h"
+
+namespace svs {
+
+class HipKernels {
+public:
+    explicit HipKernels(const svslam_limits &lim)
+    {
+        int rc = svslam_create(&lim, &ctx_);
+        if (rc != 0) {
+            std::string msg = ctx_ ? svslam_last_error(ctx_) : "no usable HIP device (libsvslam_hip has no CPU path)";
+            if (ctx_) svslam_destroy(ctx_);
+            ctx_ = nullptr;
+            throw std::runtime_error("svslam_create failed: " + msg);
+        }
+    }
+    ~HipKernels() { if (ctx_) svslam_destroy(ctx_); }
+    HipKernels(const HipKernels &) = delete;
+    HipKernels &operator=(const HipKernels &) = delete;
+
+    svslam_ctx *ctx() { return ctx_; }
+    const char *last_error() { return svslam_last_error(ctx_); }
+
+    int pyramid(int n, const int *slots, const void *const *imgs, const int *strides, int is_device)
+    { return svslam_pyramid_batch(ctx_, n, slots, imgs, strides, is_device); }
+    int track(int n, svslam_track_job *jobs, const void *const *imgs, const int *strides, int is_device,
+              int total, const double *cam, const float *prev_xy, float *next_xy, const uint8_t *has_mp,
+              const double *xyz, uint8_t *status, uint8_t *outlier, const svslam_lk_params *p, double chi2_th)
+    { return svslam_track_batch(ctx_, n, jobs, imgs, strides, is_device, total, cam, prev_xy, next_xy, has_mp, xyz, status, outlier, p, chi2_th); }
+    int lk(int n, const svslam_lk_job *jobs, int total, const float *prev_xy, float *next_xy, uint8_t *status,
+           float *err, const svslam_lk_params *p)
+    { return svslam_lk_batch(ctx_, n, jobs, total, prev_xy, next_xy, status, err, p); }
+    int gftt(int n, const svslam_gftt_job *jobs, int total_rects, const float *rect_xy, int max_corners,
+             double quality, double min_dist, float *out_xy, int *out_n)
+    { return svslam_gftt_batch(ctx_, n, jobs, total_rects, rect_xy, max_corners, quality, min_dist, out_xy, out_n); }
+    int triangulate(int n, const svslam_tri_job *jobs, int total, const double *cam_l, const double *ext_l,
+                    const double *cam_r, const double *ext_r, const float *uv_l, const float *uv_r,
+                    double *xyz, uint8_t *ok)
+    { return svslam_triangulate_batch(ctx_, n, jobs, total, cam_l, ext_l, cam_r, ext_r, uv_l, uv_r, xyz, ok); }
+    int local_ba(int n, svslam_ba_job *jobs, const double *cam_l, const double *ext_l, const double *cam_r,
+                 const double *ext_r, int total_kf, double *poses, int total_lm, double *pts, int total_obs,
+                 const int *okf, const int *olm, const uint8_t *oright, const float *ouv, double delta,
+                 int iters, double *chi2)
+    { return svslam_local_ba_batch(ctx_, n, jobs, cam_l, ext_l, cam_r, ext_r, total_kf, poses, total_lm, pts, total_obs, okf, olm, oright, ouv, delta, iters, chi2); }
+
+private:
+    svslam_ctx *ctx_ = nullptr;
+};
+
+} // namespace svs

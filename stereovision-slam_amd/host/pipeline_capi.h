@@ -1,0 +1,48 @@
+// pipeline_capi.h — C entry points of the host pipeline, shared by the product
+// build (pipeline_capi.cpp, bound to libsvslam_hip.so) and by the CPU twin that
+// the oracle directory builds for tests / the cpu_baseline leg.
+#pragma once
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct svs_pipe_config {
+    int num_features, num_features_init, num_features_tracking, num_features_tracking_bad;
+    int num_features_needed_for_keyframe;
+    double max_triangulation_depth;
+    int num_active_keyframes, backend_on;
+    double chi2_th;
+    int width, height;
+    double cam_l[4], ext_l[7], cam_r[4], ext_r[7];
+    int max_lm, max_obs;      /* BA limits per problem */
+} svs_pipe_config;
+
+typedef struct svs_frame_result {
+    double pose[7];
+    int status, is_keyframe, n_features, n_inliers;
+    long long frame_id, keyframe_id;
+} svs_frame_result;
+
+typedef struct svs_pipe_counters {
+    long long frames, keyframes, track_pts, pose_edges, gftt_calls, gftt_rects, corners, right_pts, tri_pts;
+    long long ba_calls, ba_edges, ba_kf, ba_lm, ba_iters, pyr_left, pyr_right;
+} svs_pipe_counters;
+
+void *svs_pipe_create(const svs_pipe_config *cfg, int nstreams, int device);
+void svs_pipe_destroy(void *p);
+const char *svs_pipe_last_error(void);
+/* one frame for every stream; left/right: nstreams image pointers (host or device) */
+int svs_pipe_step(void *p, const void *const *left, const void *const *right, int is_device,
+                  svs_frame_result *out);
+/* run `nframes` steps over device-resident sequences laid out [stream][frame][h*w]
+ * (left and right), writing results [frame][stream]; the whole loop stays in C++ */
+int svs_pipe_run_device(void *p, const void *left_base, const void *right_base, long long stream_stride,
+                        long long frame_stride, int first_frame, int nframes, svs_frame_result *out);
+int svs_pipe_counters_get(void *p, svs_pipe_counters *out);
+/* underlying svslam_ctx (product build) or NULL (CPU twin) */
+void *svs_pipe_kernel_ctx(void *p);
+
+#ifdef __cplusplus
+}
+#endif

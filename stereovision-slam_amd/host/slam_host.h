@@ -1,0 +1,665 @@
+// slam_host.h — host side of the drop-in: the reference's Frontend / Backend /
+// Map / Frame / Feature / MapPoint logic restated over flat arrays and staged so
+// that S independent streams advance in lockstep and every library call site of
+// the reference becomes ONE batched C-ABI call for all streams.
+//
+// Mirrors (file:line into the reference):
+//   Frontend::AddFrame/Track/StereoInit/...      src/frontend.cpp:143-721
+//   Backend::Optimize gather / scatter           src/backend.cpp:39-246
+//   Map::InsertKeyFrame/RemoveOldKeyframe/CleanMap  src/map.cpp:21-181
+//   MapPoint::AddObservation/RemoveObservation   src/mappoint.cpp:22-78
+//   Frame / Feature id factories                 src/frame.cpp:22-35
+// Differences, all deliberate: the pointer graph (shared_ptr /
+// weak_ptr) is replaced by indices; unordered_map iteration is replaced by
+// ascending-id order; BA runs synchronously inside UpdateMap() (the reference's
+// free-running backend thread makes it nondeterministic); viewer and
+// loop closure are off.
+//
+// The kernel provider K exposes the batched entry points of include/svslam.h;
+// this header never names an implementation.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/svslam.h"
+#include "se3.h"
+
+namespace svs {
+
+struct Config {                       // config/stereo_slam_configs/config-00.yaml
+    int num_features = 150;
+    int num_features_init = 50;
+    int num_features_tracking = 50;
+    int num_features_tracking_bad = 20;
+    int num_features_needed_for_keyframe = 80;
+    double max_triangulation_depth = 300.0;
+    int num_active_keyframes = 10;
+    int backend_on = 1;
+    double chi2_th = 5.991;
+    int width = 620, height = 188;
+    Camera cam_l, cam_r;
+};
+
+enum class FrontendStatus { INITING = 0, TRACKING_GOOD = 1, TRACKING_BAD = 2, LOST = 3 };
+
+struct Feature {
+    float x = 0, y = 0;
+    long mp = -1;        // map point id, -1 == expired weak_ptr
+    bool outlier = false;
+};
+
+struct Frame {
+    long id = 0;
+    long keyframe_id = 0;
+    bool is_keyframe = false;
+    SE3 pose;                         // T_cw
+    std::vector<Feature> left, right; // right[i] pairs with left[i]
+    std::vector<uint8_t> right_ok;    // 0 == nullptr in the reference
+    Frame *prev_keyframe = nullptr;
+    SE3 relative_pose_pkf;
+};
+
+struct ObsRef {
+    Frame *frame;
+    int idx;
+    bool is_left;
+    bool operator==(const ObsRef &o) const { return frame == o.frame && idx == o.idx && is_left == o.is_left; }
+};
+
+struct MapPoint {
+    long id = 0;
+    double pos[3] = { 0, 0, 0 };
+    bool is_outlier = false;
+    int observed_times = 0;
+    std::vector<ObsRef> observations;
+};
+
+inline Feature &feat_of(const ObsRef &r) { return r.is_left ? r.frame->left[r.idx] : r.frame->right[r.idx]; }
+
+// ------------------------------------------------------------------ Map
+class Map {
+public:
+    explicit Map(int num_active) : num_active_keyframes_(num_active) {}
+
+    MapPoint *CreateNewMappoint()       // src/mappoint.cpp:88-98 (per-stream factory)
+    {
+        store_.emplace_back();
+        store_.back().id = mp_factory_id_++;
+        return &store_.back();
+    }
+    MapPoint *point(long id) { return id >= 0 ? &store_[(size_t)id] : nullptr; }
+
+    void InsertMapPoint(MapPoint *mp)   // src/map.cpp:69-74
+    {
+        landmarks_[mp->id] = mp;
+        active_landmarks_[mp->id] = mp;
+    }
+    void InsertKeyFrame(Frame *frame)   // src/map.cpp:53-67
+    {
+        current_frame_ = frame;
+        keyframes_[frame->keyframe_id] = frame;
+        active_keyframes_[frame->keyframe_id] = frame;
+        if ((int)active_keyframes_.size() > num_active_keyframes_) RemoveOldKeyframe();
+    }
+    void AddObservation(MapPoint *mp, const ObsRef &f)   // src/mappoint.cpp:22-36
+    {
+        mp->observations.push_back(f);
+        mp->observed_times++;
+    }
+    void RemoveObservation(MapPoint *mp, const ObsRef &f) // src/mappoint.cpp:38-78
+    {
+        for (size_t i = 0; i < mp->observations.size(); ++i) {
+            if (mp->observations[i] == f) {
+                mp->observations.erase(mp->observations.begin() + (long)i);
+                Feature &ft = feat_of(f);
+                if (ft.outlier) ft.mp = -1;
+                mp->observed_times--;
+                break;
+            }
+        }
+    }
+    void CleanMap()                     // src/map.cpp:21-40
+    {
+        for (auto it = active_landmarks_.begin(); it != active_landmarks_.end();) {
+            if (it->second->observed_times == 0) it = active_landmarks_.erase(it);
+            else ++it;
+        }
+    }
+    void RemoveOldKeyframe()            // src/map.cpp:76-181
+    {
+        if (!current_frame_) return;
+        double max_dis = 0, min_dis = 999999;
+        long max_kf_id = 0, min_kf_id = 0;
+        SE3 Twc = current_frame_->pose.inverse();
+        for (auto &kf : active_keyframes_) {
+            if (kf.second == current_frame_) continue;
+            double dis = (kf.second->pose * Twc).log_norm();
+            if (dis > max_dis) { max_dis = dis; max_kf_id = kf.first; }
+            if (dis < min_dis) { min_dis = dis; min_kf_id = kf.first; }
+        }
+        const double min_dis_th = 0.2;
+        Frame *rm = (min_dis < min_dis_th) ? active_keyframes_.at(min_kf_id) : active_keyframes_.at(max_kf_id);
+        active_keyframes_.erase(rm->keyframe_id);
+        for (size_t i = 0; i < rm->left.size(); ++i)
+            if (rm->left[i].mp >= 0) RemoveObservation(point(rm->left[i].mp), ObsRef{ rm, (int)i, true });
+        for (size_t i = 0; i < rm->right.size(); ++i) {
+            if (!rm->right_ok[i]) continue;
+            if (rm->right[i].mp >= 0) RemoveObservation(point(rm->right[i].mp), ObsRef{ rm, (int)i, false });
+        }
+        CleanMap();
+    }
+
+    std::map<long, Frame *> keyframes_, active_keyframes_;
+    std::map<long, MapPoint *> landmarks_, active_landmarks_;
+
+private:
+    std::deque<MapPoint> store_;
+    long mp_factory_id_ = 0;
+    Frame *current_frame_ = nullptr;
+    int num_active_keyframes_;
+};
+
+// ------------------------------------------------------------------ per-stream state
+struct FrameResult {
+    double pose[7];
+    int status;
+    int is_keyframe;
+    int n_features;
+    int n_inliers;
+    long frame_id;
+    long keyframe_id;
+};
+
+struct Counters {                      // workload accounting for the roofline
+    long long frames = 0, keyframes = 0;
+    long long track_pts = 0, pose_edges = 0;
+    long long gftt_calls = 0, gftt_rects = 0, corners = 0;
+    long long right_pts = 0, tri_pts = 0;
+    long long ba_calls = 0, ba_edges = 0, ba_kf = 0, ba_lm = 0, ba_iters = 0;
+    long long pyr_left = 0, pyr_right = 0;
+};
+
+struct Stream {
+    explicit Stream(const Config &c) : map(c.num_active_keyframes) {}
+    Map map;
+    FrontendStatus status = FrontendStatus::INITING;
+    Frame *current = nullptr, *last = nullptr;
+    std::unique_ptr<Frame> cur_owned, last_owned;       // non-keyframes
+    std::vector<std::unique_ptr<Frame>> kf_store;        // keyframes live forever (Map::keyframes_)
+    SE3 relative_motion;
+    int tracking_inliers = 0;
+    Frame *frontend_current_kf = nullptr, *frontend_prev_kf = nullptr;
+    long frame_factory_id = 0, kf_factory_id = 0;
+    int slot_prev = 0, slot_cur = 1, slot_right = 2;
+    bool is_new_kf = false, init_ok = false;
+    // scratch between stages
+    std::vector<int> edge_feat;        // pose-only edge -> current left feature index
+    int n_before_detect = 0;
+};
+
+// BA job bookkeeping between gather and scatter
+struct BaGather {
+    std::vector<Frame *> kfs;
+    std::vector<MapPoint *> lms;
+    std::vector<ObsRef> edge_feat;
+};
+
+// ------------------------------------------------------------------ the staged pipeline
+template <class K>
+class Pipeline {
+public:
+    Pipeline(const Config &cfg, K &kernels, int nstreams) : cfg_(cfg), k_(kernels)
+    {
+        for (int s = 0; s < nstreams; ++s) {
+            streams_.emplace_back(new Stream(cfg));
+            streams_.back()->slot_prev = 3 * s;
+            streams_.back()->slot_cur = 3 * s + 1;
+            streams_.back()->slot_right = 3 * s + 2;
+        }
+        cfg_.cam_l.k4(cam_l_); cfg_.cam_r.k4(cam_r_);
+    }
+    int nstreams() const { return (int)streams_.size(); }
+    const Counters &counters() const { return cnt_; }
+    Stream &stream(int s) { return *streams_[s]; }
+
+    // Frontend::AddFrame for every stream (src/frontend.cpp:690-721), in lockstep.
+    // left/right: one image pointer per stream (host or device memory).
+    void step(const void *const *left, const void *const *right, const int *strides, int is_device,
+              FrameResult *out)
+    {
+        const int S = nstreams();
+        std::vector<int> TS, IS, KS;
+        for (int s = 0; s < S; ++s) {
+            Stream &st = *streams_[s];
+            // Frame::CreateFrame (src/frame.cpp:22-28)
+            st.cur_owned.reset(new Frame());
+            st.current = st.cur_owned.get();
+            st.current->id = st.frame_factory_id++;
+            st.is_new_kf = false; st.init_ok = false;
+            std::swap(st.slot_prev, st.slot_cur);   // last frame's pyramid becomes "prev"
+            if (st.status == FrontendStatus::INITING) IS.push_back(s);
+            else if (st.status == FrontendStatus::LOST) { /* Reset(): not implemented upstream */ }
+            else TS.push_back(s);
+        }
+        cnt_.frames += S;
+        if (!TS.empty()) {
+            TrackPrepareAndRun(TS, left, strides, is_device);
+            for (int s : TS) if (TrackFinish(s)) KS.push_back(s);
+        }
+        std::vector<int> DS = IS;                 // streams that detect this frame
+        DS.insert(DS.end(), KS.begin(), KS.end());
+        if (!DS.empty()) {
+            BuildPyramids(IS, DS, left, right, strides, is_device);
+            DetectFeatures(DS);
+            FindFeaturesInRight(DS);
+            std::vector<int> MS;                  // streams that triangulate + BA
+            for (int s : IS) {
+                Stream &st = *streams_[s];
+                int good = 0;
+                for (uint8_t ok : st.current->right_ok) good += ok ? 1 : 0;
+                if (good >= cfg_.num_features_init) { st.init_ok = true; MS.push_back(s); }
+            }
+            MS.insert(MS.end(), KS.begin(), KS.end());
+            if (!MS.empty()) {
+                Triangulate(MS);
+                if (cfg_.backend_on) RunBackend(MS);
+            }
+        }
+        for (int s : TS) {
+            Stream &st = *streams_[s];
+            // src/frontend.cpp:685
+            st.relative_motion = st.current->pose * st.last->pose.inverse();
+        }
+        for (int s = 0; s < S; ++s) {
+            Stream &st = *streams_[s];
+            FrameResult &r = out[s];
+            std::memcpy(r.pose, st.current->pose.v, sizeof(r.pose));
+            r.status = (int)st.status;
+            r.is_keyframe = st.current->is_keyframe ? 1 : 0;
+            r.n_features = (int)st.current->left.size();
+            r.n_inliers = st.tracking_inliers;
+            r.frame_id = st.current->id;
+            r.keyframe_id = st.current->is_keyframe ? st.current->keyframe_id : -1;
+            // last_frame_ = current_frame_ (src/frontend.cpp:718)
+            st.last = st.current;
+            st.last_owned = std::move(st.cur_owned);   // null if the frame moved into kf_store
+        }
+    }
+
+private:
+    void check(int rc, const char *what)
+    {
+        if (rc != 0) throw std::runtime_error(std::string(what) + " failed: " + k_.last_error());
+    }
+
+    // ---- Track(): constant-velocity prior + TrackLastFrame + EstimateCurrentPose
+    void TrackPrepareAndRun(const std::vector<int> &TS, const void *const *left, const int *strides, int is_device)
+    {
+        const int n = (int)TS.size();
+        jobs_track_.resize(n);
+        prev_xy_.clear(); next_xy_.clear(); has_mp_.clear(); xyz_.clear();
+        imgs_.resize(n); strides_.resize(n);
+        int ofs = 0;
+        for (int i = 0; i < n; ++i) {
+            Stream &st = *streams_[TS[i]];
+            Frame *cur = st.current, *last = st.last;
+            cur->pose = st.relative_motion * last->pose;            // :655
+            svslam_track_job &j = jobs_track_[i];
+            j.prev_slot = st.slot_prev; j.next_slot = st.slot_cur;
+            j.pt_ofs = ofs; j.npts = (int)last->left.size();
+            std::memcpy(j.pose, cur->pose.v, sizeof(j.pose));
+            j.n_tracked = 0; j.n_inlier = 0;
+            for (const Feature &f : last->left) {                   // :331-347
+                prev_xy_.push_back(f.x); prev_xy_.push_back(f.y);
+                MapPoint *mp = st.map.point(f.mp);
+                if (mp) {
+                    double uv[2];
+                    cfg_.cam_l.world2pixel(mp->pos, cur->pose, uv);
+                    next_xy_.push_back((float)uv[0]); next_xy_.push_back((float)uv[1]);
+                    has_mp_.push_back(1);
+                    xyz_.push_back(mp->pos[0]); xyz_.push_back(mp->pos[1]); xyz_.push_back(mp->pos[2]);
+                } else {
+                    next_xy_.push_back(f.x); next_xy_.push_back(f.y);
+                    has_mp_.push_back(0);
+                    xyz_.push_back(0); xyz_.push_back(0); xyz_.push_back(1);
+                }
+            }
+            ofs += j.npts;
+            imgs_[i] = left[TS[i]];
+            strides_[i] = strides ? strides[TS[i]] : cfg_.width;
+        }
+        status_.assign((size_t)std::max(ofs, 1), 0);
+        outlier_.assign((size_t)std::max(ofs, 1), 0);
+        if (prev_xy_.empty()) { prev_xy_.resize(2); next_xy_.resize(2); has_mp_.resize(1); xyz_.resize(3); }
+        svslam_lk_params prm = { 3, 30, 0.01, 1e-4, 1 };            // :353-357
+        check(k_.track(n, jobs_track_.data(), imgs_.data(), strides_.data(), is_device, ofs, cam_l_,
+                       prev_xy_.data(), next_xy_.data(), has_mp_.data(), xyz_.data(), status_.data(),
+                       outlier_.data(), &prm, 5.991), "track");
+        cnt_.track_pts += ofs; cnt_.pyr_left += n;
+        track_order_ = TS;
+    }
+
+    // returns true if the frame became a keyframe
+    bool TrackFinish(int s)
+    {
+        Stream &st = *streams_[s];
+        int i = (int)(std::find(track_order_.begin(), track_order_.end(), s) - track_order_.begin());
+        const svslam_track_job &j = jobs_track_[i];
+        Frame *cur = st.current, *last = st.last;
+        // TrackLastFrame :361-381 (status already includes the in-image test)
+        int n_edges = 0, n_outlier = 0;
+        for (int p = 0; p < j.npts; ++p) {
+            const int g = j.pt_ofs + p;
+            if (!status_[g]) continue;
+            Feature f;
+            f.x = next_xy_[2 * g]; f.y = next_xy_[2 * g + 1];
+            f.mp = last->left[p].mp;
+            // EstimateCurrentPose :546-553: outliers lose their map point
+            if (f.mp >= 0) {
+                ++n_edges;
+                if (outlier_[g]) { f.mp = -1; ++n_outlier; }
+            }
+            cur->left.push_back(f);
+        }
+        cnt_.pose_edges += n_edges;
+        cur->pose = SE3(j.pose);                                   // :542
+        st.tracking_inliers = n_edges - n_outlier;                 // :556
+        if (st.tracking_inliers > cfg_.num_features_tracking) st.status = FrontendStatus::TRACKING_GOOD;
+        else if (st.tracking_inliers > cfg_.num_features_tracking_bad) st.status = FrontendStatus::TRACKING_BAD;
+        else st.status = FrontendStatus::LOST;                     // :665-679
+        // InsertKeyframe :576-616
+        if (st.tracking_inliers >= cfg_.num_features_needed_for_keyframe) return false;
+        MakeKeyFrame(st);
+        st.frontend_prev_kf = st.frontend_current_kf;
+        st.frontend_current_kf = cur;
+        cur->prev_keyframe = st.frontend_prev_kf;
+        cur->relative_pose_pkf = cur->pose * st.frontend_prev_kf->pose.inverse();
+        // SetObservationsForKeyFrame :560-574
+        for (size_t k = 0; k < cur->left.size(); ++k)
+            if (cur->left[k].mp >= 0) st.map.AddObservation(st.map.point(cur->left[k].mp), ObsRef{ cur, (int)k, true });
+        st.is_new_kf = true;
+        return true;
+    }
+
+    void MakeKeyFrame(Stream &st)
+    {
+        Frame *cur = st.current;
+        cur->is_keyframe = true;                                   // Frame::SetKeyFrame
+        cur->keyframe_id = st.kf_factory_id++;
+        st.kf_store.push_back(std::move(st.cur_owned));            // Map::keyframes_ keeps it alive
+        st.map.InsertKeyFrame(cur);
+        cnt_.keyframes++;
+    }
+
+    void BuildPyramids(const std::vector<int> &IS, const std::vector<int> &DS, const void *const *left,
+                       const void *const *right, const int *strides, int is_device)
+    {
+        std::vector<int> slots; imgs_.clear(); strides_.clear();
+        for (int s : IS) {
+            slots.push_back(streams_[s]->slot_cur); imgs_.push_back(left[s]);
+            strides_.push_back(strides ? strides[s] : cfg_.width);
+        }
+        for (int s : DS) {
+            slots.push_back(streams_[s]->slot_right); imgs_.push_back(right[s]);
+            strides_.push_back(strides ? strides[s] : cfg_.width);
+        }
+        check(k_.pyramid((int)slots.size(), slots.data(), imgs_.data(), strides_.data(), is_device), "pyramid");
+        cnt_.pyr_left += (long long)IS.size(); cnt_.pyr_right += (long long)DS.size();
+    }
+
+    // Frontend::DetectFeatures :36-70
+    void DetectFeatures(const std::vector<int> &DS)
+    {
+        const int n = (int)DS.size();
+        jobs_gftt_.resize(n);
+        rects_.clear();
+        int ofs = 0;
+        for (int i = 0; i < n; ++i) {
+            Stream &st = *streams_[DS[i]];
+            jobs_gftt_[i].slot = st.slot_cur;
+            jobs_gftt_[i].rect_ofs = ofs;
+            jobs_gftt_[i].nrect = (int)st.current->left.size();
+            for (const Feature &f : st.current->left) { rects_.push_back(f.x); rects_.push_back(f.y); }
+            ofs += jobs_gftt_[i].nrect;
+            st.n_before_detect = (int)st.current->left.size();
+        }
+        if (rects_.empty()) rects_.resize(2);
+        corners_.assign((size_t)n * cfg_.num_features * 2, 0.f);
+        ncorners_.assign((size_t)n, 0);
+        check(k_.gftt(n, jobs_gftt_.data(), ofs, rects_.data(), cfg_.num_features, 0.01, 20.0, corners_.data(),
+                      ncorners_.data()), "gftt");                  // :24
+        for (int i = 0; i < n; ++i) {
+            Stream &st = *streams_[DS[i]];
+            for (int c = 0; c < ncorners_[i]; ++c) {
+                Feature f;
+                f.x = corners_[((size_t)i * cfg_.num_features + c) * 2];
+                f.y = corners_[((size_t)i * cfg_.num_features + c) * 2 + 1];
+                st.current->left.push_back(f);
+            }
+            cnt_.corners += ncorners_[i];
+        }
+        cnt_.gftt_calls += n; cnt_.gftt_rects += ofs;
+    }
+
+    // Frontend::FindFeaturesInRight :72-141
+    void FindFeaturesInRight(const std::vector<int> &DS)
+    {
+        const int n = (int)DS.size();
+        jobs_lk_.resize(n);
+        prev_xy_.clear(); next_xy_.clear();
+        int ofs = 0;
+        for (int i = 0; i < n; ++i) {
+            Stream &st = *streams_[DS[i]];
+            Frame *cur = st.current;
+            jobs_lk_[i].prev_slot = st.slot_cur; jobs_lk_[i].next_slot = st.slot_right;
+            jobs_lk_[i].pt_ofs = ofs; jobs_lk_[i].npts = (int)cur->left.size();
+            for (const Feature &f : cur->left) {
+                prev_xy_.push_back(f.x); prev_xy_.push_back(f.y);
+                MapPoint *mp = st.map.point(f.mp);
+                if (mp) {
+                    double uv[2];
+                    cfg_.cam_r.world2pixel(mp->pos, cur->pose, uv);
+                    next_xy_.push_back((float)uv[0]); next_xy_.push_back((float)uv[1]);
+                } else { next_xy_.push_back(f.x); next_xy_.push_back(f.y); }
+            }
+            ofs += jobs_lk_[i].npts;
+        }
+        status_.assign((size_t)std::max(ofs, 1), 0);
+        err_.assign((size_t)std::max(ofs, 1), 0.f);
+        if (prev_xy_.empty()) { prev_xy_.resize(2); next_xy_.resize(2); }
+        svslam_lk_params prm = { 3, 30, 0.01, 1e-4, 1 };            // :105-109
+        check(k_.lk(n, jobs_lk_.data(), ofs, prev_xy_.data(), next_xy_.data(), status_.data(), err_.data(), &prm), "lk");
+        for (int i = 0; i < n; ++i) {
+            Stream &st = *streams_[DS[i]];
+            Frame *cur = st.current;
+            cur->right.assign(cur->left.size(), Feature());
+            cur->right_ok.assign(cur->left.size(), 0);
+            for (int p = 0; p < jobs_lk_[i].npts; ++p) {
+                const int g = jobs_lk_[i].pt_ofs + p;
+                const float x = next_xy_[2 * g], y = next_xy_[2 * g + 1];
+                if (status_[g] && y >= 0 && y < (float)cfg_.height && x >= 0 && x < (float)cfg_.width) {  // :115-118
+                    cur->right[p].x = x; cur->right[p].y = y;
+                    cur->right_ok[p] = 1;
+                }
+            }
+        }
+        cnt_.right_pts += ofs;
+    }
+
+    // BuildInitMap :143-214 / TriangulateNewPoints :251-320
+    void Triangulate(const std::vector<int> &MS)
+    {
+        const int n = (int)MS.size();
+        jobs_tri_.resize(n);
+        uv_l_.clear(); uv_r_.clear(); tri_idx_.clear();
+        int ofs = 0;
+        for (int i = 0; i < n; ++i) {
+            Stream &st = *streams_[MS[i]];
+            Frame *cur = st.current;
+            const bool init = !st.is_new_kf;
+            svslam_tri_job &j = jobs_tri_[i];
+            j.pt_ofs = ofs; j.npts = 0;
+            SE3 Twc = init ? SE3() : cur->pose.inverse();           // :261
+            std::memcpy(j.T_wc, Twc.v, sizeof(j.T_wc));
+            j.zmax = init ? 0.0 : cfg_.max_triangulation_depth;     // :174 vs :286-288
+            for (size_t p = 0; p < cur->left.size(); ++p) {
+                if (!cur->right_ok[p]) continue;
+                if (!init && cur->left[p].mp >= 0) continue;        // :272
+                uv_l_.push_back(cur->left[p].x); uv_l_.push_back(cur->left[p].y);
+                uv_r_.push_back(cur->right[p].x); uv_r_.push_back(cur->right[p].y);
+                tri_idx_.push_back((int)p);
+                ++j.npts;
+            }
+            ofs += j.npts;
+        }
+        tri_xyz_.assign((size_t)std::max(ofs, 1) * 3, 0.0);
+        tri_ok_.assign((size_t)std::max(ofs, 1), 0);
+        if (ofs > 0)
+            check(k_.triangulate(n, jobs_tri_.data(), ofs, cam_l_, cfg_.cam_l.pose.v, cam_r_, cfg_.cam_r.pose.v,
+                                 uv_l_.data(), uv_r_.data(), tri_xyz_.data(), tri_ok_.data()), "triangulate");
+        cnt_.tri_pts += ofs;
+        for (int i = 0; i < n; ++i) {
+            Stream &st = *streams_[MS[i]];
+            Frame *cur = st.current;
+            const bool init = !st.is_new_kf;
+            for (int q = 0; q < jobs_tri_[i].npts; ++q) {
+                const int g = jobs_tri_[i].pt_ofs + q;
+                if (!tri_ok_[g]) continue;
+                const int p = tri_idx_[g];
+                MapPoint *mp = st.map.CreateNewMappoint();
+                mp->pos[0] = tri_xyz_[3 * g]; mp->pos[1] = tri_xyz_[3 * g + 1]; mp->pos[2] = tri_xyz_[3 * g + 2];
+                // the frame object is stable from here on only once it is a keyframe; for the init
+                // frame MakeKeyFrame below moves ownership without moving the object
+                st.map.AddObservation(mp, ObsRef{ cur, p, true });
+                st.map.AddObservation(mp, ObsRef{ cur, p, false });
+                cur->left[p].mp = mp->id;
+                cur->right[p].mp = mp->id;
+                st.map.InsertMapPoint(mp);
+            }
+            if (init) {
+                // StereoInit :232-246 + BuildInitMap :195-203
+                st.frontend_current_kf = cur;
+                MakeKeyFrame(st);
+                st.status = FrontendStatus::TRACKING_GOOD;
+            }
+        }
+    }
+
+    // Backend::UpdateMap -> Optimize, synchronously (src/backend.cpp:9-248)
+    void RunBackend(const std::vector<int> &MS)
+    {
+        const int n = (int)MS.size();
+        jobs_ba_.resize(n);
+        gathers_.assign((size_t)n, BaGather());
+        ba_poses_.clear(); ba_pts_.clear(); ba_okf_.clear(); ba_olm_.clear(); ba_right_.clear(); ba_uv_.clear();
+        int ko = 0, lo = 0, oo = 0;
+        for (int i = 0; i < n; ++i) {
+            Stream &st = *streams_[MS[i]];
+            BaGather &g = gathers_[i];
+            svslam_ba_job &j = jobs_ba_[i];
+            std::map<long, int> kf_local;
+            for (auto &kv : st.map.active_keyframes_) {              // :39-66
+                kf_local[kv.first] = (int)g.kfs.size();
+                g.kfs.push_back(kv.second);
+                for (int t = 0; t < 7; ++t) ba_poses_.push_back(kv.second->pose.v[t]);
+            }
+            for (auto &kv : st.map.active_landmarks_) {              // :83-160
+                MapPoint *mp = kv.second;
+                if (mp->is_outlier) continue;
+                int lm_local = -1;
+                for (const ObsRef &ob : mp->observations) {
+                    Feature &ft = feat_of(ob);
+                    if (ft.outlier) continue;
+                    if (lm_local < 0) {                              // vertex even if no edge follows (:118-130)
+                        lm_local = (int)g.lms.size();
+                        g.lms.push_back(mp);
+                        ba_pts_.push_back(mp->pos[0]); ba_pts_.push_back(mp->pos[1]); ba_pts_.push_back(mp->pos[2]);
+                    }
+                    auto it = ob.frame->is_keyframe ? kf_local.find(ob.frame->keyframe_id) : kf_local.end();
+                    if (it == kf_local.end()) continue;              // :133
+                    ba_okf_.push_back(it->second); ba_olm_.push_back(lm_local);
+                    ba_right_.push_back(ob.is_left ? 0 : 1);
+                    ba_uv_.push_back(ft.x); ba_uv_.push_back(ft.y);
+                    g.edge_feat.push_back(ob);
+                }
+            }
+            j.kf_ofs = ko; j.nkf = (int)g.kfs.size();
+            j.lm_ofs = lo; j.nlm = (int)g.lms.size();
+            j.obs_ofs = oo; j.nobs = (int)g.edge_feat.size();
+            j.iters_done = 0; j.reserved = 0;
+            ko += j.nkf; lo += j.nlm; oo += j.nobs;
+        }
+        ba_chi2_.assign((size_t)std::max(oo, 1), 0.0);
+        if (ba_pts_.empty()) ba_pts_.resize(3);
+        if (ba_okf_.empty()) { ba_okf_.resize(1); ba_olm_.resize(1); ba_right_.resize(1); ba_uv_.resize(2); }
+        check(k_.local_ba(n, jobs_ba_.data(), cam_l_, cfg_.cam_l.pose.v, cam_r_, cfg_.cam_r.pose.v, ko,
+                          ba_poses_.data(), lo, ba_pts_.data(), oo, ba_okf_.data(), ba_olm_.data(), ba_right_.data(),
+                          ba_uv_.data(), cfg_.chi2_th, 10, ba_chi2_.data()), "local_ba");   // :150-164
+        for (int i = 0; i < n; ++i) {
+            Stream &st = *streams_[MS[i]];
+            BaGather &g = gathers_[i];
+            const svslam_ba_job &j = jobs_ba_[i];
+            cnt_.ba_calls++; cnt_.ba_edges += j.nobs; cnt_.ba_kf += j.nkf; cnt_.ba_lm += j.nlm;
+            cnt_.ba_iters += j.iters_done;
+            // :167-193 threshold doubling
+            double chi2_th = cfg_.chi2_th;
+            int cnt_outlier = 0, cnt_inlier = 0, iteration = 0;
+            while (iteration < 5) {
+                cnt_outlier = 0; cnt_inlier = 0;
+                for (int e = 0; e < j.nobs; ++e) {
+                    if (ba_chi2_[j.obs_ofs + e] > chi2_th) cnt_outlier++; else cnt_inlier++;
+                }
+                double inlier_ratio = cnt_inlier / double(cnt_inlier + cnt_outlier);
+                if (inlier_ratio > 0.5) break;
+                chi2_th *= 2; iteration++;
+            }
+            // :197-213
+            for (int e = 0; e < j.nobs; ++e) {
+                const ObsRef &ob = g.edge_feat[e];
+                Feature &ft = feat_of(ob);
+                if (ba_chi2_[j.obs_ofs + e] > chi2_th) {
+                    ft.outlier = true;
+                    MapPoint *mp = st.map.point(ft.mp);
+                    if (mp) st.map.RemoveObservation(mp, ob);
+                } else ft.outlier = false;
+            }
+            // :224-231
+            for (int k = 0; k < j.nkf; ++k) g.kfs[k]->pose = SE3(&ba_poses_[(size_t)(j.kf_ofs + k) * 7]);
+            for (int l = 0; l < j.nlm; ++l) std::memcpy(g.lms[l]->pos, &ba_pts_[(size_t)(j.lm_ofs + l) * 3], 24);
+            // :235-246
+            for (Frame *kf : g.kfs) {
+                if (kf->keyframe_id == 0) continue;
+                if (kf->prev_keyframe) kf->relative_pose_pkf = kf->pose * kf->prev_keyframe->pose.inverse();
+            }
+        }
+    }
+
+    Config cfg_;
+    K &k_;
+    std::vector<std::unique_ptr<Stream>> streams_;
+    Counters cnt_;
+    double cam_l_[4], cam_r_[4];
+    // staging vectors (reused across frames: no per-frame allocation in steady state)
+    std::vector<svslam_track_job> jobs_track_;
+    std::vector<svslam_lk_job> jobs_lk_;
+    std::vector<svslam_gftt_job> jobs_gftt_;
+    std::vector<svslam_tri_job> jobs_tri_;
+    std::vector<svslam_ba_job> jobs_ba_;
+    std::vector<BaGather> gathers_;
+    std::vector<int> track_order_;
+    std::vector<const void *> imgs_;
+    std::vector<int> strides_;
+    std::vector<float> prev_xy_, next_xy_, rects_, corners_, uv_l_, uv_r_, err_, ba_uv_;
+    std::vector<uint8_t> has_mp_, status_, outlier_, tri_ok_, ba_right_;
+    std::vector<double> xyz_, tri_xyz_, ba_poses_, ba_pts_, ba_chi2_;
+    std::vector<int> ncorners_, tri_idx_, ba_okf_, ba_olm_;
+};
+
+} // namespace svs

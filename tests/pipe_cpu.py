@@ -1,0 +1,19 @@
+"""CPU twin of the host pipeline (oracle kernels) for tests and the cpu_baseline
+leg of bench.py.  Test infrastructure only."""
+import ctypes as C
+import importlib
+import os
+
+import oracle_lib
+
+TWIN_SO = os.path.join(oracle_lib.ORC_DIR, "_build", "libsvs_pipeline_cpu.so")
+
+
+def twin_lib():
+    oracle_lib.build()
+    return C.CDLL(TWIN_SO)
+
+
+def make(cfg=None, nstreams=1):
+    pl = importlib.import_module("stereovision-slam_amd.pipeline")
+    return pl.Pipeline(cfg, nstreams, lib=twin_lib())
