@@ -45,7 +45,7 @@ void *svs_pipe_create(const svs_pipe_config *cfg, int nstreams, int device)
         svslam_limits lim;
         std::memset(&lim, 0, sizeof(lim));
         lim.device = device; lim.width = cfg->width; lim.height = cfg->height;
-        lim.max_slots = 3 * nstreams; lim.max_jobs = nstreams;
+        lim.max_slots = 3 * nstreams; lim.max_jobs = 2 * nstreams; // one call may build left+right pyramids
         lim.max_pts = 512; lim.max_corners = cfg->num_features;
         lim.max_kf = cfg->num_active_keyframes + 1; lim.max_lm = cfg->max_lm; lim.max_obs = cfg->max_obs;
         h->kernels.reset(SVS_PIPE_MAKE_KERNELS(lim));
