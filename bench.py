@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the stereo-SLAM hot path on MI355X.
+
+A "step" is one pass of the hot path (Frontend::AddFrame: fused pyramid + LK +
+pose-only every frame; GFTT + stereo LK + triangulation + synchronous local BA
+on keyframes) over one batch of S synthetic stereo frames — one new frame for
+each of the S independent streams a rank owns.  Frames are rendered into HBM
+by the HIP generator before the timed region, so `value` is whole-job
+frames/s with inputs resident in HBM.  One process per GPU; streams are
+independent (no data-path collective); N>1 is weak scaling.
+
+  python bench.py --gpus 1 --steps 200 --warmup 10
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+# One HIP stream per host thread: by default ROCm multiplexes all streams of a process onto 4
+# hardware queues, which serialises one group's ~3 ms BA kernel with the other groups' tracking.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+
+W, H = 620, 188                     # KITTI-00 1241x376 after the reference's 1/2 decimation (F3)
+HBM_PEAK_GBS = 8000.0               # spec (MI355X_MICROARCH.md); 6290 GB/s measured streaming
+LEVEL_PIX = (620 * 188, 310 * 94, 155 * 47, 78 * 24)
+
+
+def algorithmic_bytes(fam, cnt, launches):
+    """SURVEY.md §8d per-unit figures x the units the timed launches processed."""
+    if fam == "lk":          # 4 levels x (14x14 I patch + 20x20 J region) + 21 B point I/O
+        return (cnt["track_pts"] + cnt["right_pts"]) * (2384 + 21)
+    if fam == "pose_only":   # 40 B per edge (xyz f64 + uv f32 + flags) + 56 B pose
+        return cnt["pose_edges"] * 40 + launches * 56
+    if fam == "pyramid":     # image read once + levels 1..3 written once
+        return (cnt["pyr_left"] + cnt["pyr_right"]) * sum(LEVEL_PIX)
+    if fam == "gftt":        # image read once + rect list + corners out
+        return cnt["gftt_calls"] * LEVEL_PIX[0] + cnt["gftt_rects"] * 8 + cnt["corners"] * 8
+    if fam == "triangulate":
+        return cnt["tri_pts"] * (16 + 24 + 1)
+    if fam == "local_ba":    # iters x (E x 40 B obs+ids + K x 56 B + M x 24 B)
+        it = max(cnt["ba_iters"], 1) / max(cnt["ba_calls"], 1)
+        return it * (cnt["ba_edges"] * 40 + cnt["ba_kf"] * 56 + cnt["ba_lm"] * 24)
+    return 0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("SVS_BENCH_STREAMS", "512")),
+                    help="independent stereo streams per GPU, advanced in lockstep")
+    ap.add_argument("--groups", type=int, default=int(os.environ.get("SVS_BENCH_GROUPS", "16")),
+                    help="host threads per GPU, each driving streams/groups streams through its own "
+                         "svslam context (own HIP stream): one group's BA overlaps the others' tracking")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=1500, help="bound of the CPU baseline sample")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+
+    svs = importlib.import_module("stereovision-slam_amd")
+    pl = importlib.import_module("stereovision-slam_amd.pipeline")
+    svs.load()                                      # fails loudly if the HIP library is missing
+
+    S, Wm, K = args.streams, args.warmup, args.steps
+    G = max(1, min(args.groups, S))
+    while S % G:
+        G -= 1
+    Sg = S // G
+    F = Wm + K
+    cfg = pl.default_config(W, H)
+    pipes = [pl.Pipeline(cfg, nstreams=Sg, device=local_rank) for _ in range(G)]
+    ctxs = [svs.Context.borrow(p.kernel_ctx(), W, H) for p in pipes]   # alloc / timing through the pipelines' contexts
+    ctx = ctxs[0]
+
+    # ---- render the synthetic streams straight into HBM: layout [stream][frame][H*W]
+    img = W * H
+    d_left = ctx.dev_alloc(S * F * img)
+    d_right = ctx.dev_alloc(S * F * img)
+    seed0 = 0x5EED0000 + rank * S
+    CH = 256
+    for s in range(S):
+        for f0 in range(0, F, CH):
+            vl, vr = zip(*[svs.synth_views(seed0 + s, f) for f in range(f0, min(F, f0 + CH))])
+            svs.synth_render_device(list(vl), W, H, d_left + (s * F + f0) * img, device=local_rank)
+            svs.synth_render_device(list(vr), W, H, d_right + (s * F + f0) * img, device=local_rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    import threading
+
+    def run_all(first, nframes, want):
+        """every group advances its streams by nframes steps; groups run concurrently (ctypes
+        releases the GIL inside the C++ loop), each on its own HIP stream"""
+        outs = [None] * G
+        errs = []
+
+        def work(g):
+            try:
+                base = g * Sg * F * img
+                outs[g] = pipes[g].run_device(d_left + base, d_right + base, F * img, img, first, nframes,
+                                              want_results=want)
+            except Exception as e:   # noqa: BLE001
+                errs.append(e)
+        th = [threading.Thread(target=work, args=(g,)) for g in range(G)]
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        if errs:
+            raise errs[0]
+        return outs
+
+    def counters_sum():
+        tot = {}
+        for p in pipes:
+            for k, v in p.counters().items():
+                tot[k] = tot.get(k, 0) + v
+        return tot
+
+    # ---- warmup (includes StereoInit of every stream), untimed
+    run_all(0, Wm, False)
+    c0 = counters_sum()
+    for c in ctxs:
+        c.timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    res_g = run_all(Wm, K, True)
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    barrier()
+    elapsed = t1 - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    c1 = counters_sum()
+    cnt = {k: c1[k] - c0[k] for k in c1}
+    fam_t = {}
+    for f in svs.FAMILIES:
+        parts = [c.timing_get(f) for c in ctxs]
+        fam_t[f] = (sum(p[0] for p in parts), sum(p[1] for p in parts), sum(p[2] for p in parts))
+    res = np.concatenate(res_g, axis=1)
+
+    ok_frames = int((res["status"] != 3).sum())      # not LOST
+    total_frames = S * K * world
+    value = total_frames / elapsed
+
+    if rank == 0:
+        dom = max(fam_t, key=lambda f: fam_t[f][0])
+        ms, launches, _ = fam_t[dom]
+        abytes = algorithmic_bytes(dom, cnt, launches)
+        avg_s = (ms / 1e3) / max(launches, 1)
+        achieved = (abytes / max(launches, 1)) / max(avg_s, 1e-12) / 1e9
+        out = {
+            "metric": "stereo frames/sec (track + local BA), KITTI-00-shaped synthetic stereo 1241x376 "
+                      "(620x188 after the reference's 1/2 decimation)",
+            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8/i32 fixed-point (pyramid, LK), f32 (GFTT), f64 (LM, BA)",
+            "data": "synthetic",
+            "config": {"workload": "configs[1..3] on synthetic input: full Frontend::AddFrame hot path on HIP "
+                                   "(GFTT + pyramidal LK + triangulation + pose-only LM) with synchronous HIP "
+                                   "local BA, config-00.yaml hyper-parameters (150 features, 10 active keyframes)",
+                       "streams_per_gpu": S, "host_threads_per_gpu": G, "frame": "%dx%d u8 stereo pair" % (W, H),
+                       "keyframes_in_timed_region": cnt["keyframes"], "tracked_ok_fraction": ok_frames / (S * K),
+                       "parallelism": "%d independent streams/GPU x %d GPU(s), no collective" % (S, world)},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "avg_launch_us": round(avg_s * 1e6, 2), "launches": launches,
+                         "algorithmic_bytes_per_launch": round(abytes / max(launches, 1), 1)},
+            "kernel_ms": {f: round(fam_t[f][0], 3) for f in fam_t},
+            "host_ms_per_step": {"in_step": round(cnt["ns_step"] / 1e6 / K / G, 3),
+                                 "in_abi_calls": round(cnt["ns_kernel_calls"] / 1e6 / K / G, 3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(svs, pl, ctx, cfg, d_left, F, img, S, min(args.cpu_frames, S * F),
+                                               d_right)
+        print(json.dumps(out), flush=True)
+    for p in pipes:
+        p.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(svs, pl, ctx, cfg, d_left, F, img, S, budget_frames, d_right):
+    """The CPU twin (reference-shaped host logic over the oracle kernels, single thread) on a
+    bounded sample of the same workload: the first streams' frames, downloaded from HBM."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import pipe_cpu
+    nstreams = max(1, min(S, budget_frames // F))
+    twin = pipe_cpu.make(cfg, nstreams=1)
+    left = np.zeros((F, H, W), np.uint8); right = np.zeros((F, H, W), np.uint8)
+    total_t, total_f = 0.0, 0
+    for s in range(nstreams):
+        ctx.dev_download(d_left + s * F * img, left)
+        ctx.dev_download(d_right + s * F * img, right)
+        twin.close()
+        twin = pipe_cpu.make(cfg, nstreams=1)
+        t0 = time.perf_counter()
+        for f in range(F):
+            twin.step([left[f]], [right[f]])
+        total_t += time.perf_counter() - t0
+        total_f += F
+    twin.close()
+    return {"value": round(total_f / total_t, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d stream(s) x %d frames of the same synthetic workload, CPU restatement "
+                      "(oracle kernels: pyramids rebuilt per LK call, numeric BA Jacobians like g2o), "
+                      "1 thread, %s" % (nstreams, F, cpu_model())}
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip() + " (%d logical cores)" % os.cpu_count()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+if __name__ == "__main__":
+    main()

@@ -179,6 +179,11 @@ int svslam_local_ba_batch(svslam_ctx *ctx, int njobs, svslam_ba_job *jobs,
                           const float *obs_uv, double huber_delta, int iters,
                           double *edge_chi2);
 
+/* test hook: accumulated per-phase ticks (wall_clock64, 100 MHz) of BA job 0;
+ * out12[11] = LM trials.  enable=1 allocates the counters, out12 != NULL reads
+ * and clears them.                                                            */
+int svslam_ba_profile(svslam_ctx *ctx, int enable, long long *out12);
+
 /* ---- fused per-frame tracking (pyramid + LK + pose-only, one submission) --
  * The whole data-parallel part of Frontend::Track (src/frontend.cpp:645-663)
  * without a host round trip between TrackLastFrame and EstimateCurrentPose:

@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "svslam_lk_batch", "svslam_gftt_batch", "svslam_gftt_eigmap", "svslam_triangulate_batch",
     "svslam_pose_only_batch", "svslam_local_ba_batch", "svslam_track_batch",
     "svslam_dev_alloc", "svslam_dev_free", "svslam_dev_upload", "svslam_dev_download", "svslam_sync",
-    "svslam_timing_enable", "svslam_timing_reset", "svslam_timing_get",
+    "svslam_timing_enable", "svslam_timing_reset", "svslam_timing_get", "svslam_ba_profile",
 ]
 
 FAMILIES = {"pyramid": 0, "lk": 1, "gftt": 2, "triangulate": 3, "pose_only": 4, "local_ba": 5}
@@ -132,11 +132,22 @@ class Context:
                 self.h = C.c_void_p()
             raise RuntimeError("svslam_create failed (%d): %s" % (rc, msg))
         self.width, self.height = width, height
+        self._owned = True
+
+    @classmethod
+    def borrow(cls, handle, width, height):
+        """wrap an svslam_ctx owned by someone else (e.g. the host pipeline)"""
+        self = cls.__new__(cls)
+        self.L = load()
+        self.h = C.c_void_p(handle)
+        self.width, self.height = width, height
+        self._owned = False
+        return self
 
     def close(self):
-        if self.h:
+        if self.h and getattr(self, "_owned", False):
             self.L.svslam_destroy(self.h)
-            self.h = C.c_void_p()
+        self.h = C.c_void_p()
 
     def __del__(self):
         try:
@@ -176,6 +187,11 @@ class Context:
         ms, n, u = C.c_double(), C.c_longlong(), C.c_longlong()
         self._chk(self.L.svslam_timing_get(self.h, FAMILIES[family], C.byref(ms), C.byref(n), C.byref(u)), "timing")
         return ms.value, n.value, u.value
+
+    def ba_profile(self, enable=True, read=False):
+        out = (C.c_longlong * 12)()
+        self._chk(self.L.svslam_ba_profile(self.h, 1 if enable else 0, out if read else None), "ba_profile")
+        return list(out)
 
     # ---- pyramids --------------------------------------------------------
     def pyramid(self, slots, imgs, device=False, strides=None, decimate_from=None):

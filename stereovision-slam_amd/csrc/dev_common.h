@@ -40,30 +40,84 @@ __device__ __forceinline__ uint8_t *lvl_origin(uint8_t *slot, const PyrGeom &g, 
 }
 
 // ---- wave reductions (all lanes end with the total) -------------------
+// DPP row operations (quad_perm xor1, xor2, row_half_mirror, row_mirror) give every
+// lane the sum of its 16-lane row in 4 VALU steps with no LDS traffic; the four row
+// totals are then combined through v_readlane (SGPR broadcast).  Requires a fully
+// active wave.  The tree is fixed, so f64 sums are deterministic.
+#define SVS_DPP_XOR1 0xB1        // quad_perm:[1,0,3,2]
+#define SVS_DPP_XOR2 0x4E        // quad_perm:[2,3,0,1]
+#define SVS_DPP_HALF_MIRROR 0x141
+#define SVS_DPP_MIRROR 0x140
+
+template <int CTRL> __device__ __forceinline__ int dpp_i32(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL> __device__ __forceinline__ long long dpp_i64(long long v)
+{
+    int lo = (int)(v & 0xffffffffll), hi = (int)(v >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ long long readlane_i64(long long v, int lane)
+{
+    int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), lane);
+    int hi = __builtin_amdgcn_readlane((int)(v >> 32), lane);
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+// sum over each 16-lane row (every lane of the row gets it)
+__device__ __forceinline__ double row_sum_f64(double v)
+{
+    v += dpp_f64<SVS_DPP_XOR1>(v);
+    v += dpp_f64<SVS_DPP_XOR2>(v);
+    v += dpp_f64<SVS_DPP_HALF_MIRROR>(v);
+    v += dpp_f64<SVS_DPP_MIRROR>(v);
+    return v;
+}
 __device__ __forceinline__ int wave_sum_i32(int v)
 {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_i32<SVS_DPP_XOR1>(v);
+    v += dpp_i32<SVS_DPP_XOR2>(v);
+    v += dpp_i32<SVS_DPP_HALF_MIRROR>(v);
+    v += dpp_i32<SVS_DPP_MIRROR>(v);
+    return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) +
+           (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
 }
 __device__ __forceinline__ long long wave_sum_i64(long long v)
 {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_i64<SVS_DPP_XOR1>(v);
+    v += dpp_i64<SVS_DPP_XOR2>(v);
+    v += dpp_i64<SVS_DPP_HALF_MIRROR>(v);
+    v += dpp_i64<SVS_DPP_MIRROR>(v);
+    return (readlane_i64(v, 0) + readlane_i64(v, 16)) + (readlane_i64(v, 32) + readlane_i64(v, 48));
 }
 __device__ __forceinline__ double wave_sum_f64(double v)
 {
-    // fixed butterfly order: deterministic
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v = row_sum_f64(v);
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 __device__ __forceinline__ double wave_max_f64(double v)
 {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { double u = __shfl_xor(v, o, 64); v = u > v ? u : v; }
-    return v;
+    v = fmax(v, dpp_f64<SVS_DPP_XOR1>(v));
+    v = fmax(v, dpp_f64<SVS_DPP_XOR2>(v));
+    v = fmax(v, dpp_f64<SVS_DPP_HALF_MIRROR>(v));
+    v = fmax(v, dpp_f64<SVS_DPP_MIRROR>(v));
+    return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 
 // ---- SE(3), Sophus layout qx qy qz qw tx ty tz (mirrors oracle/orc_geom.c) ----

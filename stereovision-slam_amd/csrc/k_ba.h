@@ -7,22 +7,29 @@
 // flow of oracle/orc_geom.c:orc_local_ba; Jacobians are analytic (the reference
 // lets g2o differentiate numerically; see DESIGN.md for the tolerance).
 //
-// Data flow per LM iteration (all sums in fixed order -> deterministic):
-//   edge pass      e, rho', Jp(2x6), Jl(2x3) per edge            (thread / edge)
-//   landmark pass  Hll_j, bl_j, W_kj = sum w Jp^T Jl             (thread / landmark)
-//   pose pass      Hpp_k, bp_k                                   (wave / pose)
-//   per trial:  Dinv_j, Y_kj = W_kj Dinv_j                        (thread / landmark)
-//               S_ab = Hpp+lambda - sum_j Y_aj W_bj^T             (wave / pose pair)
-//               Cholesky + solves on the 6K x 6K system in LDS    (one wave)
-//               back-substitution, update, new errors, rho test
+// Data flow per LM iteration (every sum has a fixed order -> deterministic):
+//   edge pass      e, rho', Jp(2x6), Jl(2x3) per edge               thread / edge
+//   landmark pass  Hll_j, bl_j, W_kj = sum w Jp^T Jl                thread / landmark
+//   pose pass      Hpp_k, bp_k (kept in LDS)                        wave / pose
+//   per LM trial:
+//     Dinv_j, db_j, Y_kj = W_kj Dinv_j                              thread / block
+//     S_ab = Hpp + lambda I - sum_j Y_aj W_bj^T  (S lives in LDS)   16-lane row /
+//       the (Y,W) block pairs of every pose pair are listed by the  (pose pair, half)
+//       host once per call, so the assembly is a gather with DPP row reductions
+//     Cholesky + triangular solves of the 6K x 6K system in LDS     one wave
+//     back-substitution, update, new errors, rho test
 // The reduced camera system is 60x60 f64 at K=10: MFMA does not apply.
 #pragma once
 #include "dev_common.h"
 #include <vector>
 #include <algorithm>
+#include <cstring>
 
-#define BA_THREADS 1024
+#ifndef BA_THREADS
+#define BA_THREADS 512
+#endif
 #define BA_WAVES (BA_THREADS / 64)
+#define BA_ROWS (BA_THREADS / 16)
 #define BA_MAX_NP 192
 
 struct BaJob { int kf_ofs, nkf, lm_ofs, nlm, obs_ofs, nobs, iters_done, reserved; };
@@ -31,8 +38,10 @@ struct BaCams { double cam[2][4]; double ext[2][7]; };
 struct BaDev {               // device-side job descriptor (built on the host)
     int kf_ofs, nkf, lm_ofs, nlm, obs_ofs, nobs;
     int nblk, na;            // unique (kf,lm) blocks, active poses
+    int ncontrib;            // (Y,W) block pairs
     int aux_ofs;             // offset into the int aux buffer
     int iters_done;
+    int pad;
 };
 
 struct BaWork {              // per-job HBM scratch, strided by the context limits
@@ -43,16 +52,12 @@ struct BaWork {              // per-job HBM scratch, strided by the context limi
     double *wgt = nullptr;   // [max_obs]
     double *W = nullptr;     // [18*max_obs]
     double *Y = nullptr;     // [18*max_obs]
-    double *Hpp = nullptr;   // [36*max_kf]
-    double *bp = nullptr;    // [6*max_kf]
     double *Hll = nullptr;   // [9*max_lm]
     double *Dinv = nullptr;  // [9*max_lm]
     double *bl = nullptr;    // [3*max_lm]
     double *db = nullptr;    // [3*max_lm]
-    double *xl = nullptr;    // [3*max_lm]
     double *poses_b = nullptr; // [7*max_kf]
     double *pts_b = nullptr;   // [3*max_lm]
-    int *tbl = nullptr;      // [max_kf*max_lm]
     void *all = nullptr;
 };
 
@@ -61,10 +66,9 @@ static inline hipError_t ba_work_alloc(BaWork &w, int jobs, int max_kf, int max_
     w.max_kf = max_kf; w.max_lm = max_lm; w.max_obs = max_obs;
     if (max_kf <= 0 || max_lm <= 0 || max_obs <= 0) return hipSuccess;
     size_t J = jobs;
-    size_t nd = J * ((size_t)max_obs * (2 + 12 + 6 + 1 + 18 + 18) + (size_t)max_kf * (36 + 6 + 7) +
-                     (size_t)max_lm * (9 + 9 + 3 + 3 + 3 + 3));
-    size_t ni = J * (size_t)max_kf * max_lm;
-    hipError_t e = hipMalloc(&w.all, nd * sizeof(double) + ni * sizeof(int));
+    size_t nd = J * ((size_t)max_obs * (2 + 12 + 6 + 1 + 18 + 18) + (size_t)max_kf * 7 +
+                     (size_t)max_lm * (9 + 9 + 3 + 3 + 3));
+    hipError_t e = hipMalloc(&w.all, nd * sizeof(double));
     if (e != hipSuccess) return e;
     double *p = static_cast<double *>(w.all);
     w.err = p; p += J * 2 * max_obs;
@@ -73,94 +77,140 @@ static inline hipError_t ba_work_alloc(BaWork &w, int jobs, int max_kf, int max_
     w.wgt = p; p += J * max_obs;
     w.W = p; p += J * 18 * max_obs;
     w.Y = p; p += J * 18 * max_obs;
-    w.Hpp = p; p += J * 36 * max_kf;
-    w.bp = p; p += J * 6 * max_kf;
     w.poses_b = p; p += J * 7 * max_kf;
     w.Hll = p; p += J * 9 * max_lm;
     w.Dinv = p; p += J * 9 * max_lm;
     w.bl = p; p += J * 3 * max_lm;
     w.db = p; p += J * 3 * max_lm;
-    w.xl = p; p += J * 3 * max_lm;
     w.pts_b = p; p += J * 3 * max_lm;
-    w.tbl = reinterpret_cast<int *>(p);
     return hipSuccess;
 }
 static inline void ba_work_free(BaWork &w) { if (w.all) (void)hipFree(w.all); w.all = nullptr; }
 
 // ---------------------------------------------------------------- host-side structure
-// aux layout per job (ints):
-//   lm_estart[nlm+1] | lm_edges[nobs] | kf_estart[nkf+1] | kf_edges[nobs] |
-//   eblk[nobs] | lm_bstart[nlm+1] | blk_kf[nblk<=nobs, padded to nobs] | kf_pidx[nkf] | act_kf[nkf]
-static inline size_t ba_aux_ints(int nkf, int nlm, int nobs)
+// aux layout per job (ints), offsets from ba_aux_layout():
+//   lm_estart[nlm+1] lm_edges[nobs] kf_estart[nkf+1] kf_edges[nobs] eblk[nobs]
+//   lm_bstart[nlm+1] blk_kf[nblk] blk_lm[nblk] kf_pidx[nkf] act_kf[nkf]
+//   pc_start[npairs+1] pc_y[ncontrib] pc_w[ncontrib] pb_start[na+1] pb_blk[nblk]
+struct BaAuxLayout {
+    size_t lm_estart, lm_edges, kf_estart, kf_edges, eblk, lm_bstart, blk_kf, blk_lm, kf_pidx, act_kf;
+    size_t pc_start, pc_y, pc_w, pb_start, pb_blk, total;
+};
+__host__ __device__ inline BaAuxLayout ba_aux_layout(int nkf, int nlm, int nobs, int nblk, int na, int ncontrib)
 {
-    return (size_t)(nlm + 1) + nobs + (nkf + 1) + nobs + nobs + (nlm + 1) + nobs + nkf + nkf;
+    BaAuxLayout L;
+    size_t o = 0;
+    L.lm_estart = o; o += (size_t)nlm + 1;
+    L.lm_edges = o; o += nobs;
+    L.kf_estart = o; o += (size_t)nkf + 1;
+    L.kf_edges = o; o += nobs;
+    L.eblk = o; o += nobs;
+    L.lm_bstart = o; o += (size_t)nlm + 1;
+    L.blk_kf = o; o += nblk;
+    L.blk_lm = o; o += nblk;
+    L.kf_pidx = o; o += nkf;
+    L.act_kf = o; o += nkf;
+    L.pc_start = o; o += (size_t)na * (na + 1) / 2 + 1;
+    L.pc_y = o; o += ncontrib;
+    L.pc_w = o; o += ncontrib;
+    L.pb_start = o; o += (size_t)na + 1;
+    L.pb_blk = o; o += nblk;
+    L.total = o;
+    return L;
 }
 
-static inline void ba_build_aux(const BaJob &j, const int *obs_kf, const int *obs_lm, int *aux, BaDev &d)
-{
-    const int nkf = j.nkf, nlm = j.nlm, nobs = j.nobs;
-    int *lm_estart = aux;
-    int *lm_edges = lm_estart + nlm + 1;
-    int *kf_estart = lm_edges + nobs;
-    int *kf_edges = kf_estart + nkf + 1;
-    int *eblk = kf_edges + nobs;
-    int *lm_bstart = eblk + nobs;
-    int *blk_kf = lm_bstart + nlm + 1;
-    int *kf_pidx = blk_kf + nobs;
-    int *act_kf = kf_pidx + nkf;
-    const int *okf = obs_kf + j.obs_ofs, *olm = obs_lm + j.obs_ofs;
-    // edges sorted by (lm, kf, edge id): counting sort by lm after stable sort by kf
-    std::vector<int> order(nobs);
-    for (int e = 0; e < nobs; ++e) order[e] = e;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-        if (olm[a] != olm[b]) return olm[a] < olm[b];
-        return okf[a] < okf[b];
-    });
-    for (int i = 0; i <= nlm; ++i) lm_estart[i] = 0;
-    for (int e = 0; e < nobs; ++e) lm_estart[olm[e] + 1]++;
-    for (int i = 0; i < nlm; ++i) lm_estart[i + 1] += lm_estart[i];
-    int nblk = 0;
-    for (int i = 0; i <= nlm; ++i) lm_bstart[i] = 0;
-    int prev_lm = -1, prev_kf = -1;
-    for (int i = 0; i < nobs; ++i) {
-        int e = order[i];
-        lm_edges[i] = e;
-        if (olm[e] != prev_lm || okf[e] != prev_kf) {
-            blk_kf[nblk] = okf[e];
-            lm_bstart[olm[e] + 1]++;
-            ++nblk;
-            prev_lm = olm[e]; prev_kf = okf[e];
+__host__ __device__ inline int ba_pair_index(int a, int b, int na) { return a * na - a * (a - 1) / 2 + (b - a); }
+
+struct BaHostStruct {        // scratch reused across jobs
+    std::vector<int> order, lm_estart, lm_edges, kf_estart, kf_edges, eblk, lm_bstart, blk_kf, blk_lm, kf_pidx,
+        act_kf, pc_start, pc_y, pc_w, pb_start, pb_blk, fill;
+    int nblk = 0, na = 0, ncontrib = 0;
+
+    void build(const BaJob &j, const int *obs_kf, const int *obs_lm)
+    {
+        const int nkf = j.nkf, nlm = j.nlm, nobs = j.nobs;
+        const int *okf = obs_kf + j.obs_ofs, *olm = obs_lm + j.obs_ofs;
+        order.resize(nobs);
+        for (int e = 0; e < nobs; ++e) order[e] = e;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+            if (olm[a] != olm[b]) return olm[a] < olm[b];
+            return okf[a] < okf[b];
+        });
+        lm_estart.assign((size_t)nlm + 1, 0);
+        for (int e = 0; e < nobs; ++e) lm_estart[olm[e] + 1]++;
+        for (int i = 0; i < nlm; ++i) lm_estart[i + 1] += lm_estart[i];
+        kf_estart.assign((size_t)nkf + 1, 0);
+        for (int e = 0; e < nobs; ++e) kf_estart[okf[e] + 1]++;
+        for (int i = 0; i < nkf; ++i) kf_estart[i + 1] += kf_estart[i];
+        kf_pidx.assign(nkf, -1); act_kf.assign(nkf, -1);
+        na = 0;
+        for (int k = 0; k < nkf; ++k)
+            if (kf_estart[k + 1] > kf_estart[k]) { kf_pidx[k] = na; act_kf[na] = k; ++na; }
+        lm_edges.resize(nobs); eblk.resize(nobs);
+        lm_bstart.assign((size_t)nlm + 1, 0);
+        blk_kf.clear(); blk_lm.clear();
+        int prev_lm = -1, prev_kf = -1;
+        for (int i = 0; i < nobs; ++i) {
+            int e = order[i];
+            lm_edges[i] = e;
+            if (olm[e] != prev_lm || okf[e] != prev_kf) {
+                blk_kf.push_back(okf[e]); blk_lm.push_back(olm[e]);
+                lm_bstart[olm[e] + 1]++;
+                prev_lm = olm[e]; prev_kf = okf[e];
+            }
+            eblk[e] = (int)blk_kf.size() - 1;
         }
-        eblk[e] = nblk - 1;
+        nblk = (int)blk_kf.size();
+        for (int i = 0; i < nlm; ++i) lm_bstart[i + 1] += lm_bstart[i];
+        kf_edges.resize(nobs);
+        fill.assign(kf_estart.begin(), kf_estart.begin() + nkf);
+        for (int e = 0; e < nobs; ++e) kf_edges[fill[okf[e]]++] = e;
+        // (Y,W) block pairs per pose pair, counting sort by pair; landmark-ascending inside a pair
+        const int npairs = na * (na + 1) / 2;
+        pc_start.assign((size_t)npairs + 1, 0);
+        for (int l = 0; l < nlm; ++l)
+            for (int u = lm_bstart[l]; u < lm_bstart[l + 1]; ++u)
+                for (int v = u; v < lm_bstart[l + 1]; ++v)
+                    pc_start[ba_pair_index(kf_pidx[blk_kf[u]], kf_pidx[blk_kf[v]], na) + 1]++;
+        for (int p = 0; p < npairs; ++p) pc_start[p + 1] += pc_start[p];
+        ncontrib = pc_start[npairs];
+        pc_y.resize(ncontrib); pc_w.resize(ncontrib);
+        fill.assign(pc_start.begin(), pc_start.begin() + npairs);
+        for (int l = 0; l < nlm; ++l)
+            for (int u = lm_bstart[l]; u < lm_bstart[l + 1]; ++u)
+                for (int v = u; v < lm_bstart[l + 1]; ++v) {
+                    int p = ba_pair_index(kf_pidx[blk_kf[u]], kf_pidx[blk_kf[v]], na);
+                    pc_y[fill[p]] = u; pc_w[fill[p]] = v; fill[p]++;
+                }
+        // blocks per active pose (landmark-ascending)
+        pb_start.assign((size_t)na + 1, 0);
+        for (int b = 0; b < nblk; ++b) pb_start[kf_pidx[blk_kf[b]] + 1]++;
+        for (int a = 0; a < na; ++a) pb_start[a + 1] += pb_start[a];
+        pb_blk.resize(nblk);
+        fill.assign(pb_start.begin(), pb_start.begin() + na);
+        for (int b = 0; b < nblk; ++b) pb_blk[fill[kf_pidx[blk_kf[b]]]++] = b;
     }
-    for (int i = 0; i < nlm; ++i) lm_bstart[i + 1] += lm_bstart[i];
-    // edges by pose (edge id ascending inside a pose)
-    for (int i = 0; i <= nkf; ++i) kf_estart[i] = 0;
-    for (int e = 0; e < nobs; ++e) kf_estart[okf[e] + 1]++;
-    for (int i = 0; i < nkf; ++i) kf_estart[i + 1] += kf_estart[i];
-    std::vector<int> fill(kf_estart, kf_estart + nkf);
-    for (int e = 0; e < nobs; ++e) kf_edges[fill[okf[e]]++] = e;
-    int na = 0;
-    for (int k = 0; k < nkf; ++k) {
-        if (kf_estart[k + 1] > kf_estart[k]) { kf_pidx[k] = na; act_kf[na] = k; ++na; }
-        else kf_pidx[k] = -1;
+    size_t aux_ints(const BaJob &j) const { return ba_aux_layout(j.nkf, j.nlm, j.nobs, nblk, na, ncontrib).total; }
+    void write(const BaJob &j, int *aux, BaDev &d) const
+    {
+        BaAuxLayout L = ba_aux_layout(j.nkf, j.nlm, j.nobs, nblk, na, ncontrib);
+        auto cp = [&](size_t off, const std::vector<int> &v, size_t n) { if (n) std::memcpy(aux + off, v.data(), n * sizeof(int)); };
+        cp(L.lm_estart, lm_estart, (size_t)j.nlm + 1); cp(L.lm_edges, lm_edges, j.nobs);
+        cp(L.kf_estart, kf_estart, (size_t)j.nkf + 1); cp(L.kf_edges, kf_edges, j.nobs);
+        cp(L.eblk, eblk, j.nobs); cp(L.lm_bstart, lm_bstart, (size_t)j.nlm + 1);
+        cp(L.blk_kf, blk_kf, nblk); cp(L.blk_lm, blk_lm, nblk);
+        cp(L.kf_pidx, kf_pidx, j.nkf); cp(L.act_kf, act_kf, j.nkf);
+        cp(L.pc_start, pc_start, (size_t)na * (na + 1) / 2 + 1); cp(L.pc_y, pc_y, ncontrib); cp(L.pc_w, pc_w, ncontrib);
+        cp(L.pb_start, pb_start, (size_t)na + 1); cp(L.pb_blk, pb_blk, nblk);
+        d.kf_ofs = j.kf_ofs; d.nkf = j.nkf; d.lm_ofs = j.lm_ofs; d.nlm = j.nlm; d.obs_ofs = j.obs_ofs; d.nobs = j.nobs;
+        d.nblk = nblk; d.na = na; d.ncontrib = ncontrib; d.iters_done = 0; d.pad = 0;
     }
-    for (int k = na; k < nkf; ++k) act_kf[k] = -1;
-    d.kf_ofs = j.kf_ofs; d.nkf = nkf; d.lm_ofs = j.lm_ofs; d.nlm = nlm; d.obs_ofs = j.obs_ofs; d.nobs = nobs;
-    d.nblk = nblk; d.na = na; d.iters_done = 0;
-}
+};
 
 // ---------------------------------------------------------------- device helpers
-__device__ __forceinline__ void ba_project(const BaCams &c, int cam, const double *T, const double *P,
-                                           double *q, double *p)
-{
-    d_se3_act(T, P, q);
-    d_se3_act(c.ext[cam], q, p);
-}
-
 __device__ __forceinline__ double block_sum(double v, double *red, int tid)
 {
-    // wave butterfly, then the 16 wave partials summed in fixed order
+    // wave DPP tree, then the 16 wave partials summed in fixed order
     v = wave_sum_f64(v);
     __syncthreads();
     if ((tid & 63) == 0) red[tid >> 6] = v;
@@ -194,26 +244,34 @@ __device__ __forceinline__ void d_inv3(const double *A, double *Ai)
     Ai[6] = c2 * id; Ai[7] = (A[1] * A[6] - A[0] * A[7]) * id; Ai[8] = (A[0] * A[4] - A[1] * A[3]) * id;
 }
 
+// optional cycle profile of job 0 (thread 0): index = phase
+#define BA_PROF_N 12
+#define BA_PROF(i) do { if (prof && tid == 0) { long long t_ = wall_clock64(); prof[i] += t_ - tprev; tprev = t_; } } while (0)
+
 __global__ void __launch_bounds__(BA_THREADS)
 k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all, const int *obs_kf_all,
            const int *obs_lm_all, const uint8_t *obs_right_all, const float2 *obs_uv_all, const int *aux_all,
-           BaWork wk, double delta, int iters, double *edge_chi2_all)
+           BaWork wk, double delta, int iters, double *edge_chi2_all, long long *prof_all)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // LDS carve (all dynamic): S[np*np] | bs[np] | xp[np] | red[16] | flags
     const int job = blockIdx.x;
     BaDev &jd = jobs[job];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int nkf = jd.nkf, nlm = jd.nlm, nobs = jd.nobs, na = jd.na, np = 6 * jd.na;
+    const int nkf = jd.nkf, nlm = jd.nlm, nobs = jd.nobs, na = jd.na, np = 6 * jd.na, nblk = jd.nblk;
     if (nobs <= 0 || na <= 0) { if (tid == 0) jd.iters_done = 0; return; }
+    long long *prof = (prof_all && job == 0) ? prof_all : nullptr;
+    long long tprev = prof ? wall_clock64() : 0;
+    // LDS carve (all dynamic): S[np*(np+1)] | bs[np] | xp[np] | Hpp[36*na] | bp[np] | red[16] | flag
     const int ld = np + 1;   // odd row stride (in doubles): spreads LDS banks
     double *S = reinterpret_cast<double *>(smem);
     double *bs = S + (size_t)np * ld;
     double *xp = bs + np;
-    double *red = xp + np;
+    double *Hpp = xp + np;
+    double *bp = Hpp + 36 * na;
+    double *red = bp + np;
     int *iflag = reinterpret_cast<int *>(red + BA_WAVES);
 
-    const BaCams cams = *camsp;
+    const BaCams &cams = *camsp;
     double *poses = poses_all + (size_t)jd.kf_ofs * 7;
     double *pts = pts_all + (size_t)jd.lm_ofs * 3;
     const int *okf = obs_kf_all + jd.obs_ofs, *olm = obs_lm_all + jd.obs_ofs;
@@ -221,15 +279,14 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
     const float2 *ouv = obs_uv_all + jd.obs_ofs;
     double *edge_chi2 = edge_chi2_all + jd.obs_ofs;
     const int *aux = aux_all + jd.aux_ofs;
-    const int *lm_estart = aux;
-    const int *lm_edges = lm_estart + nlm + 1;
-    const int *kf_estart = lm_edges + nobs;
-    const int *kf_edges = kf_estart + nkf + 1;
-    const int *eblk = kf_edges + nobs;
-    const int *lm_bstart = eblk + nobs;
-    const int *blk_kf = lm_bstart + nlm + 1;
-    const int *kf_pidx = blk_kf + nobs;
-    const int *act_kf = kf_pidx + nkf;
+    const BaAuxLayout AL = ba_aux_layout(nkf, nlm, nobs, nblk, na, jd.ncontrib);
+    const int *lm_estart = aux + AL.lm_estart, *lm_edges = aux + AL.lm_edges;
+    const int *kf_estart = aux + AL.kf_estart, *kf_edges = aux + AL.kf_edges;
+    const int *eblk = aux + AL.eblk, *lm_bstart = aux + AL.lm_bstart;
+    const int *blk_kf = aux + AL.blk_kf, *blk_lm = aux + AL.blk_lm;
+    const int *kf_pidx = aux + AL.kf_pidx, *act_kf = aux + AL.act_kf;
+    const int *pc_start = aux + AL.pc_start, *pc_y = aux + AL.pc_y, *pc_w = aux + AL.pc_w;
+    const int *pb_start = aux + AL.pb_start, *pb_blk = aux + AL.pb_blk;
 
     const size_t J = job;
     double *err = wk.err + J * 2 * wk.max_obs;
@@ -238,37 +295,61 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
     double *wgt = wk.wgt + J * wk.max_obs;
     double *W = wk.W + J * 18 * wk.max_obs;
     double *Y = wk.Y + J * 18 * wk.max_obs;
-    double *Hpp = wk.Hpp + J * 36 * wk.max_kf;
-    double *bp = wk.bp + J * 6 * wk.max_kf;
     double *Hll = wk.Hll + J * 9 * wk.max_lm;
     double *Dinv = wk.Dinv + J * 9 * wk.max_lm;
     double *bl = wk.bl + J * 3 * wk.max_lm;
     double *db = wk.db + J * 3 * wk.max_lm;
-    double *xl = wk.xl + J * 3 * wk.max_lm;
     double *poses_b = wk.poses_b + J * 7 * wk.max_kf;
     double *pts_b = wk.pts_b + J * 3 * wk.max_lm;
-    int *tbl = wk.tbl + J * (size_t)wk.max_kf * wk.max_lm;
 
-    // (kf,lm) -> block table
-    for (int i = tid; i < nkf * nlm; i += BA_THREADS) tbl[i] = -1;
-    __syncthreads();
-    for (int j = tid; j < nlm; j += BA_THREADS)
-        for (int b = lm_bstart[j]; b < lm_bstart[j + 1]; ++b) tbl[blk_kf[b] * nlm + j] = b;
-    __syncthreads();
-
-    auto compute_errors = [&]() -> double {
+    // errors (+ optionally Jacobians and robust weights) at the current state
+    auto edge_pass = [&](bool with_jac) -> double {
         double chi = 0;
         for (int e = tid; e < nobs; e += BA_THREADS) {
             const int cam = oright[e] ? 1 : 0;
-            double q[3], p[3];
-            ba_project(cams, cam, poses + 7 * okf[e], pts + 3 * olm[e], q, p);
+            const double *T = poses + 7 * okf[e];
+            const double *ext = cams.ext[cam];
             const double *K = cams.cam[cam];
-            double px = K[0] * p[0] + K[2] * p[2], py = K[1] * p[1] + K[3] * p[2];
-            double ex = (double)ouv[e].x - px / p[2], ey = (double)ouv[e].y - py / p[2];
+            double q[3], p[3];
+            d_se3_act(T, pts + 3 * olm[e], q);
+            d_se3_act(ext, q, p);
+            const double zi = 1.0 / p[2];
+            const double px = K[0] * p[0] + K[2] * p[2], py = K[1] * p[1] + K[3] * p[2];
+            const double ex = (double)ouv[e].x - px * zi, ey = (double)ouv[e].y - py * zi;
             err[2 * e] = ex; err[2 * e + 1] = ey;
             double r0, r1;
             d_huber(ex * ex + ey * ey, delta, r0, r1);
             chi += r0;
+            if (with_jac) {
+                wgt[e] = r1;
+                // de/dp (2x3) times Re -> M; Jp = M [I | -q^]; Jl = M R
+                const double zi2 = zi * zi;
+                const double e00 = -K[0] * zi, e02 = K[0] * p[0] * zi2, e11 = -K[1] * zi, e12 = K[1] * p[1] * zi2;
+                double Re[9];
+                d_quat_to_R(ext, Re);
+                double M[6];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    M[c] = e00 * Re[c] + e02 * Re[6 + c];
+                    M[3 + c] = e11 * Re[3 + c] + e12 * Re[6 + c];
+                }
+                double *jp = Jp + 12 * (size_t)e, *jl = Jl + 6 * (size_t)e;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const double m0 = M[3 * r], m1 = M[3 * r + 1], m2 = M[3 * r + 2];
+                    jp[6 * r + 0] = m0; jp[6 * r + 1] = m1; jp[6 * r + 2] = m2;
+                    jp[6 * r + 3] = m2 * q[1] - m1 * q[2];
+                    jp[6 * r + 4] = m0 * q[2] - m2 * q[0];
+                    jp[6 * r + 5] = m1 * q[0] - m0 * q[1];
+                }
+                double R[9];
+                d_quat_to_R(T, R);
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        jl[3 * r + c] = M[3 * r] * R[c] + M[3 * r + 1] * R[3 + c] + M[3 * r + 2] * R[6 + c];
+            }
         }
         return block_sum(chi, red, tid);
     };
@@ -276,54 +357,14 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
     double lambda = 0, ni = 2;
     int it_done = 0;
     for (int it = 0; it < iters; ++it) {
-        double currentChi = compute_errors();
+        double currentChi = edge_pass(true);
         double tempChi = currentChi;
-        // ---- buildSystem: edge pass
-        for (int e = tid; e < nobs; e += BA_THREADS) {
-            const int cam = oright[e] ? 1 : 0;
-            const double *T = poses + 7 * okf[e];
-            double q[3], p[3], Re[9], R[9];
-            ba_project(cams, cam, T, pts + 3 * olm[e], q, p);
-            d_quat_to_R(cams.ext[cam], Re);
-            d_quat_to_R(T, R);
-            const double *K = cams.cam[cam];
-            double X = p[0], Yc = p[1], Z = p[2];
-            double zi = 1.0 / Z, zi2 = zi * zi;
-            double E[6] = { -K[0] * zi, 0, K[0] * X * zi2, 0, -K[1] * zi, K[1] * Yc * zi2 };
-            double qh[9] = { 0, q[2], -q[1], -q[2], 0, q[0], q[1], -q[0], 0 };
-            double A[18];
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    A[i * 6 + j] = Re[i * 3 + j];
-                    A[i * 6 + 3 + j] = Re[i * 3] * qh[j] + Re[i * 3 + 1] * qh[3 + j] + Re[i * 3 + 2] * qh[6 + j];
-                }
-            double *jp = Jp + 12 * (size_t)e, *jl = Jl + 6 * (size_t)e;
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int j = 0; j < 6; ++j)
-                    jp[r * 6 + j] = E[r * 3] * A[j] + E[r * 3 + 1] * A[6 + j] + E[r * 3 + 2] * A[12 + j];
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    double m0 = Re[0] * R[j] + Re[1] * R[3 + j] + Re[2] * R[6 + j];
-                    double m1 = Re[3] * R[j] + Re[4] * R[3 + j] + Re[5] * R[6 + j];
-                    double m2 = Re[6] * R[j] + Re[7] * R[3 + j] + Re[8] * R[6 + j];
-                    jl[r * 3 + j] = E[r * 3] * m0 + E[r * 3 + 1] * m1 + E[r * 3 + 2] * m2;
-                }
-            double r0, r1;
-            d_huber(err[2 * e] * err[2 * e] + err[2 * e + 1] * err[2 * e + 1], delta, r0, r1);
-            wgt[e] = r1;
-        }
-        __syncthreads();
-        // ---- landmark pass: Hll, bl, W blocks
+        BA_PROF(0);
+        // ---- landmark pass: Hll, bl, W blocks (edges of a landmark are sorted by pose)
         for (int j = tid; j < nlm; j += BA_THREADS) {
-            double h[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, b3[3] = { 0, 0, 0 };
-            int ebeg = lm_estart[j], eend = lm_estart[j + 1];
-            int i = ebeg;
+            double h[6] = { 0, 0, 0, 0, 0, 0 }, b3[3] = { 0, 0, 0 };
+            const int eend = lm_estart[j + 1];
+            int i = lm_estart[j];
             while (i < eend) {
                 const int blk = eblk[lm_edges[i]];
                 double wacc[18];
@@ -333,26 +374,29 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
                     const int e = lm_edges[i];
                     const double *jp = Jp + 12 * (size_t)e, *jl = Jl + 6 * (size_t)e;
                     const double w = wgt[e], ex = err[2 * e], ey = err[2 * e + 1];
+                    const double l0 = jl[0], l1 = jl[1], l2 = jl[2], l3 = jl[3], l4 = jl[4], l5 = jl[5];
+                    const double wl0 = w * l0, wl1 = w * l1, wl2 = w * l2, wl3 = w * l3, wl4 = w * l4, wl5 = w * l5;
 #pragma unroll
-                    for (int a = 0; a < 6; ++a)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) wacc[a * 3 + c] += w * (jp[a] * jl[c] + jp[6 + a] * jl[3 + c]);
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) {
-                        b3[a] -= w * (jl[a] * ex + jl[3 + a] * ey);
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) h[a * 3 + c] += w * (jl[a] * jl[c] + jl[3 + a] * jl[3 + c]);
+                    for (int a = 0; a < 6; ++a) {
+                        const double p0 = jp[a], p1 = jp[6 + a];
+                        wacc[a * 3 + 0] += p0 * wl0 + p1 * wl3;
+                        wacc[a * 3 + 1] += p0 * wl1 + p1 * wl4;
+                        wacc[a * 3 + 2] += p0 * wl2 + p1 * wl5;
                     }
+                    b3[0] -= wl0 * ex + wl3 * ey; b3[1] -= wl1 * ex + wl4 * ey; b3[2] -= wl2 * ex + wl5 * ey;
+                    h[0] += wl0 * l0 + wl3 * l3; h[1] += wl0 * l1 + wl3 * l4; h[2] += wl0 * l2 + wl3 * l5;
+                    h[3] += wl1 * l1 + wl4 * l4; h[4] += wl1 * l2 + wl4 * l5; h[5] += wl2 * l2 + wl5 * l5;
                     ++i;
                 }
 #pragma unroll
                 for (int t = 0; t < 18; ++t) W[18 * (size_t)blk + t] = wacc[t];
             }
-#pragma unroll
-            for (int t = 0; t < 9; ++t) Hll[9 * j + t] = h[t];
+            double *hj = Hll + 9 * (size_t)j;
+            hj[0] = h[0]; hj[1] = h[1]; hj[2] = h[2]; hj[3] = h[1]; hj[4] = h[3]; hj[5] = h[4];
+            hj[6] = h[2]; hj[7] = h[4]; hj[8] = h[5];
             bl[3 * j] = b3[0]; bl[3 * j + 1] = b3[1]; bl[3 * j + 2] = b3[2];
         }
-        // ---- pose pass: Hpp (block diagonal), bp   (wave per active pose)
+        // ---- pose pass: Hpp (block diagonal), bp -> LDS   (wave per active pose)
         for (int a = wv; a < na; a += BA_WAVES) {
             const int k = act_kf[a];
             double acc[27];
@@ -362,62 +406,71 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
                 const int e = kf_edges[i];
                 const double *jp = Jp + 12 * (size_t)e;
                 const double w = wgt[e], ex = err[2 * e], ey = err[2 * e + 1];
+                double j0[6], j1[6];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) { j0[r] = jp[r]; j1[r] = jp[6 + r]; }
                 int t = 0;
 #pragma unroll
                 for (int r = 0; r < 6; ++r) {
+                    const double w0 = w * j0[r], w1 = w * j1[r];
 #pragma unroll
-                    for (int c = r; c < 6; ++c) { acc[t] += w * (jp[r] * jp[c] + jp[6 + r] * jp[6 + c]); ++t; }
+                    for (int c = r; c < 6; ++c) { acc[t] += w0 * j0[c] + w1 * j1[c]; ++t; }
+                    acc[21 + r] -= w0 * ex + w1 * ey;
                 }
-#pragma unroll
-                for (int r = 0; r < 6; ++r) acc[21 + r] -= w * (jp[r] * ex + jp[6 + r] * ey);
             }
 #pragma unroll
             for (int t = 0; t < 27; ++t) acc[t] = wave_sum_f64(acc[t]);
             if (lane == 0) {
                 int t = 0;
+#pragma unroll
                 for (int r = 0; r < 6; ++r)
+#pragma unroll
                     for (int c = r; c < 6; ++c) { Hpp[36 * a + r * 6 + c] = acc[t]; Hpp[36 * a + c * 6 + r] = acc[t]; ++t; }
+#pragma unroll
                 for (int r = 0; r < 6; ++r) bp[6 * a + r] = acc[21 + r];
             }
         }
         __syncthreads();
+        BA_PROF(1);
         if (it == 0) {
             double md = 0;
             for (int i = tid; i < np; i += BA_THREADS) md = fmax(md, fabs(Hpp[36 * (i / 6) + (i % 6) * 7]));
             for (int i = tid; i < 3 * nlm; i += BA_THREADS)
-                if (lm_estart[i / 3 + 1] > lm_estart[i / 3]) md = fmax(md, fabs(Hll[9 * (i / 3) + (i % 3) * 4]));
+                if (lm_estart[i / 3 + 1] > lm_estart[i / 3]) md = fmax(md, fabs(Hll[9 * (size_t)(i / 3) + (i % 3) * 4]));
             md = block_max(md, red, tid);
             lambda = 1e-5 * md; ni = 2;
         }
         double rho = 0; int qmax = 0;
         do {
-            // backup
+            // backup, Dinv / db / Y, S = blockdiag(Hpp) + lambda I
             for (int i = tid; i < 7 * nkf; i += BA_THREADS) poses_b[i] = poses[i];
             for (int i = tid; i < 3 * nlm; i += BA_THREADS) pts_b[i] = pts[i];
-            // Dinv, db, Y
-            for (int j = tid; j < nlm; j += BA_THREADS) {
-                if (lm_estart[j + 1] == lm_estart[j]) continue;
+            for (int b = tid; b < nblk; b += BA_THREADS) {
+                const int j = blk_lm[b];
                 double D[9], Di[9];
+                const double *hj = Hll + 9 * (size_t)j;
 #pragma unroll
-                for (int t = 0; t < 9; ++t) D[t] = Hll[9 * j + t];
+                for (int t = 0; t < 9; ++t) D[t] = hj[t];
                 D[0] += lambda; D[4] += lambda; D[8] += lambda;
                 d_inv3(D, Di);
+                if (b == lm_bstart[j]) {     // first block of the landmark publishes Dinv, db
+                    double *dj = Dinv + 9 * (size_t)j;
 #pragma unroll
-                for (int t = 0; t < 9; ++t) Dinv[9 * j + t] = Di[t];
+                    for (int t = 0; t < 9; ++t) dj[t] = Di[t];
+                    const double b0 = bl[3 * j], b1 = bl[3 * j + 1], b2 = bl[3 * j + 2];
 #pragma unroll
-                for (int a = 0; a < 3; ++a)
-                    db[3 * j + a] = Di[a * 3] * bl[3 * j] + Di[a * 3 + 1] * bl[3 * j + 1] + Di[a * 3 + 2] * bl[3 * j + 2];
-                for (int b = lm_bstart[j]; b < lm_bstart[j + 1]; ++b) {
-                    const double *w1 = W + 18 * (size_t)b;
-                    double *y = Y + 18 * (size_t)b;
+                    for (int a = 0; a < 3; ++a) db[3 * j + a] = Di[a * 3] * b0 + Di[a * 3 + 1] * b1 + Di[a * 3 + 2] * b2;
+                }
+                const double *w1 = W + 18 * (size_t)b;
+                double *y = Y + 18 * (size_t)b;
 #pragma unroll
-                    for (int a = 0; a < 6; ++a)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c)
-                            y[a * 3 + c] = w1[a * 3] * Di[c] + w1[a * 3 + 1] * Di[3 + c] + w1[a * 3 + 2] * Di[6 + c];
+                for (int a = 0; a < 6; ++a) {
+                    const double x0 = w1[a * 3], x1 = w1[a * 3 + 1], x2 = w1[a * 3 + 2];
+                    y[a * 3 + 0] = x0 * Di[0] + x1 * Di[3] + x2 * Di[6];
+                    y[a * 3 + 1] = x0 * Di[1] + x1 * Di[4] + x2 * Di[7];
+                    y[a * 3 + 2] = x0 * Di[2] + x1 * Di[5] + x2 * Di[8];
                 }
             }
-            // S = blockdiag(Hpp) + lambda I ; bs = bp
             for (int i = tid; i < np * np; i += BA_THREADS) {
                 int r = i / np, c = i - r * np;
                 double v = 0;
@@ -426,78 +479,104 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
                 S[(size_t)r * ld + c] = v;
             }
             __syncthreads();
-            // pose-pair pass: S_ab -= sum_j Y_aj W_bj^T ; bs_a = bp_a - sum_j W_aj db_j
-            const int npairs = na * (na + 1) / 2;
-            for (int pidx = wv; pidx < npairs + na; pidx += BA_WAVES) {
-                if (pidx < npairs) {
-                    int a = 0, rem = pidx;
-                    while (rem >= na - a) { rem -= na - a; ++a; }
-                    const int b = a + rem;
-                    const int *ta = tbl + act_kf[a] * nlm, *tb = tbl + act_kf[b] * nlm;
-                    double acc[36];
+            BA_PROF(2);
+            // ---- Schur assembly: 16-lane row per (pose pair, 3-row half) task, then bs tasks
+            {
+                const int npairs = na * (na + 1) / 2;
+                const int row = tid >> 4, rl = tid & 15;
+                for (int t = row; t < 2 * npairs + na; t += BA_ROWS) {
+                    if (t < 2 * npairs) {
+                        const int pidx = t >> 1, half = t & 1;
+                        int a = 0, rem = pidx;
+                        while (rem >= na - a) { rem -= na - a; ++a; }
+                        const int b = a + rem;
+                        double acc[18];
 #pragma unroll
-                    for (int t = 0; t < 36; ++t) acc[t] = 0;
-                    for (int j = lane; j < nlm; j += 64) {
-                        const int i1 = ta[j], i2 = tb[j];
-                        if (i1 < 0 || i2 < 0) continue;
-                        const double *y = Y + 18 * (size_t)i1, *w2 = W + 18 * (size_t)i2;
+                        for (int z = 0; z < 18; ++z) acc[z] = 0;
+                        for (int c = pc_start[pidx] + rl; c < pc_start[pidx + 1]; c += 16) {
+                            const double *y = Y + 18 * (size_t)pc_y[c] + 9 * half;
+                            const double *w2 = W + 18 * (size_t)pc_w[c];
+                            double yy[9], ww[18];
 #pragma unroll
-                        for (int r = 0; r < 6; ++r)
+                            for (int z = 0; z < 9; ++z) yy[z] = y[z];
 #pragma unroll
-                            for (int c = 0; c < 6; ++c)
-                                acc[r * 6 + c] += y[r * 3] * w2[c * 3] + y[r * 3 + 1] * w2[c * 3 + 1] + y[r * 3 + 2] * w2[c * 3 + 2];
+                            for (int z = 0; z < 18; ++z) ww[z] = w2[z];
+#pragma unroll
+                            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                                for (int cc = 0; cc < 6; ++cc)
+                                    acc[r * 6 + cc] += yy[r * 3] * ww[cc * 3] + yy[r * 3 + 1] * ww[cc * 3 + 1] + yy[r * 3 + 2] * ww[cc * 3 + 2];
+                        }
+#pragma unroll
+                        for (int z = 0; z < 18; ++z) acc[z] = row_sum_f64(acc[z]);
+                        // every lane of the row now holds the 18 sums; lane z retires entry z,
+                        // lanes 0,1 additionally retire entries 16,17
+                        double mine = acc[0];
+#pragma unroll
+                        for (int z = 1; z < 16; ++z) mine = (rl == z) ? acc[z] : mine;
+                        {
+                            const int r = 3 * half + rl / 6, cc = rl % 6;
+                            S[(size_t)(6 * a + r) * ld + 6 * b + cc] -= mine;
+                            if (a != b) S[(size_t)(6 * b + cc) * ld + 6 * a + r] -= mine;
+                        }
+                        if (rl < 2) {
+                            const int z = 16 + rl;
+                            const double v = (rl == 0) ? acc[16] : acc[17];
+                            const int r = 3 * half + z / 6, cc = z % 6;
+                            S[(size_t)(6 * a + r) * ld + 6 * b + cc] -= v;
+                            if (a != b) S[(size_t)(6 * b + cc) * ld + 6 * a + r] -= v;
+                        }
+                    } else {
+                        const int a = t - 2 * npairs;
+                        double acc[6] = { 0, 0, 0, 0, 0, 0 };
+                        for (int i = pb_start[a] + rl; i < pb_start[a + 1]; i += 16) {
+                            const int b = pb_blk[i];
+                            const double *w1 = W + 18 * (size_t)b;
+                            const double *d3 = db + 3 * (size_t)blk_lm[b];
+                            const double d0 = d3[0], d1 = d3[1], d2 = d3[2];
+#pragma unroll
+                            for (int r = 0; r < 6; ++r) acc[r] += w1[r * 3] * d0 + w1[r * 3 + 1] * d1 + w1[r * 3 + 2] * d2;
+                        }
+#pragma unroll
+                        for (int r = 0; r < 6; ++r) acc[r] = row_sum_f64(acc[r]);
+                        if (rl < 6) {
+                            double v = acc[0];
+#pragma unroll
+                            for (int r = 1; r < 6; ++r) v = (rl == r) ? acc[r] : v;
+                            bs[6 * a + rl] = bp[6 * a + rl] - v;
+                        }
                     }
-#pragma unroll
-                    for (int t = 0; t < 36; ++t) acc[t] = wave_sum_f64(acc[t]);
-                    if (lane == 0) {
-                        for (int r = 0; r < 6; ++r)
-                            for (int c = 0; c < 6; ++c) {
-                                S[(size_t)(6 * a + r) * ld + 6 * b + c] -= acc[r * 6 + c];
-                                if (a != b) S[(size_t)(6 * b + c) * ld + 6 * a + r] -= acc[r * 6 + c];
-                            }
-                    }
-                } else {
-                    const int a = pidx - npairs;
-                    const int *ta = tbl + act_kf[a] * nlm;
-                    double acc[6] = { 0, 0, 0, 0, 0, 0 };
-                    for (int j = lane; j < nlm; j += 64) {
-                        const int i1 = ta[j];
-                        if (i1 < 0) continue;
-                        const double *w1 = W + 18 * (size_t)i1;
-#pragma unroll
-                        for (int r = 0; r < 6; ++r)
-                            acc[r] += w1[r * 3] * db[3 * j] + w1[r * 3 + 1] * db[3 * j + 1] + w1[r * 3 + 2] * db[3 * j + 2];
-                    }
-#pragma unroll
-                    for (int r = 0; r < 6; ++r) acc[r] = wave_sum_f64(acc[r]);
-                    if (lane == 0)
-                        for (int r = 0; r < 6; ++r) bs[6 * a + r] = bp[6 * a + r] - acc[r];
                 }
             }
             __syncthreads();
-            // Cholesky S = L L^T (lower, in place) and the two triangular solves: wave 0.
+            BA_PROF(3);
+            // ---- Cholesky S = L L^T (lower, in place) and the two triangular solves: wave 0
             if (wv == 0) {
                 int ok = 1;
                 for (int k = 0; k < np; ++k) {
-                    // left-looking: column k
                     for (int i = k + lane; i < np; i += 64) {
-                        double v = S[(size_t)i * ld + k];
-                        for (int m = 0; m < k; ++m) v -= S[(size_t)i * ld + m] * S[(size_t)k * ld + m];
-                        S[(size_t)i * ld + k] = v; // un-normalised
+                        const double *ri = S + (size_t)i * ld, *rk = S + (size_t)k * ld;
+                        double v0 = ri[k], v1 = 0, v2 = 0, v3 = 0;
+                        int m = 0;
+                        for (; m + 3 < k; m += 4) {
+                            v0 -= ri[m] * rk[m]; v1 -= ri[m + 1] * rk[m + 1];
+                            v2 -= ri[m + 2] * rk[m + 2]; v3 -= ri[m + 3] * rk[m + 3];
+                        }
+                        for (; m < k; ++m) v0 -= ri[m] * rk[m];
+                        S[(size_t)i * ld + k] = (v0 + v1) + (v2 + v3);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    double d = S[(size_t)k * ld + k];
+                    const double d = S[(size_t)k * ld + k];
                     if (!(d > 0)) { ok = 0; break; }
-                    double sd = sqrt(d);
-                    for (int i = k + lane; i < np; i += 64) S[(size_t)i * ld + k] = (i == k) ? sd : S[(size_t)i * ld + k] / sd;
+                    const double sd = sqrt(d), isd = 1.0 / sd;
+                    for (int i = k + lane; i < np; i += 64) S[(size_t)i * ld + k] = (i == k) ? sd : S[(size_t)i * ld + k] * isd;
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 }
                 if (ok) {
-                    // forward: L y = bs  (y overwrites xp)
                     for (int i = lane; i < np; i += 64) xp[i] = bs[i];
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    for (int k = 0; k < np; ++k) {
-                        double yk = xp[k] / S[(size_t)k * ld + k];
+                    for (int k = 0; k < np; ++k) {           // L y = bs
+                        const double yk = xp[k] / S[(size_t)k * ld + k];
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         for (int i = k + lane; i < np; i += 64) {
                             if (i == k) xp[i] = yk;
@@ -505,9 +584,8 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
                         }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     }
-                    // backward: L^T x = y
-                    for (int k = np - 1; k >= 0; --k) {
-                        double xk = xp[k] / S[(size_t)k * ld + k];
+                    for (int k = np - 1; k >= 0; --k) {      // L^T x = y
+                        const double xk = xp[k] / S[(size_t)k * ld + k];
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         for (int i = lane; i <= k; i += 64) {
                             if (i == k) xp[i] = xk;
@@ -519,26 +597,26 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
                 if (lane == 0) iflag[0] = ok;
             }
             __syncthreads();
+            BA_PROF(4);
             const int ok2 = iflag[0];
             double scale_part = 0;
             if (ok2) {
-                // back-substitution + landmark update
                 for (int j = tid; j < nlm; j += BA_THREADS) {
                     if (lm_estart[j + 1] == lm_estart[j]) continue;
-                    double c3[3] = { bl[3 * j], bl[3 * j + 1], bl[3 * j + 2] };
+                    double c0 = bl[3 * j], c1 = bl[3 * j + 1], c2 = bl[3 * j + 2];
                     for (int b = lm_bstart[j]; b < lm_bstart[j + 1]; ++b) {
                         const double *w1 = W + 18 * (size_t)b;
                         const double *x6 = xp + 6 * kf_pidx[blk_kf[b]];
 #pragma unroll
-                        for (int a = 0; a < 6; ++a)
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) c3[c] -= w1[a * 3 + c] * x6[a];
+                        for (int a = 0; a < 6; ++a) {
+                            const double xa = x6[a];
+                            c0 -= w1[a * 3] * xa; c1 -= w1[a * 3 + 1] * xa; c2 -= w1[a * 3 + 2] * xa;
+                        }
                     }
-                    const double *Di = Dinv + 9 * j;
+                    const double *Di = Dinv + 9 * (size_t)j;
 #pragma unroll
                     for (int a = 0; a < 3; ++a) {
-                        double x = Di[a * 3] * c3[0] + Di[a * 3 + 1] * c3[1] + Di[a * 3 + 2] * c3[2];
-                        xl[3 * j + a] = x;
+                        const double x = Di[a * 3] * c0 + Di[a * 3 + 1] * c1 + Di[a * 3 + 2] * c2;
                         pts[3 * j + a] += x;
                         scale_part += x * (lambda * x + bl[3 * j + a]);
                     }
@@ -556,7 +634,9 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
             }
             double scale = block_sum(scale_part, red, tid);
             __syncthreads();
-            tempChi = compute_errors();
+            BA_PROF(5);
+            tempChi = edge_pass(false);
+            BA_PROF(6);
             if (!ok2) tempChi = 1.7976931348623157e308;
             rho = currentChi - tempChi;
             scale += 1e-3;
@@ -575,6 +655,7 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
                 if (!isfinite(lambda)) break;
             }
             ++qmax;
+            if (prof && tid == 0) prof[BA_PROF_N - 1] += 1;
         } while (rho < 0 && qmax < 10);
         ++it_done;
         if (qmax == 10 || rho == 0 || !isfinite(lambda)) break;
@@ -587,5 +668,5 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
 static inline size_t ba_lds_bytes(int max_kf)
 {
     size_t np = 6 * (size_t)max_kf;
-    return (np * (np + 1) + 2 * np + BA_WAVES) * sizeof(double) + 64;
+    return (np * (np + 1) + 3 * np + 36 * (size_t)max_kf + BA_WAVES) * sizeof(double) + 64;
 }

@@ -92,48 +92,50 @@ k_triangulate(const TriJob *jobs, TriCams cams, const float2 *uv_l, const float2
 // ------------------------------------------------------------------ pose-only LM
 struct PoseJob { int pt_ofs, npts; double pose[7]; int n_inlier; int pad; };
 
-// in-register 6x6 LDLT with diagonal pivoting (Eigen::LDLT semantics);
-// executed redundantly by every lane (wave-uniform data)
-__device__ inline bool d_ldlt6(const double *Hin, const double *b, double *x)
+// 6x6 SPD solve (H + lambda I) x = b by an unpivoted, fully unrolled LDL^T kept in
+// registers (no dynamically indexed arrays -> no scratch).  Eigen's LDLT pivots; for
+// the positive definite damped system both give the solution to rounding.  Returns
+// false when a pivot is not positive (g2o: solver failure -> step rejected).
+// Executed redundantly by every lane on wave-uniform data.
+__device__ __forceinline__ bool d_ldlt6(const double *H, const double *b, double *x)
 {
-    double L[36], D[6];
-    int perm[6];
-    for (int i = 0; i < 36; ++i) L[i] = Hin[i];
-    for (int i = 0; i < 6; ++i) perm[i] = i;
-    bool positive = true;
+    double L[6][6], D[6], y[6];
+    bool ok = true;
+#pragma unroll
     for (int k = 0; k < 6; ++k) {
-        int piv = k; double best = fabs(L[k * 7]);
-        for (int i = k + 1; i < 6; ++i) if (fabs(L[i * 7]) > best) { best = fabs(L[i * 7]); piv = i; }
-        if (piv != k) {
-            for (int j = 0; j < 6; ++j) { double t = L[k * 6 + j]; L[k * 6 + j] = L[piv * 6 + j]; L[piv * 6 + j] = t; }
-            for (int i = 0; i < 6; ++i) { double t = L[i * 6 + k]; L[i * 6 + k] = L[i * 6 + piv]; L[i * 6 + piv] = t; }
-            int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t;
-        }
-        double dk = L[k * 7];
-        for (int j = 0; j < k; ++j) dk -= L[k * 6 + j] * L[k * 6 + j] * D[j];
+        double dk = H[k * 6 + k];
+#pragma unroll
+        for (int j = 0; j < k; ++j) dk -= L[k][j] * L[k][j] * D[j];
         D[k] = dk;
-        if (dk < 0) positive = false;
+        ok = ok && (dk > 0);
+        const double inv = 1.0 / dk;
+#pragma unroll
         for (int i = k + 1; i < 6; ++i) {
-            double v = L[i * 6 + k];
-            for (int j = 0; j < k; ++j) v -= L[i * 6 + j] * L[k * 6 + j] * D[j];
-            L[i * 6 + k] = (dk != 0.0) ? v / dk : 0.0;
+            double v = H[i * 6 + k];
+#pragma unroll
+            for (int j = 0; j < k; ++j) v -= L[i][j] * L[k][j] * D[j];
+            L[i][k] = v * inv;
         }
     }
-    if (!positive) return false;
-    double y[6];
+#pragma unroll
     for (int i = 0; i < 6; ++i) {
-        double v = b[perm[i]];
-        for (int j = 0; j < i; ++j) v -= L[i * 6 + j] * y[j];
+        double v = b[i];
+#pragma unroll
+        for (int j = 0; j < i; ++j) v -= L[i][j] * y[j];
         y[i] = v;
     }
-    for (int i = 0; i < 6; ++i) y[i] = (D[i] != 0.0) ? y[i] / D[i] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) y[i] = y[i] / D[i];
+#pragma unroll
     for (int i = 5; i >= 0; --i) {
         double v = y[i];
-        for (int j = i + 1; j < 6; ++j) v -= L[j * 6 + i] * y[j];
+#pragma unroll
+        for (int j = i + 1; j < 6; ++j) v -= L[j][i] * y[j];
         y[i] = v;
     }
-    for (int i = 0; i < 6; ++i) x[perm[i]] = y[i];
-    return true;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x[i] = y[i];
+    return ok;
 }
 
 #define PO_MAX_PER_LANE 8     // up to 512 edges per job

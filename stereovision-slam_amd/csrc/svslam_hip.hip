@@ -63,6 +63,8 @@ struct svslam_ctx {
     GfttWork gw;
     // BA scratch
     BaWork bw;
+    std::vector<BaHostStruct> ba_hs;
+    long long *d_ba_prof = nullptr;
     // timing
     bool timing = false;
     Timing tm;
@@ -267,7 +269,7 @@ int svslam_create(const svslam_limits *lim, svslam_ctx **out)
     const size_t J = lim->max_jobs, N = lim->max_pts;
     size_t per_job_pts = N * (8 + 8 + 1 + 4 + 24 + 8 + 1 + 1 + 8) + 1024;
     size_t per_job_ba = (size_t)lim->max_kf * 56 + (size_t)lim->max_lm * 24 +
-                        (size_t)lim->max_obs * (4 + 4 + 1 + 8 + 8 + 16 + 16) + (size_t)lim->max_lm * 8 + 1024;
+                        (size_t)lim->max_obs * (4 + 4 + 1 + 8 + 8 + 24 + 4 * (size_t)(lim->max_kf + 1)) + (size_t)lim->max_lm * 8 + 4096;
     size_t per_job = std::max(per_job_pts, per_job_ba) + (size_t)lim->max_corners * 8 + 4096;
     c->ar.cap = per_job * J + (1 << 20);
     HIPCHK(c, hipHostMalloc(&c->ar.h, c->ar.cap));
@@ -309,6 +311,7 @@ void svslam_destroy(svslam_ctx *c)
     if (c->h_img) (void)(void)hipHostFree(c->h_img);
     (void)hipFree(c->gw.eig); (void)hipFree(c->gw.mask); (void)hipFree(c->gw.keys); (void)hipFree(c->gw.counters);
     ba_work_free(c->bw);
+    if (c->d_ba_prof) (void)hipFree(c->d_ba_prof);
     for (int i = 0; i < 16; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -611,8 +614,16 @@ int svslam_local_ba_batch(svslam_ctx *c, int njobs, svslam_ba_job *jobs, const d
     }
     c->ar.reset();
     static_assert(sizeof(BaJob) == sizeof(svslam_ba_job), "job layout");
+    // host-side structure of every problem (edge / block / pose-pair lists)
+    std::vector<BaHostStruct> &hs = c->ba_hs;
+    if ((int)hs.size() < njobs) hs.resize(njobs);
     size_t aux_total = 0;
-    for (int i = 0; i < njobs; ++i) aux_total += ba_aux_ints(jobs[i].nkf, jobs[i].nlm, jobs[i].nobs);
+    for (int i = 0; i < njobs; ++i) {
+        BaJob bj;
+        memcpy(&bj, &jobs[i], sizeof(bj));
+        hs[i].build(bj, obs_kf, obs_lm);
+        aux_total += hs[i].aux_ints(bj);
+    }
     size_t ocams = c->ar.take(sizeof(BaCams));
     size_t okf = c->ar.take(sizeof(int) * std::max(total_obs, 1));
     size_t olm = c->ar.take(sizeof(int) * std::max(total_obs, 1));
@@ -624,7 +635,7 @@ int svslam_local_ba_batch(svslam_ctx *c, int njobs, svslam_ba_job *jobs, const d
     size_t opts = c->ar.take(sizeof(double) * 3 * std::max(total_lm, 1));
     size_t in_end = c->ar.off;
     size_t ochi = c->ar.take(sizeof(double) * std::max(total_obs, 1));
-    if (c->ar.off > c->ar.cap) return fail(c, "local_ba: staging arena too small");
+    if (c->ar.off > c->ar.cap) return fail(c, "local_ba: staging arena too small (%zu > %zu bytes)", c->ar.off, c->ar.cap);
     BaCams *cams = hp<BaCams>(c, ocams);
     memcpy(cams->cam[0], cam_l, 32); memcpy(cams->cam[1], cam_r, 32);
     memcpy(cams->ext[0], ext_l, 56); memcpy(cams->ext[1], ext_r, 56);
@@ -641,9 +652,9 @@ int svslam_local_ba_batch(svslam_ctx *c, int njobs, svslam_ba_job *jobs, const d
         for (int i = 0; i < njobs; ++i) {
             BaJob bj;
             memcpy(&bj, &jobs[i], sizeof(bj));
-            ba_build_aux(bj, obs_kf, obs_lm, aux + aofs, dj[i]);
+            hs[i].write(bj, aux + aofs, dj[i]);
             dj[i].aux_ofs = (int)aofs;
-            aofs += ba_aux_ints(bj.nkf, bj.nlm, bj.nobs);
+            aofs += hs[i].aux_ints(bj);
         }
     }
     if (total_kf > 0) memcpy(hp<void>(c, oposes), poses, sizeof(double) * 7 * total_kf);
@@ -653,7 +664,7 @@ int svslam_local_ba_batch(svslam_ctx *c, int njobs, svslam_ba_job *jobs, const d
     hipLaunchKernelGGL(k_local_ba, dim3(njobs), dim3(BA_THREADS), ba_lds_bytes(c->lim.max_kf), c->stream,
                        dp<BaDev>(c, ojobs), dp<BaCams>(c, ocams), dp<double>(c, oposes), dp<double>(c, opts),
                        dp<int>(c, okf), dp<int>(c, olm), dp<uint8_t>(c, oright), dp<float2>(c, ouv),
-                       dp<int>(c, oaux), c->bw, huber_delta, iters, dp<double>(c, ochi));
+                       dp<int>(c, oaux), c->bw, huber_delta, iters, dp<double>(c, ochi), c->d_ba_prof);
     tm_end(c);
     HIPCHK(c, hipGetLastError());
     if (d2h_sync(c, ojobs, c->ar.off)) return -1;
@@ -661,6 +672,43 @@ int svslam_local_ba_batch(svslam_ctx *c, int njobs, svslam_ba_job *jobs, const d
     if (total_kf > 0) memcpy(poses, hp<void>(c, oposes), sizeof(double) * 7 * total_kf);
     if (total_lm > 0) memcpy(pts, hp<void>(c, opts), sizeof(double) * 3 * total_lm);
     if (total_obs > 0) memcpy(edge_chi2, hp<void>(c, ochi), sizeof(double) * total_obs);
+    return 0;
+}
+
+// test hook: effective shader clock.  A single wave spins for ~`ms` milliseconds of
+// wall_clock64 (100 MHz, constant) and reports the clock64() (shader cycles) it saw.
+__global__ void k_clock_probe(long long *out, long long wall_ticks)
+{
+    long long w0 = wall_clock64(), c0 = clock64();
+    long long w = w0;
+    while (w - w0 < wall_ticks) w = wall_clock64();
+    long long c1 = clock64();
+    if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = w - w0; out[1] = c1 - c0; }
+}
+int svslam_debug_clock_mhz(svslam_ctx *c, int blocks, double ms, double *mhz)
+{
+    long long *d = nullptr, h[2] = { 0, 0 };
+    HIPCHK(c, hipMalloc(&d, 16));
+    hipLaunchKernelGGL(k_clock_probe, dim3(blocks), dim3(64), 0, c->stream, d, (long long)(ms * 1e5));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(h, d, 16, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    *mhz = h[0] > 0 ? 100.0 * (double)h[1] / (double)h[0] : 0.0;
+    return 0;
+}
+
+// test hook: per-phase cycle counters of BA job 0 (wall_clock64 ticks, 100 MHz)
+int svslam_ba_profile(svslam_ctx *c, int enable, long long *out12)
+{
+    if (enable && !c->d_ba_prof) {
+        HIPCHK(c, hipMalloc(&c->d_ba_prof, sizeof(long long) * BA_PROF_N));
+        HIPCHK(c, hipMemset(c->d_ba_prof, 0, sizeof(long long) * BA_PROF_N));
+    }
+    if (out12 && c->d_ba_prof) {
+        HIPCHK(c, hipMemcpy(out12, c->d_ba_prof, sizeof(long long) * BA_PROF_N, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemset(c->d_ba_prof, 0, sizeof(long long) * BA_PROF_N));
+    }
+    if (!enable && c->d_ba_prof) { (void)hipFree(c->d_ba_prof); c->d_ba_prof = nullptr; }
     return 0;
 }
 

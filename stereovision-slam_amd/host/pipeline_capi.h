@@ -27,6 +27,7 @@ typedef struct svs_frame_result {
 typedef struct svs_pipe_counters {
     long long frames, keyframes, track_pts, pose_edges, gftt_calls, gftt_rects, corners, right_pts, tri_pts;
     long long ba_calls, ba_edges, ba_kf, ba_lm, ba_iters, pyr_left, pyr_right;
+    long long ns_step, ns_kernel_calls;
 } svs_pipe_counters;
 
 void *svs_pipe_create(const svs_pipe_config *cfg, int nstreams, int device);

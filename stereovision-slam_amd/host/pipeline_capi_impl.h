@@ -115,6 +115,7 @@ int svs_pipe_counters_get(void *p, svs_pipe_counters *out)
     out->right_pts = c.right_pts; out->tri_pts = c.tri_pts; out->ba_calls = c.ba_calls; out->ba_edges = c.ba_edges;
     out->ba_kf = c.ba_kf; out->ba_lm = c.ba_lm; out->ba_iters = c.ba_iters; out->pyr_left = c.pyr_left;
     out->pyr_right = c.pyr_right;
+    out->ns_step = c.ns_step; out->ns_kernel_calls = c.ns_kernel_calls;
     return 0;
 }
 

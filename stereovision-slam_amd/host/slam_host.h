@@ -19,6 +19,7 @@
 // this header never names an implementation.
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <deque>
@@ -184,6 +185,7 @@ struct Counters {                      // workload accounting for the roofline (
     long long right_pts = 0, tri_pts = 0;
     long long ba_calls = 0, ba_edges = 0, ba_kf = 0, ba_lm = 0, ba_iters = 0;
     long long pyr_left = 0, pyr_right = 0;
+    long long ns_step = 0, ns_kernel_calls = 0;   // wall time inside step() / inside the C-ABI calls
 };
 
 struct Stream {
@@ -235,6 +237,7 @@ public:
               FrameResult *out)
     {
         const int S = nstreams();
+        const long long t_step0 = now_ns();
         std::vector<int> TS, IS, KS;
         for (int s = 0; s < S; ++s) {
             Stream &st = *streams_[s];
@@ -291,6 +294,7 @@ public:
             st.last = st.current;
             st.last_owned = std::move(st.cur_owned);   // null if the frame moved into kf_store
         }
+        cnt_.ns_step += now_ns() - t_step0;
     }
 
 private:
@@ -298,6 +302,15 @@ private:
     {
         if (rc != 0) throw std::runtime_error(std::string(what) + " failed: " + k_.last_error());
     }
+    static long long now_ns()
+    {
+        return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    }
+    struct KTimer {            // accumulates the wall time of one C-ABI call
+        Counters &c; long long t0;
+        explicit KTimer(Counters &cc) : c(cc), t0(now_ns()) {}
+        ~KTimer() { c.ns_kernel_calls += now_ns() - t0; }
+    };
 
     // ---- Track(): constant-velocity prior + TrackLastFrame + EstimateCurrentPose
     void TrackPrepareAndRun(const std::vector<int> &TS, const void *const *left, const int *strides, int is_device)
@@ -339,9 +352,9 @@ private:
         outlier_.assign((size_t)std::max(ofs, 1), 0);
         if (prev_xy_.empty()) { prev_xy_.resize(2); next_xy_.resize(2); has_mp_.resize(1); xyz_.resize(3); }
         svslam_lk_params prm = { 3, 30, 0.01, 1e-4, 1 };            // :353-357
-        check(k_.track(n, jobs_track_.data(), imgs_.data(), strides_.data(), is_device, ofs, cam_l_,
+        { KTimer kt_(cnt_); check(k_.track(n, jobs_track_.data(), imgs_.data(), strides_.data(), is_device, ofs, cam_l_,
                        prev_xy_.data(), next_xy_.data(), has_mp_.data(), xyz_.data(), status_.data(),
-                       outlier_.data(), &prm, 5.991), "track");
+                       outlier_.data(), &prm, 5.991), "track"); }
         cnt_.track_pts += ofs; cnt_.pyr_left += n;
         track_order_ = TS;
     }
@@ -410,7 +423,7 @@ private:
             slots.push_back(streams_[s]->slot_right); imgs_.push_back(right[s]);
             strides_.push_back(strides ? strides[s] : cfg_.width);
         }
-        check(k_.pyramid((int)slots.size(), slots.data(), imgs_.data(), strides_.data(), is_device), "pyramid");
+        { KTimer kt_(cnt_); check(k_.pyramid((int)slots.size(), slots.data(), imgs_.data(), strides_.data(), is_device), "pyramid"); }
         cnt_.pyr_left += (long long)IS.size(); cnt_.pyr_right += (long long)DS.size();
     }
 
@@ -433,8 +446,8 @@ private:
         if (rects_.empty()) rects_.resize(2);
         corners_.assign((size_t)n * cfg_.num_features * 2, 0.f);
         ncorners_.assign((size_t)n, 0);
-        check(k_.gftt(n, jobs_gftt_.data(), ofs, rects_.data(), cfg_.num_features, 0.01, 20.0, corners_.data(),
-                      ncorners_.data()), "gftt");                  // :24
+        { KTimer kt_(cnt_); check(k_.gftt(n, jobs_gftt_.data(), ofs, rects_.data(), cfg_.num_features, 0.01, 20.0, corners_.data(),
+                      ncorners_.data()), "gftt"); }  // :24
         for (int i = 0; i < n; ++i) {
             Stream &st = *streams_[DS[i]];
             for (int c = 0; c < ncorners_[i]; ++c) {
@@ -475,7 +488,7 @@ private:
         err_.assign((size_t)std::max(ofs, 1), 0.f);
         if (prev_xy_.empty()) { prev_xy_.resize(2); next_xy_.resize(2); }
         svslam_lk_params prm = { 3, 30, 0.01, 1e-4, 1 };            // :105-109
-        check(k_.lk(n, jobs_lk_.data(), ofs, prev_xy_.data(), next_xy_.data(), status_.data(), err_.data(), &prm), "lk");
+        { KTimer kt_(cnt_); check(k_.lk(n, jobs_lk_.data(), ofs, prev_xy_.data(), next_xy_.data(), status_.data(), err_.data(), &prm), "lk"); }
         for (int i = 0; i < n; ++i) {
             Stream &st = *streams_[DS[i]];
             Frame *cur = st.current;
@@ -522,8 +535,8 @@ private:
         tri_xyz_.assign((size_t)std::max(ofs, 1) * 3, 0.0);
         tri_ok_.assign((size_t)std::max(ofs, 1), 0);
         if (ofs > 0)
-            check(k_.triangulate(n, jobs_tri_.data(), ofs, cam_l_, cfg_.cam_l.pose.v, cam_r_, cfg_.cam_r.pose.v,
-                                 uv_l_.data(), uv_r_.data(), tri_xyz_.data(), tri_ok_.data()), "triangulate");
+            { KTimer kt_(cnt_); check(k_.triangulate(n, jobs_tri_.data(), ofs, cam_l_, cfg_.cam_l.pose.v, cam_r_, cfg_.cam_r.pose.v,
+                                 uv_l_.data(), uv_r_.data(), tri_xyz_.data(), tri_ok_.data()), "triangulate"); }
         cnt_.tri_pts += ofs;
         for (int i = 0; i < n; ++i) {
             Stream &st = *streams_[MS[i]];
@@ -599,9 +612,9 @@ private:
         ba_chi2_.assign((size_t)std::max(oo, 1), 0.0);
         if (ba_pts_.empty()) ba_pts_.resize(3);
         if (ba_okf_.empty()) { ba_okf_.resize(1); ba_olm_.resize(1); ba_right_.resize(1); ba_uv_.resize(2); }
-        check(k_.local_ba(n, jobs_ba_.data(), cam_l_, cfg_.cam_l.pose.v, cam_r_, cfg_.cam_r.pose.v, ko,
+        { KTimer kt_(cnt_); check(k_.local_ba(n, jobs_ba_.data(), cam_l_, cfg_.cam_l.pose.v, cam_r_, cfg_.cam_r.pose.v, ko,
                           ba_poses_.data(), lo, ba_pts_.data(), oo, ba_okf_.data(), ba_olm_.data(), ba_right_.data(),
-                          ba_uv_.data(), cfg_.chi2_th, 10, ba_chi2_.data()), "local_ba");   // :150-164
+                          ba_uv_.data(), cfg_.chi2_th, 10, ba_chi2_.data()), "local_ba"); }  // :150-164
         for (int i = 0; i < n; ++i) {
             Stream &st = *streams_[MS[i]];
             BaGather &g = gathers_[i];

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""kernel micro-benchmarks on the GPU box: per-family HIP-event times for a batch of
+jobs, plus the per-phase cycle profile of the BA kernel.  Development tool."""
+import importlib
+import sys
+import os
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import common as cm
+
+svs = importlib.import_module("stereovision-slam_amd")
+
+
+def ba(nj=1, nkf=10, nlm=700, reps=3):
+    rng = np.random.default_rng(1)
+    c = svs.Context(cm.W, cm.H, max_slots=1, max_jobs=max(nj, 1), max_kf=nkf + 1, max_lm=4096, max_obs=16384)
+    probs = [cm.make_ba_problem(rng, nkf, nlm) for _ in range(nj)]
+    # thin the observations to a realistic ~4 per landmark
+    jobs = []
+    for p in probs:
+        keep = rng.random(len(p["okf"])) < 0.3
+        jobs.append((p["poses0"], p["pts0"], p["okf"][keep], p["olm"][keep], p["ori"][keep], p["ouv"][keep]))
+    print("BA jobs=%d nkf=%d nlm=%d nobs=%d" % (nj, nkf, nlm, len(jobs[0][2])))
+    c.ba_profile(True)
+    c.timing(True)
+    for r in range(reps):
+        c.local_ba(jobs, cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R)
+        ms, n, _ = c.timing_get("local_ba")
+        prof = c.ba_profile(True, read=True)
+        c.timing(True)
+        names = ["edge+J", "lm+pose", "dinv/Y/Sinit", "schur", "chol", "backsub", "errors"]
+        tot = sum(prof[:7])
+        print("  rep %d: %.3f ms/launch; trials %d; phase us (100MHz ticks/100): " % (r, ms / max(n, 1), prof[11]) +
+              ", ".join("%s %.1f" % (nm, prof[i] / 100.0) for i, nm in enumerate(names)) + "  sum %.1f" % (tot / 100.0))
+    c.close()
+
+
+def frontend(nj=1, npts=230):
+    l0, r0 = svs.synth_pair(3, 0); l1, _ = svs.synth_pair(3, 1)
+    import oracle_lib as orc
+    pts = orc.gftt(l0, max_corners=npts, min_dist=8.0)
+    c = svs.Context(cm.W, cm.H, max_slots=3 * nj, max_jobs=3 * nj, max_kf=0, max_lm=0, max_obs=0)
+    c.pyramid(list(range(3 * nj)), [l0, r0, l1] * nj)
+    q, st, _ = orc.lk(l0, r0, pts, pts)
+    xyz, ok = orc.triangulate(cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R, pts, q)
+    m = (st > 0) & (ok > 0)
+    c.timing(True)
+    for r in range(3):
+        c.pyramid(list(range(0, 3 * nj, 3)), [l0] * nj)
+        c.lk([(3 * i, 3 * i + 2, pts, pts) for i in range(nj)])
+        c.gftt([(3 * i, pts[:80]) for i in range(nj)])
+        q1 = c.lk([(3 * i, 3 * i + 2, pts, pts) for i in range(nj)])[0][0]
+        c.pose_only([(cm.EXT_L, xyz[m], q1[m]) for i in range(nj)], cm.CAM)
+        c.triangulate([(pts, q, None, 0.0) for i in range(nj)], cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R)
+    print("frontend jobs=%d npts=%d (edges %d): " % (nj, len(pts), m.sum()) +
+          ", ".join("%s %.1f us" % (f, 1e3 * c.timing_get(f)[0] / max(c.timing_get(f)[1], 1)) for f in svs.FAMILIES if c.timing_get(f)[1]))
+    c.close()
+
+
+def clock():
+    import ctypes as C
+    c = svs.Context(cm.W, cm.H, max_slots=1, max_jobs=1, max_kf=0, max_lm=0, max_obs=0)
+    for blocks, ms in ((1, 0.05), (1, 1.0), (1, 20.0), (256, 1.0), (2048, 20.0), (1, 0.05)):
+        mhz = C.c_double()
+        c.L.svslam_debug_clock_mhz(c.h, blocks, C.c_double(ms), C.byref(mhz))
+        print("clock probe: %4d blocks, %.2f ms spin -> %.0f MHz" % (blocks, ms, mhz.value))
+    c.close()
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("clock", "all"):
+        clock()
+    if what in ("ba", "all"):
+        ba(1, 10, 700); ba(1, 7, 300); ba(16, 10, 700)
+    if what in ("fe", "all"):
+        frontend(1); frontend(16); frontend(64)
