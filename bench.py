@@ -64,22 +64,14 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=1500, help="bound of the CPU baseline sample")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    elif torch.cuda.is_available():
-        torch.cuda.set_device(local_rank)
-
     svs = importlib.import_module("stereovision-slam_amd")
     pl = importlib.import_module("stereovision-slam_amd.pipeline")
+    sdist = importlib.import_module("stereovision-slam_amd.dist")
+    rk = sdist.init("nccl")                          # RCCL; one process per GPU
+    rank, local_rank, world = rk.rank, rk.local_rank, rk.world
+    if world == 1 and torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
     svs.load()                                      # fails loudly if the HIP library is missing
 
     S, Wm, K = args.streams, args.warmup, args.steps
@@ -97,17 +89,16 @@ def main():
     img = W * H
     d_left = ctx.dev_alloc(S * F * img)
     d_right = ctx.dev_alloc(S * F * img)
-    seed0 = 0x5EED0000 + rank * S
+    seeds = rk.stream_seeds(S)
     CH = 256
     for s in range(S):
         for f0 in range(0, F, CH):
-            vl, vr = zip(*[svs.synth_views(seed0 + s, f) for f in range(f0, min(F, f0 + CH))])
+            vl, vr = zip(*[svs.synth_views(seeds[s], f) for f in range(f0, min(F, f0 + CH))])
             svs.synth_render_device(list(vl), W, H, d_left + (s * F + f0) * img, device=local_rank)
             svs.synth_render_device(list(vr), W, H, d_right + (s * F + f0) * img, device=local_rank)
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        rk.barrier()
         if torch.cuda.is_available():
             torch.cuda.synchronize()
 
@@ -154,11 +145,7 @@ def main():
         torch.cuda.synchronize()
     t1 = time.perf_counter()
     barrier()
-    elapsed = t1 - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = rk.max_over_ranks(t1 - t0)
     c1 = counters_sum()
     cnt = {k: c1[k] - c0[k] for k in c1}
     fam_t = {}
@@ -204,8 +191,7 @@ def main():
         print(json.dumps(out), flush=True)
     for p in pipes:
         p.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    rk.close()
 
 
 def cpu_baseline(svs, pl, ctx, cfg, d_left, F, img, S, budget_frames, d_right):
