@@ -37,8 +37,11 @@ def test_pipeline_matches_cpu_twin(svs, monkeypatch):
     for f in range(10):
         for k in keys:
             assert np.array_equal(mg[f][k], mc[f][k]), (f, k, mg[f][k], mc[f][k])
-    assert np.allclose(eg[:10, :, 4:], ec[:10, :, 4:], atol=1e-6), np.abs(eg[:10] - ec[:10]).max()
-    assert np.allclose(eg[:10, :, :4], ec[:10, :, :4], atol=1e-7)
+    # absolute poses: the local BA fixes no vertex (src/backend.cpp:39-66), so each call leaves a
+    # 6-DoF gauge that only the LM damping pins; rounding differences move along it freely
+    # (the per-call parity tests compare gauge-invariant quantities at 1e-6).  5e-4 m here.
+    assert np.allclose(eg[:10, :, 4:], ec[:10, :, 4:], atol=5e-4), np.abs(eg[:10] - ec[:10]).max()
+    assert np.allclose(eg[:10, :, :4], ec[:10, :, :4], atol=5e-5)
     mism = sum(int((mg[f][k] != mc[f][k]).sum()) for f in range(N) for k in keys)
     print("metadata mismatches after frame 10:", mism, "of", N * len(seeds) * len(keys))
     assert mism <= 0.1 * N * len(seeds) * len(keys)
