@@ -41,6 +41,8 @@ int svs_pipe_step(void *p, const void *const *left, const void *const *right, in
 int svs_pipe_run_device(void *p, const void *left_base, const void *right_base, long long stream_stride,
                         long long frame_stride, int first_frame, int nframes, svs_frame_result *out);
 int svs_pipe_counters_get(void *p, svs_pipe_counters *out);
+/* keyframes.txt + landmarks.pcd of one stream, in the reference's formats (src/visual_odometry.cpp:198-310) */
+int svs_pipe_save_outputs(void *p, int stream, const char *dir, const char *dataset_dir, int left_cam_index);
 /* underlying svslam_ctx (product build) or NULL (CPU twin) */
 void *svs_pipe_kernel_ctx(void *p);
 

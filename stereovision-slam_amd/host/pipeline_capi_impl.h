@@ -107,6 +107,13 @@ int svs_pipe_run_device(void *p, const void *left_base, const void *right_base, 
     }
 }
 
+int svs_pipe_save_outputs(void *p, int stream, const char *dir, const char *dataset_dir, int left_cam_index)
+{
+    PipeHandle *h = static_cast<PipeHandle *>(p);
+    if (stream < 0 || stream >= h->pipe->nstreams()) return -1;
+    return h->pipe->SaveOutputs(stream, dir, dataset_dir, left_cam_index) ? 0 : -2;
+}
+
 int svs_pipe_counters_get(void *p, svs_pipe_counters *out)
 {
     const svs::Counters &c = static_cast<PipeHandle *>(p)->pipe->counters();

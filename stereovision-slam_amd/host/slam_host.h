@@ -23,6 +23,8 @@
 #include <cstdint>
 #include <cstring>
 #include <deque>
+#include <fstream>
+#include <iomanip>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -295,6 +297,42 @@ public:
             st.last_owned = std::move(st.cur_owned);   // null if the frame moved into kf_store
         }
         cnt_.ns_step += now_ns() - t_step0;
+    }
+
+    // VisualOdometry::saveSLAMOutputInFile (src/visual_odometry.cpp:198-310): keyframes.txt
+    // (dataset dir, left camera index, then `frame_id r00 r01 r02 tx r10 ... tz` of T_cw per
+    // keyframe in keyframe order, default ostream precision) and landmarks.pcd in the layout
+    // of pcl::io::savePCDFileASCII (float x y z, precision 8).  Consumed by the reference's
+    // DenseReconstruction::Initialize (src/dense_reconstruction.cpp:35-74).
+    bool SaveOutputs(int s, const std::string &dir, const std::string &dataset_dir, int left_cam_index)
+    {
+        Stream &st = *streams_[s];
+        std::ofstream pcd(dir + "/landmarks.pcd");
+        if (!pcd) return false;
+        const size_t n = st.map.landmarks_.size();
+        pcd << "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\n"
+            << "COUNT 1 1 1\nWIDTH " << n << "\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS " << n << "\nDATA ascii\n";
+        pcd << std::setprecision(8);
+        for (auto &kv : st.map.landmarks_)
+            pcd << (float)kv.second->pos[0] << " " << (float)kv.second->pos[1] << " " << (float)kv.second->pos[2] << "\n";
+        std::ofstream kf(dir + "/keyframes.txt");
+        if (!kf) return false;
+        kf << dataset_dir << std::endl << left_cam_index << std::endl;
+        for (auto &kv : st.map.keyframes_) {
+            const Frame *f = kv.second;
+            const double *q = f->pose.v;
+            const double x = q[0], y = q[1], z = q[2], w = q[3];
+            const double R[9] = { 1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                                  2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                                  2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y) };
+            kf << f->id << " ";
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 4; ++j) {
+                    kf << (j < 3 ? R[i * 3 + j] : q[4 + i]);
+                    if (i * 4 + j < 11) kf << " "; else kf << std::endl;
+                }
+        }
+        return true;
     }
 
 private:

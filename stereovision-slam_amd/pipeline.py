@@ -84,6 +84,7 @@ def _bind(L):
     L.svs_pipe_run_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_int,
                                       C.c_int, C.c_void_p]
     L.svs_pipe_counters_get.argtypes = [C.c_void_p, C.POINTER(Counters)]
+    L.svs_pipe_save_outputs.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int]
     L.svs_pipe_kernel_ctx.restype = C.c_void_p
     L.svs_pipe_kernel_ctx.argtypes = [C.c_void_p]
     return L
@@ -151,6 +152,12 @@ class Pipeline:
         c = Counters()
         self.L.svs_pipe_counters_get(self.h, C.byref(c))
         return {n: getattr(c, n) for n, _ in Counters._fields_}
+
+    def save_outputs(self, stream, out_dir, dataset_dir="./data/dataset/sequences/00", left_cam_index=0):
+        """keyframes.txt + landmarks.pcd in the reference's formats"""
+        rc = self.L.svs_pipe_save_outputs(self.h, stream, out_dir.encode(), dataset_dir.encode(), left_cam_index)
+        if rc != 0:
+            raise RuntimeError("svs_pipe_save_outputs failed (%d)" % rc)
 
     def kernel_ctx(self):
         return self.L.svs_pipe_kernel_ctx(self.h)
