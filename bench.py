@@ -55,11 +55,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("SVS_BENCH_STREAMS", "512")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("SVS_BENCH_STREAMS", "1536")),
                     help="independent stereo streams per GPU, advanced in lockstep")
-    ap.add_argument("--groups", type=int, default=int(os.environ.get("SVS_BENCH_GROUPS", "16")),
+    ap.add_argument("--groups", type=int, default=int(os.environ.get("SVS_BENCH_GROUPS", "3")),
                     help="host threads per GPU, each driving streams/groups streams through its own "
                          "svslam context (own HIP stream): one group's BA overlaps the others' tracking")
+    ap.add_argument("--host-threads", type=int, default=int(os.environ.get("SVS_BENCH_HOST_THREADS", "16")),
+                    help="threads per group for the per-stream host bookkeeping (Frontend/Map/Backend glue)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=1500, help="bound of the CPU baseline sample")
     args = ap.parse_args()
@@ -80,7 +82,7 @@ def main():
         G -= 1
     Sg = S // G
     F = Wm + K
-    cfg = pl.default_config(W, H)
+    cfg = pl.default_config(W, H, host_threads=max(1, args.host_threads))
     pipes = [pl.Pipeline(cfg, nstreams=Sg, device=local_rank) for _ in range(G)]
     ctxs = [svs.Context.borrow(p.kernel_ctx(), W, H) for p in pipes]   # alloc / timing through the pipelines' contexts
     ctx = ctxs[0]
@@ -153,6 +155,12 @@ def main():
         parts = [c.timing_get(f) for c in ctxs]
         fam_t[f] = (sum(p[0] for p in parts), sum(p[1] for p in parts), sum(p[2] for p in parts))
     res = np.concatenate(res_g, axis=1)
+    import ctypes as _C
+    hostns = np.zeros(8)
+    for c in ctxs:
+        o = (_C.c_longlong * 8)()
+        c.L.svslam_debug_host_ns(c.h, o)
+        hostns += np.array(list(o), float)
 
     ok_frames = int((res["status"] != 3).sum())      # not LOST
     total_frames = S * K * world
@@ -174,7 +182,7 @@ def main():
             "config": {"workload": "configs[1..3] on synthetic input: full Frontend::AddFrame hot path on HIP "
                                    "(GFTT + pyramidal LK + triangulation + pose-only LM) with synchronous HIP "
                                    "local BA, config-00.yaml hyper-parameters (150 features, 10 active keyframes)",
-                       "streams_per_gpu": S, "host_threads_per_gpu": G, "frame": "%dx%d u8 stereo pair" % (W, H),
+                       "streams_per_gpu": S, "host_threads_per_gpu": G, "bookkeeping_threads_per_group": args.host_threads, "frame": "%dx%d u8 stereo pair" % (W, H),
                        "keyframes_in_timed_region": cnt["keyframes"], "tracked_ok_fraction": ok_frames / (S * K),
                        "parallelism": "%d independent streams/GPU x %d GPU(s), no collective" % (S, world)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
@@ -183,7 +191,9 @@ def main():
                          "algorithmic_bytes_per_launch": round(abytes / max(launches, 1), 1)},
             "kernel_ms": {f: round(fam_t[f][0], 3) for f in fam_t},
             "host_ms_per_step": {"in_step": round(cnt["ns_step"] / 1e6 / K / G, 3),
-                                 "in_abi_calls": round(cnt["ns_kernel_calls"] / 1e6 / K / G, 3)},
+                                 "in_abi_calls": round(cnt["ns_kernel_calls"] / 1e6 / K / G, 3),
+                                 "h2d_enqueue": round(hostns[0] / 1e6 / K / G, 3), "d2h_enqueue": round(hostns[1] / 1e6 / K / G, 3),
+                                 "stream_wait": round(hostns[2] / 1e6 / K / G, 3), "event_collect": round(hostns[5] / 1e6 / K / G, 3)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(svs, pl, ctx, cfg, d_left, F, img, S, min(args.cpu_frames, S * F),
@@ -195,6 +205,7 @@ def main():
 
 
 def cpu_baseline(svs, pl, ctx, cfg, d_left, F, img, S, budget_frames, d_right):
+    cfg = pl.default_config(W, H)          # single-threaded twin
     """The CPU twin (reference-shaped host logic over the oracle kernels, single thread) on a
     bounded sample of the same workload: the first streams' frames, downloaded from HBM."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))

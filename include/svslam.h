@@ -205,6 +205,13 @@ int svslam_track_batch(svslam_ctx *ctx, int njobs, svslam_track_job *jobs,
                        uint8_t *status, uint8_t *outlier,
                        const svslam_lk_params *p, double chi2_th);
 
+/* host threads the library may use to prepare a batched call (per-problem BA structure
+ * building); default 1.                                                        */
+int svslam_set_host_threads(svslam_ctx *ctx, int n);
+/* test hooks */
+int svslam_debug_host_ns(svslam_ctx *ctx, long long *out8);
+int svslam_debug_clock_mhz(svslam_ctx *ctx, int blocks, double ms, double *mhz);
+
 /* ---- device memory helpers for HBM-resident inputs (bench, pipelining) --- */
 int svslam_dev_alloc(svslam_ctx *ctx, size_t bytes, void **out);
 int svslam_dev_free(svslam_ctx *ctx, void *p);

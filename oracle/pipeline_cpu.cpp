@@ -26,6 +26,7 @@ public:
         jac_mode_ = jm ? std::atoi(jm) : 1;
     }
     void *ctx() { return nullptr; }
+    void set_host_threads(int) {}
     const char *last_error() { return err_.c_str(); }
 
     int pyramid(int n, const int *slots, const void *const *imgs, const int *strides, int)

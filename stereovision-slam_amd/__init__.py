@@ -23,6 +23,7 @@ ABI_SYMBOLS = [
     "svslam_pose_only_batch", "svslam_local_ba_batch", "svslam_track_batch",
     "svslam_dev_alloc", "svslam_dev_free", "svslam_dev_upload", "svslam_dev_download", "svslam_sync",
     "svslam_timing_enable", "svslam_timing_reset", "svslam_timing_get", "svslam_ba_profile",
+    "svslam_set_host_threads", "svslam_debug_host_ns", "svslam_debug_clock_mhz",
 ]
 
 FAMILIES = {"pyramid": 0, "lk": 1, "gftt": 2, "triangulate": 3, "pose_only": 4, "local_ba": 5}

@@ -244,6 +244,20 @@ __device__ __forceinline__ void d_inv3(const double *A, double *Ai)
     Ai[6] = c2 * id; Ai[7] = (A[1] * A[6] - A[0] * A[7]) * id; Ai[8] = (A[0] * A[4] - A[1] * A[3]) * id;
 }
 
+// 6x3 blocks (18 doubles = 144 B, 16-B aligned) moved as 9 x 16-byte accesses
+__device__ __forceinline__ void ld_block18(const double *p, double *o)
+{
+    const double2 *q = reinterpret_cast<const double2 *>(p);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { double2 v = q[t]; o[2 * t] = v.x; o[2 * t + 1] = v.y; }
+}
+__device__ __forceinline__ void st_block18(double *p, const double *o)
+{
+    double2 *q = reinterpret_cast<double2 *>(p);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) q[t] = make_double2(o[2 * t], o[2 * t + 1]);
+}
+
 // optional cycle profile of job 0 (thread 0): index = phase
 #define BA_PROF_N 12
 #define BA_PROF(i) do { if (prof && tid == 0) { long long t_ = wall_clock64(); prof[i] += t_ - tprev; tprev = t_; } } while (0)
@@ -261,10 +275,10 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
     if (nobs <= 0 || na <= 0) { if (tid == 0) jd.iters_done = 0; return; }
     long long *prof = (prof_all && job == 0) ? prof_all : nullptr;
     long long tprev = prof ? wall_clock64() : 0;
-    // LDS carve (all dynamic): S[np*(np+1)] | bs[np] | xp[np] | Hpp[36*na] | bp[np] | red[16] | flag
+    // LDS carve (all dynamic): S[(np+1)*(np+1)] | bs[np] | xp[np] | Hpp[36*na] | bp[np] | red[16] | flag
     const int ld = np + 1;   // odd row stride (in doubles): spreads LDS banks
     double *S = reinterpret_cast<double *>(smem);
-    double *bs = S + (size_t)np * ld;
+    double *bs = S + (size_t)(np + 1) * ld;    // row np of S carries the right-hand side
     double *xp = bs + np;
     double *Hpp = xp + np;
     double *bp = Hpp + 36 * na;
@@ -461,8 +475,9 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
 #pragma unroll
                     for (int a = 0; a < 3; ++a) db[3 * j + a] = Di[a * 3] * b0 + Di[a * 3 + 1] * b1 + Di[a * 3 + 2] * b2;
                 }
-                const double *w1 = W + 18 * (size_t)b;
-                double *y = Y + 18 * (size_t)b;
+                // W and Y blocks are 144 B, 16-B aligned: move them as 9 x double2
+                double w1[18], y[18];
+                ld_block18(W + 18 * (size_t)b, w1);
 #pragma unroll
                 for (int a = 0; a < 6; ++a) {
                     const double x0 = w1[a * 3], x1 = w1[a * 3 + 1], x2 = w1[a * 3 + 2];
@@ -470,6 +485,7 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
                     y[a * 3 + 1] = x0 * Di[1] + x1 * Di[4] + x2 * Di[7];
                     y[a * 3 + 2] = x0 * Di[2] + x1 * Di[5] + x2 * Di[8];
                 }
+                st_block18(Y + 18 * (size_t)b, y);
             }
             for (int i = tid; i < np * np; i += BA_THREADS) {
                 int r = i / np, c = i - r * np;
@@ -480,58 +496,50 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
             }
             __syncthreads();
             BA_PROF(2);
-            // ---- Schur assembly: 16-lane row per (pose pair, 3-row half) task, then bs tasks
+            // ---- Schur assembly: one 16-lane row per pose pair (then one per pose for bs)
             {
                 const int npairs = na * (na + 1) / 2;
                 const int row = tid >> 4, rl = tid & 15;
-                for (int t = row; t < 2 * npairs + na; t += BA_ROWS) {
-                    if (t < 2 * npairs) {
-                        const int pidx = t >> 1, half = t & 1;
-                        int a = 0, rem = pidx;
+                for (int t = row; t < npairs + na; t += BA_ROWS) {
+                    if (t < npairs) {
+                        int a = 0, rem = t;
                         while (rem >= na - a) { rem -= na - a; ++a; }
                         const int b = a + rem;
-                        double acc[18];
+                        double acc[36];
 #pragma unroll
-                        for (int z = 0; z < 18; ++z) acc[z] = 0;
-                        for (int c = pc_start[pidx] + rl; c < pc_start[pidx + 1]; c += 16) {
-                            const double *y = Y + 18 * (size_t)pc_y[c] + 9 * half;
-                            const double *w2 = W + 18 * (size_t)pc_w[c];
-                            double yy[9], ww[18];
+                        for (int z = 0; z < 36; ++z) acc[z] = 0;
+                        for (int c = pc_start[t] + rl; c < pc_start[t + 1]; c += 16) {
+                            double yy[18], ww[18];
+                            ld_block18(Y + 18 * (size_t)pc_y[c], yy);
+                            ld_block18(W + 18 * (size_t)pc_w[c], ww);
 #pragma unroll
-                            for (int z = 0; z < 9; ++z) yy[z] = y[z];
-#pragma unroll
-                            for (int z = 0; z < 18; ++z) ww[z] = w2[z];
-#pragma unroll
-                            for (int r = 0; r < 3; ++r)
+                            for (int r = 0; r < 6; ++r)
 #pragma unroll
                                 for (int cc = 0; cc < 6; ++cc)
                                     acc[r * 6 + cc] += yy[r * 3] * ww[cc * 3] + yy[r * 3 + 1] * ww[cc * 3 + 1] + yy[r * 3 + 2] * ww[cc * 3 + 2];
                         }
 #pragma unroll
-                        for (int z = 0; z < 18; ++z) acc[z] = row_sum_f64(acc[z]);
-                        // every lane of the row now holds the 18 sums; lane z retires entry z,
-                        // lanes 0,1 additionally retire entries 16,17
-                        double mine = acc[0];
+                        for (int z = 0; z < 36; ++z) acc[z] = row_sum_f64(acc[z]);
+                        // every lane of the row holds the 36 sums; lane l retires entries l, l+16, l+32
 #pragma unroll
-                        for (int z = 1; z < 16; ++z) mine = (rl == z) ? acc[z] : mine;
-                        {
-                            const int r = 3 * half + rl / 6, cc = rl % 6;
-                            S[(size_t)(6 * a + r) * ld + 6 * b + cc] -= mine;
-                            if (a != b) S[(size_t)(6 * b + cc) * ld + 6 * a + r] -= mine;
-                        }
-                        if (rl < 2) {
-                            const int z = 16 + rl;
-                            const double v = (rl == 0) ? acc[16] : acc[17];
-                            const int r = 3 * half + z / 6, cc = z % 6;
-                            S[(size_t)(6 * a + r) * ld + 6 * b + cc] -= v;
-                            if (a != b) S[(size_t)(6 * b + cc) * ld + 6 * a + r] -= v;
+                        for (int g = 0; g < 3; ++g) {
+                            double mine = acc[16 * g];
+#pragma unroll
+                            for (int z = 1; z < 16; ++z) if (16 * g + z < 36) mine = (rl == z) ? acc[16 * g + z] : mine;
+                            const int z = 16 * g + rl;
+                            if (z < 36) {
+                                const int r = z / 6, cc = z % 6;
+                                S[(size_t)(6 * a + r) * ld + 6 * b + cc] -= mine;
+                                if (a != b) S[(size_t)(6 * b + cc) * ld + 6 * a + r] -= mine;
+                            }
                         }
                     } else {
-                        const int a = t - 2 * npairs;
+                        const int a = t - npairs;
                         double acc[6] = { 0, 0, 0, 0, 0, 0 };
                         for (int i = pb_start[a] + rl; i < pb_start[a + 1]; i += 16) {
                             const int b = pb_blk[i];
-                            const double *w1 = W + 18 * (size_t)b;
+                            double w1[18];
+                            ld_block18(W + 18 * (size_t)b, w1);
                             const double *d3 = db + 3 * (size_t)blk_lm[b];
                             const double d0 = d3[0], d1 = d3[1], d2 = d3[2];
 #pragma unroll
@@ -550,42 +558,106 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
             }
             __syncthreads();
             BA_PROF(3);
-            // ---- Cholesky S = L L^T (lower, in place) and the two triangular solves: wave 0
+            // ---- blocked (6x6 = one pose) right-looking Cholesky S = L L^T in LDS, one wave, one
+            // matrix row per lane; the right-hand side rides along as row np, so L y = bs
+            // comes out of the same sweep; then L^T x = y.  Per block column: every lane
+            // factors the 6x6 diagonal block redundantly in registers (broadcast LDS reads),
+            // solves its own row of the panel, and updates its own row of the trailing matrix.
             if (wv == 0) {
                 int ok = 1;
-                for (int k = 0; k < np; ++k) {
-                    for (int i = k + lane; i < np; i += 64) {
-                        const double *ri = S + (size_t)i * ld, *rk = S + (size_t)k * ld;
-                        double v0 = ri[k], v1 = 0, v2 = 0, v3 = 0;
-                        int m = 0;
-                        for (; m + 3 < k; m += 4) {
-                            v0 -= ri[m] * rk[m]; v1 -= ri[m + 1] * rk[m + 1];
-                            v2 -= ri[m + 2] * rk[m + 2]; v3 -= ri[m + 3] * rk[m + 3];
+                double *rhs = S + (size_t)np * ld;        // extra row: bs on entry, y on exit
+                double *invd = xp;                         // 1 / L_kk (xp is free until the back-substitution)
+                for (int i = lane; i < np; i += 64) rhs[i] = bs[i];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                for (int kb = 0; kb < na; ++kb) {
+                    const int c0 = 6 * kb;
+                    // 1. + 2. diagonal block -> Ld (lower), inverse pivots
+                    double Ld[6][6], inv[6];
+#pragma unroll
+                    for (int r = 0; r < 6; ++r)
+#pragma unroll
+                        for (int c = 0; c <= r; ++c) Ld[r][c] = S[(size_t)(c0 + r) * ld + c0 + c];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {
+                        double d = Ld[c][c];
+#pragma unroll
+                        for (int m = 0; m < c; ++m) d -= Ld[c][m] * Ld[c][m];
+                        if (!(d > 0)) ok = 0;
+                        // rsqrt: hardware estimate + 2 Newton steps
+                        double y = __builtin_amdgcn_rsq(d);
+                        y = y * (1.5 - 0.5 * d * y * y);
+                        y = y * (1.5 - 0.5 * d * y * y);
+                        inv[c] = y;
+                        Ld[c][c] = d * y;
+#pragma unroll
+                        for (int r = c + 1; r < 6; ++r) {
+                            double v = Ld[r][c];
+#pragma unroll
+                            for (int m = 0; m < c; ++m) v -= Ld[r][m] * Ld[c][m];
+                            Ld[r][c] = v * y;
                         }
-                        for (; m < k; ++m) v0 -= ri[m] * rk[m];
-                        S[(size_t)i * ld + k] = (v0 + v1) + (v2 + v3);
+                    }
+                    if (!ok) break;
+                    if (lane < 6) {
+                        double v = inv[0];
+#pragma unroll
+                        for (int c = 1; c < 6; ++c) v = (lane == c) ? inv[c] : v;
+                        invd[c0 + lane] = v;
+                    }
+                    // 3. panel: own rows i >= c0 (rows inside the diagonal block reproduce Ld)
+                    for (int i = c0 + lane; i <= np; i += 64) {
+                        double *ri = S + (size_t)i * ld + c0;
+                        double x[6];
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) x[c] = ri[c];
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) {
+                            double v = x[c];
+#pragma unroll
+                            for (int m = 0; m < c; ++m) v -= x[m] * Ld[c][m];
+                            x[c] = v * inv[c];
+                        }
+                        const int r = i - c0;
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) ri[c] = (r < 6 && c > r) ? 0.0 : x[c];
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    const double d = S[(size_t)k * ld + k];
-                    if (!(d > 0)) { ok = 0; break; }
-                    const double sd = sqrt(d), isd = 1.0 / sd;
-                    for (int i = k + lane; i < np; i += 64) S[(size_t)i * ld + k] = (i == k) ? sd : S[(size_t)i * ld + k] * isd;
+                    // 4. trailing update: S[i][6jb + c'] -= sum_c L[i][c0 + c] * L[6jb + c'][c0 + c]
+                    for (int i = c0 + 6 + lane; i <= np; i += 64) {
+                        const double *pi = S + (size_t)i * ld + c0;
+                        double x[6];
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) x[c] = pi[c];
+                        const int jb_last = (i < np) ? i / 6 : na - 1;     // only the lower triangle is used
+                        for (int jb = kb + 1; jb <= jb_last; ++jb) {
+                            double *u = S + (size_t)i * ld + 6 * jb;
+                            const double *P = S + (size_t)(6 * jb) * ld + c0;
+                            double uu[6];
+#pragma unroll
+                            for (int cp = 0; cp < 6; ++cp) uu[cp] = u[cp];
+#pragma unroll
+                            for (int cp = 0; cp < 6; ++cp) {
+                                const double *pr = P + (size_t)cp * ld;
+                                uu[cp] -= x[0] * pr[0] + x[1] * pr[1] + x[2] * pr[2] + x[3] * pr[3] + x[4] * pr[4] + x[5] * pr[5];
+                            }
+#pragma unroll
+                            for (int cp = 0; cp < 6; ++cp) u[cp] = uu[cp];
+                        }
+                    }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 }
+                if (prof && tid == 0) { long long t_ = wall_clock64(); prof[7] += t_ - tprev; }
                 if (ok) {
-                    for (int i = lane; i < np; i += 64) xp[i] = bs[i];
+                    // rhs holds y; back-substitution L^T x = y with the stored inverse pivots
+                    double ivk[2];
+                    ivk[0] = (lane < np) ? invd[lane] : 0.0;
+                    ivk[1] = (lane + 64 < np) ? invd[lane + 64] : 0.0;
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    for (int k = 0; k < np; ++k) {           // L y = bs
-                        const double yk = xp[k] / S[(size_t)k * ld + k];
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        for (int i = k + lane; i < np; i += 64) {
-                            if (i == k) xp[i] = yk;
-                            else xp[i] -= S[(size_t)i * ld + k] * yk;
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    }
-                    for (int k = np - 1; k >= 0; --k) {      // L^T x = y
-                        const double xk = xp[k] / S[(size_t)k * ld + k];
+                    for (int i = lane; i < np; i += 64) xp[i] = rhs[i] ;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    for (int k = np - 1; k >= 0; --k) {
+                        const double ik = readlane_f64(ivk[k >> 6], k & 63);
+                        const double xk = xp[k] * ik;
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         for (int i = lane; i <= k; i += 64) {
                             if (i == k) xp[i] = xk;
@@ -668,5 +740,5 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
 static inline size_t ba_lds_bytes(int max_kf)
 {
     size_t np = 6 * (size_t)max_kf;
-    return (np * (np + 1) + 3 * np + 36 * (size_t)max_kf + BA_WAVES) * sizeof(double) + 64;
+    return ((np + 1) * (np + 1) + 3 * np + 36 * (size_t)max_kf + BA_WAVES) * sizeof(double) + 64;
 }

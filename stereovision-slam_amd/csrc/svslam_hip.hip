@@ -4,6 +4,7 @@
 // No CPU fallback exists: if no HIP device is usable svslam_create fails.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -14,6 +15,8 @@
 #include <vector>
 
 #include "../../include/svslam.h"
+#include "../host/thread_pool.h"
+#include <memory>
 #include "dev_common.h"
 #include "k_pyramid.h"
 #include "k_lk.h"
@@ -64,7 +67,10 @@ struct svslam_ctx {
     // BA scratch
     BaWork bw;
     std::vector<BaHostStruct> ba_hs;
+    std::unique_ptr<svs::ThreadPool> pool;   // host-side per-problem preparation
     long long *d_ba_prof = nullptr;
+    // host-side wall time (ns): 0 h2d enqueue, 1 d2h enqueue, 2 stream wait, 3 launches, 4 staging memcpy/prep
+    long long host_ns[8] = { 0 };
     // timing
     bool timing = false;
     Timing tm;
@@ -142,16 +148,28 @@ void tm_collect(svslam_ctx *c)
     c->nev = 0;
 }
 
+inline long long now_ns()
+{
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 int h2d(svslam_ctx *c, size_t from, size_t to)
 {
+    const long long t0 = now_ns();
     if (to > from) HIPCHK(c, hipMemcpyAsync(c->ar.d + from, c->ar.h + from, to - from, hipMemcpyHostToDevice, c->stream));
+    c->host_ns[0] += now_ns() - t0;
     return 0;
 }
 int d2h_sync(svslam_ctx *c, size_t from, size_t to)
 {
+    long long t0 = now_ns();
     if (to > from) HIPCHK(c, hipMemcpyAsync(c->ar.h + from, c->ar.d + from, to - from, hipMemcpyDeviceToHost, c->stream));
+    long long t1 = now_ns();
+    c->host_ns[1] += t1 - t0;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    t0 = now_ns();
+    c->host_ns[2] += t0 - t1;
     tm_collect(c);
+    c->host_ns[5] += now_ns() - t0;
     return 0;
 }
 
@@ -618,11 +636,19 @@ int svslam_local_ba_batch(svslam_ctx *c, int njobs, svslam_ba_job *jobs, const d
     std::vector<BaHostStruct> &hs = c->ba_hs;
     if ((int)hs.size() < njobs) hs.resize(njobs);
     size_t aux_total = 0;
-    for (int i = 0; i < njobs; ++i) {
-        BaJob bj;
-        memcpy(&bj, &jobs[i], sizeof(bj));
-        hs[i].build(bj, obs_kf, obs_lm);
-        aux_total += hs[i].aux_ints(bj);
+    {
+        auto build_one = [&](int i) {
+            BaJob bj;
+            memcpy(&bj, &jobs[i], sizeof(bj));
+            hs[i].build(bj, obs_kf, obs_lm);
+        };
+        if (c->pool && njobs > 1) c->pool->parallel_for(njobs, build_one);
+        else for (int i = 0; i < njobs; ++i) build_one(i);
+        for (int i = 0; i < njobs; ++i) {
+            BaJob bj;
+            memcpy(&bj, &jobs[i], sizeof(bj));
+            aux_total += hs[i].aux_ints(bj);
+        }
     }
     size_t ocams = c->ar.take(sizeof(BaCams));
     size_t okf = c->ar.take(sizeof(int) * std::max(total_obs, 1));
@@ -649,13 +675,21 @@ int svslam_local_ba_batch(svslam_ctx *c, int njobs, svslam_ba_job *jobs, const d
     {
         size_t aofs = 0;
         int *aux = hp<int>(c, oaux);
+        std::vector<size_t> aoff((size_t)njobs);
         for (int i = 0; i < njobs; ++i) {
             BaJob bj;
             memcpy(&bj, &jobs[i], sizeof(bj));
-            hs[i].write(bj, aux + aofs, dj[i]);
-            dj[i].aux_ofs = (int)aofs;
+            aoff[(size_t)i] = aofs;
             aofs += hs[i].aux_ints(bj);
         }
+        auto write_one = [&](int i) {
+            BaJob bj;
+            memcpy(&bj, &jobs[i], sizeof(bj));
+            hs[i].write(bj, aux + aoff[(size_t)i], dj[i]);
+            dj[i].aux_ofs = (int)aoff[(size_t)i];
+        };
+        if (c->pool && njobs > 1) c->pool->parallel_for(njobs, write_one);
+        else for (int i = 0; i < njobs; ++i) write_one(i);
     }
     if (total_kf > 0) memcpy(hp<void>(c, oposes), poses, sizeof(double) * 7 * total_kf);
     if (total_lm > 0) memcpy(hp<void>(c, opts), pts, sizeof(double) * 3 * total_lm);
@@ -672,6 +706,22 @@ int svslam_local_ba_batch(svslam_ctx *c, int njobs, svslam_ba_job *jobs, const d
     if (total_kf > 0) memcpy(poses, hp<void>(c, oposes), sizeof(double) * 7 * total_kf);
     if (total_lm > 0) memcpy(pts, hp<void>(c, opts), sizeof(double) * 3 * total_lm);
     if (total_obs > 0) memcpy(edge_chi2, hp<void>(c, ochi), sizeof(double) * total_obs);
+    return 0;
+}
+
+// number of host threads the library may use to prepare batched calls (BA structure
+// building is per problem and independent); default 1
+int svslam_set_host_threads(svslam_ctx *c, int n)
+{
+    c->pool.reset(n > 1 ? new svs::ThreadPool(n) : nullptr);
+    return 0;
+}
+
+// test hook: host-side wall time per category since the last call (ns):
+// 0 h2d enqueue, 1 d2h enqueue, 2 stream wait, 5 event collection
+int svslam_debug_host_ns(svslam_ctx *c, long long *out8)
+{
+    for (int i = 0; i < 8; ++i) { out8[i] = c->host_ns[i]; c->host_ns[i] = 0; }
     return 0;
 }
 

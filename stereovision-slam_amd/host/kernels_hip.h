@@ -24,6 +24,7 @@ public:
     HipKernels &operator=(const HipKernels &) = delete;
 
     svslam_ctx *ctx() { return ctx_; }
+    void set_host_threads(int n) { svslam_set_host_threads(ctx_, n); }
     const char *last_error() { return svslam_last_error(ctx_); }
 
     int pyramid(int n, const int *slots, const void *const *imgs, const int *strides, int is_device)

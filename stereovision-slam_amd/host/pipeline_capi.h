@@ -16,6 +16,7 @@ typedef struct svs_pipe_config {
     int width, height;
     double cam_l[4], ext_l[7], cam_r[4], ext_r[7];
     int max_lm, max_obs;      /* BA limits per problem */
+    int host_threads;         /* threads for the per-stream host bookkeeping (>=1) */
 } svs_pipe_config;
 
 typedef struct svs_frame_result {

@@ -49,7 +49,9 @@ void *svs_pipe_create(const svs_pipe_config *cfg, int nstreams, int device)
         lim.max_pts = 512; lim.max_corners = cfg->num_features;
         lim.max_kf = cfg->num_active_keyframes + 1; lim.max_lm = cfg->max_lm; lim.max_obs = cfg->max_obs;
         h->kernels.reset(SVS_PIPE_MAKE_KERNELS(lim));
-        h->pipe.reset(new svs::Pipeline<SVS_PIPE_KERNELS>(to_config(*cfg), *h->kernels, nstreams));
+        h->kernels->set_host_threads(cfg->host_threads > 0 ? cfg->host_threads : 1);
+        h->pipe.reset(new svs::Pipeline<SVS_PIPE_KERNELS>(to_config(*cfg), *h->kernels, nstreams,
+                                                             cfg->host_threads > 0 ? cfg->host_threads : 1));
         h->lp.resize(nstreams); h->rp.resize(nstreams); h->res.resize(nstreams);
         return h.release();
     } catch (const std::exception &e) {

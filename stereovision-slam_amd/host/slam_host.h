@@ -20,12 +20,13 @@
 #pragma once
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <deque>
 #include <fstream>
 #include <iomanip>
-#include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -33,6 +34,7 @@
 
 #include "../../include/svslam.h"
 #include "se3.h"
+#include "thread_pool.h"
 
 namespace svs {
 
@@ -67,6 +69,7 @@ struct Frame {
     std::vector<uint8_t> right_ok;    // 0 == nullptr in the reference
     Frame *prev_keyframe = nullptr;
     SE3 relative_pose_pkf;
+    int ba_local = -1;                // index in the current BA problem (scratch of Backend::Optimize)
 };
 
 struct ObsRef {
@@ -87,6 +90,9 @@ struct MapPoint {
 inline Feature &feat_of(const ObsRef &r) { return r.is_left ? r.frame->left[r.idx] : r.frame->right[r.idx]; }
 
 // ------------------------------------------------------------------ Map
+// The reference keeps four unordered_maps (src/map.h:15-16).  Ids come from monotonically
+// increasing factories, so "all" containers are append-only arrays indexed by id and the
+// "active" containers are id-sorted vectors: no node allocation on the per-frame path.
 class Map {
 public:
     explicit Map(int num_active) : num_active_keyframes_(num_active) {}
@@ -94,21 +100,23 @@ public:
     MapPoint *CreateNewMappoint()       // src/mappoint.cpp:88-98 (per-stream factory)
     {
         store_.emplace_back();
-        store_.back().id = mp_factory_id_++;
+        store_.back().id = (long)store_.size() - 1;
         return &store_.back();
     }
     MapPoint *point(long id) { return id >= 0 ? &store_[(size_t)id] : nullptr; }
+    size_t num_landmarks() const { return store_.size(); }                 // Map::landmarks_
+    const MapPoint &landmark(size_t i) const { return store_[i]; }
 
     void InsertMapPoint(MapPoint *mp)   // src/map.cpp:69-74
     {
-        landmarks_[mp->id] = mp;
-        active_landmarks_[mp->id] = mp;
+        // landmarks_[id] = mp is implicit (store_); ids are new, so appending keeps id order
+        active_landmarks_.push_back(mp);
     }
     void InsertKeyFrame(Frame *frame)   // src/map.cpp:53-67
     {
         current_frame_ = frame;
-        keyframes_[frame->keyframe_id] = frame;
-        active_keyframes_[frame->keyframe_id] = frame;
+        keyframes_.push_back(frame);              // keyframe_id == index
+        active_keyframes_.push_back(frame);
         if ((int)active_keyframes_.size() > num_active_keyframes_) RemoveOldKeyframe();
     }
     void AddObservation(MapPoint *mp, const ObsRef &f)   // src/mappoint.cpp:22-36
@@ -130,26 +138,28 @@ public:
     }
     void CleanMap()                     // src/map.cpp:21-40
     {
-        for (auto it = active_landmarks_.begin(); it != active_landmarks_.end();) {
-            if (it->second->observed_times == 0) it = active_landmarks_.erase(it);
-            else ++it;
-        }
+        active_landmarks_.erase(std::remove_if(active_landmarks_.begin(), active_landmarks_.end(),
+                                               [](MapPoint *m) { return m->observed_times == 0; }),
+                                active_landmarks_.end());
     }
     void RemoveOldKeyframe()            // src/map.cpp:76-181
     {
         if (!current_frame_) return;
         double max_dis = 0, min_dis = 999999;
-        long max_kf_id = 0, min_kf_id = 0;
+        Frame *max_kf = nullptr, *min_kf = nullptr;
         SE3 Twc = current_frame_->pose.inverse();
-        for (auto &kf : active_keyframes_) {
-            if (kf.second == current_frame_) continue;
-            double dis = (kf.second->pose * Twc).log_norm();
-            if (dis > max_dis) { max_dis = dis; max_kf_id = kf.first; }
-            if (dis < min_dis) { min_dis = dis; min_kf_id = kf.first; }
+        for (Frame *kf : active_keyframes_) {
+            if (kf == current_frame_) continue;
+            double dis = (kf->pose * Twc).log_norm();
+            if (dis > max_dis) { max_dis = dis; max_kf = kf; }
+            if (dis < min_dis) { min_dis = dis; min_kf = kf; }
         }
         const double min_dis_th = 0.2;
-        Frame *rm = (min_dis < min_dis_th) ? active_keyframes_.at(min_kf_id) : active_keyframes_.at(max_kf_id);
-        active_keyframes_.erase(rm->keyframe_id);
+        // the reference indexes with the ids it found (default id 0 if nothing qualified)
+        Frame *rm = (min_dis < min_dis_th) ? min_kf : max_kf;
+        if (!rm) rm = keyframes_.empty() ? nullptr : keyframes_[0];
+        if (!rm) return;
+        active_keyframes_.erase(std::remove(active_keyframes_.begin(), active_keyframes_.end(), rm), active_keyframes_.end());
         for (size_t i = 0; i < rm->left.size(); ++i)
             if (rm->left[i].mp >= 0) RemoveObservation(point(rm->left[i].mp), ObsRef{ rm, (int)i, true });
         for (size_t i = 0; i < rm->right.size(); ++i) {
@@ -159,12 +169,11 @@ public:
         CleanMap();
     }
 
-    std::map<long, Frame *> keyframes_, active_keyframes_;
-    std::map<long, MapPoint *> landmarks_, active_landmarks_;
+    std::vector<Frame *> keyframes_, active_keyframes_;   // id-ascending
+    std::vector<MapPoint *> active_landmarks_;            // id-ascending
 
 private:
     std::deque<MapPoint> store_;
-    long mp_factory_id_ = 0;
     Frame *current_frame_ = nullptr;
     int num_active_keyframes_;
 };
@@ -190,6 +199,22 @@ struct Counters {                      // workload accounting for the roofline (
     long long ns_step = 0, ns_kernel_calls = 0;   // wall time inside step() / inside the C-ABI calls
 };
 
+// BA job bookkeeping between gather and scatter (per stream, reused)
+struct BaGather {
+    std::vector<Frame *> kfs;
+    std::vector<MapPoint *> lms;
+    std::vector<ObsRef> edge_feat;
+    std::vector<double> poses, pts;
+    std::vector<int> okf, olm;
+    std::vector<uint8_t> right;
+    std::vector<float> uv;
+    void clear()
+    {
+        kfs.clear(); lms.clear(); edge_feat.clear(); poses.clear(); pts.clear(); okf.clear(); olm.clear();
+        right.clear(); uv.clear();
+    }
+};
+
 struct Stream {
     explicit Stream(const Config &c) : map(c.num_active_keyframes) {}
     Map map;
@@ -203,23 +228,20 @@ struct Stream {
     long frame_factory_id = 0, kf_factory_id = 0;
     int slot_prev = 0, slot_cur = 1, slot_right = 2;
     bool is_new_kf = false, init_ok = false;
-    // scratch between stages
-    std::vector<int> edge_feat;        // pose-only edge -> current left feature index
-    int n_before_detect = 0;
-};
-
-// BA job bookkeeping between gather and scatter
-struct BaGather {
-    std::vector<Frame *> kfs;
-    std::vector<MapPoint *> lms;
-    std::vector<ObsRef> edge_feat;
+    // scratch between stages (per stream: the stages run one thread per stream)
+    std::vector<int> tri_idx;
+    BaGather ba;
+    long long c_pose_edges = 0, c_keyframes = 0, c_corners = 0;   // merged into Counters after the step
 };
 
 // ------------------------------------------------------------------ the staged pipeline
+// Every stage has the shape  [serial: sizes -> offsets]  [parallel over streams: fill the
+// batched arrays]  [ONE C-ABI call for all streams]  [parallel over streams: consume].
 template <class K>
 class Pipeline {
 public:
-    Pipeline(const Config &cfg, K &kernels, int nstreams) : cfg_(cfg), k_(kernels)
+    Pipeline(const Config &cfg, K &kernels, int nstreams, int host_threads = 1)
+        : cfg_(cfg), k_(kernels), pool_(host_threads)
     {
         for (int s = 0; s < nstreams; ++s) {
             streams_.emplace_back(new Stream(cfg));
@@ -228,6 +250,16 @@ public:
             streams_.back()->slot_right = 3 * s + 2;
         }
         cfg_.cam_l.k4(cam_l_); cfg_.cam_r.k4(cam_r_);
+    }
+    ~Pipeline()
+    {
+        if (std::getenv("SVS_PIPE_PROFILE")) {
+            const char *nm[9] = { "begin", "track-prep", "track-finish", "detect", "right", "tri", "ba-gather", "ba-scatter", "end" };
+            double fr = (double)std::max<long long>(cnt_.frames / std::max(1, nstreams()), 1);
+            std::fprintf(stderr, "[pipe %d streams, %d host threads] host ms/step:", nstreams(), pool_.size());
+            for (int i = 0; i < 9; ++i) std::fprintf(stderr, " %s %.3f", nm[i], st_[i] / 1e6 / fr);
+            std::fprintf(stderr, " | step %.3f abi %.3f\n", cnt_.ns_step / 1e6 / fr, cnt_.ns_kernel_calls / 1e6 / fr);
+        }
     }
     int nstreams() const { return (int)streams_.size(); }
     const Counters &counters() const { return cnt_; }
@@ -241,6 +273,7 @@ public:
         const int S = nstreams();
         const long long t_step0 = now_ns();
         std::vector<int> TS, IS, KS;
+        long long t_b = now_ns();
         for (int s = 0; s < S; ++s) {
             Stream &st = *streams_[s];
             // Frame::CreateFrame (src/frame.cpp:22-28)
@@ -254,9 +287,11 @@ public:
             else TS.push_back(s);
         }
         cnt_.frames += S;
+        st_[0] += now_ns() - t_b;
         if (!TS.empty()) {
             TrackPrepareAndRun(TS, left, strides, is_device);
-            for (int s : TS) if (TrackFinish(s)) KS.push_back(s);
+            { STimer t_(st_[2]); pool_.parallel_for((int)TS.size(), [&](int i) { TrackFinish(TS[i], i); }); }
+            for (int s : TS) if (streams_[s]->is_new_kf) KS.push_back(s);
         }
         std::vector<int> DS = IS;                 // streams that detect this frame
         DS.insert(DS.end(), KS.begin(), KS.end());
@@ -269,7 +304,7 @@ public:
                 Stream &st = *streams_[s];
                 int good = 0;
                 for (uint8_t ok : st.current->right_ok) good += ok ? 1 : 0;
-                if (good >= cfg_.num_features_init) { st.init_ok = true; MS.push_back(s); }
+                if (good >= cfg_.num_features_init) { st.init_ok = true; MS.push_back(s); }   // :227
             }
             MS.insert(MS.end(), KS.begin(), KS.end());
             if (!MS.empty()) {
@@ -277,10 +312,10 @@ public:
                 if (cfg_.backend_on) RunBackend(MS);
             }
         }
+        long long t_e = now_ns();
         for (int s : TS) {
             Stream &st = *streams_[s];
-            // src/frontend.cpp:685
-            st.relative_motion = st.current->pose * st.last->pose.inverse();
+            st.relative_motion = st.current->pose * st.last->pose.inverse();   // src/frontend.cpp:685
         }
         for (int s = 0; s < S; ++s) {
             Stream &st = *streams_[s];
@@ -295,7 +330,10 @@ public:
             // last_frame_ = current_frame_ (src/frontend.cpp:718)
             st.last = st.current;
             st.last_owned = std::move(st.cur_owned);   // null if the frame moved into kf_store
+            cnt_.pose_edges += st.c_pose_edges; cnt_.keyframes += st.c_keyframes; cnt_.corners += st.c_corners;
+            st.c_pose_edges = st.c_keyframes = st.c_corners = 0;
         }
+        st_[8] += now_ns() - t_e;
         cnt_.ns_step += now_ns() - t_step0;
     }
 
@@ -309,17 +347,18 @@ public:
         Stream &st = *streams_[s];
         std::ofstream pcd(dir + "/landmarks.pcd");
         if (!pcd) return false;
-        const size_t n = st.map.landmarks_.size();
+        const size_t n = st.map.num_landmarks();
         pcd << "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\n"
             << "COUNT 1 1 1\nWIDTH " << n << "\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS " << n << "\nDATA ascii\n";
         pcd << std::setprecision(8);
-        for (auto &kv : st.map.landmarks_)
-            pcd << (float)kv.second->pos[0] << " " << (float)kv.second->pos[1] << " " << (float)kv.second->pos[2] << "\n";
+        for (size_t i = 0; i < n; ++i) {
+            const MapPoint &m = st.map.landmark(i);
+            pcd << (float)m.pos[0] << " " << (float)m.pos[1] << " " << (float)m.pos[2] << "\n";
+        }
         std::ofstream kf(dir + "/keyframes.txt");
         if (!kf) return false;
         kf << dataset_dir << std::endl << left_cam_index << std::endl;
-        for (auto &kv : st.map.keyframes_) {
-            const Frame *f = kv.second;
+        for (const Frame *f : st.map.keyframes_) {
             const double *q = f->pose.v;
             const double x = q[0], y = q[1], z = q[2], w = q[3];
             const double R[9] = { 1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
@@ -344,6 +383,11 @@ private:
     {
         return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
     }
+    struct STimer {            // host-side stage profile (SVS_PIPE_PROFILE=1 prints it at destruction)
+        long long &acc; long long t0;
+        explicit STimer(long long &a) : acc(a), t0(now_ns()) {}
+        ~STimer() { acc += now_ns() - t0; }
+    };
     struct KTimer {            // accumulates the wall time of one C-ABI call
         Counters &c; long long t0;
         explicit KTimer(Counters &cc) : c(cc), t0(now_ns()) {}
@@ -354,58 +398,64 @@ private:
     void TrackPrepareAndRun(const std::vector<int> &TS, const void *const *left, const int *strides, int is_device)
     {
         const int n = (int)TS.size();
+        long long t_p = now_ns();
         jobs_track_.resize(n);
-        prev_xy_.clear(); next_xy_.clear(); has_mp_.clear(); xyz_.clear();
         imgs_.resize(n); strides_.resize(n);
         int ofs = 0;
         for (int i = 0; i < n; ++i) {
             Stream &st = *streams_[TS[i]];
-            Frame *cur = st.current, *last = st.last;
-            cur->pose = st.relative_motion * last->pose;            // :655
             svslam_track_job &j = jobs_track_[i];
             j.prev_slot = st.slot_prev; j.next_slot = st.slot_cur;
-            j.pt_ofs = ofs; j.npts = (int)last->left.size();
-            std::memcpy(j.pose, cur->pose.v, sizeof(j.pose));
+            j.pt_ofs = ofs; j.npts = (int)st.last->left.size();
             j.n_tracked = 0; j.n_inlier = 0;
-            for (const Feature &f : last->left) {                   // :331-347
-                prev_xy_.push_back(f.x); prev_xy_.push_back(f.y);
-                MapPoint *mp = st.map.point(f.mp);
-                if (mp) {
-                    double uv[2];
-                    cfg_.cam_l.world2pixel(mp->pos, cur->pose, uv);
-                    next_xy_.push_back((float)uv[0]); next_xy_.push_back((float)uv[1]);
-                    has_mp_.push_back(1);
-                    xyz_.push_back(mp->pos[0]); xyz_.push_back(mp->pos[1]); xyz_.push_back(mp->pos[2]);
-                } else {
-                    next_xy_.push_back(f.x); next_xy_.push_back(f.y);
-                    has_mp_.push_back(0);
-                    xyz_.push_back(0); xyz_.push_back(0); xyz_.push_back(1);
-                }
-            }
             ofs += j.npts;
             imgs_[i] = left[TS[i]];
             strides_[i] = strides ? strides[TS[i]] : cfg_.width;
         }
-        status_.assign((size_t)std::max(ofs, 1), 0);
-        outlier_.assign((size_t)std::max(ofs, 1), 0);
-        if (prev_xy_.empty()) { prev_xy_.resize(2); next_xy_.resize(2); has_mp_.resize(1); xyz_.resize(3); }
+        const size_t tot = (size_t)std::max(ofs, 1);
+        prev_xy_.resize(2 * tot); next_xy_.resize(2 * tot); has_mp_.resize(tot); xyz_.resize(3 * tot);
+        status_.assign(tot, 0); outlier_.assign(tot, 0);
+        pool_.parallel_for(n, [&](int i) {
+            Stream &st = *streams_[TS[i]];
+            Frame *cur = st.current, *last = st.last;
+            cur->pose = st.relative_motion * last->pose;            // :655
+            svslam_track_job &j = jobs_track_[i];
+            std::memcpy(j.pose, cur->pose.v, sizeof(j.pose));
+            size_t g = (size_t)j.pt_ofs;
+            for (const Feature &f : last->left) {                   // :331-347
+                prev_xy_[2 * g] = f.x; prev_xy_[2 * g + 1] = f.y;
+                MapPoint *mp = st.map.point(f.mp);
+                if (mp) {
+                    double uv[2];
+                    cfg_.cam_l.world2pixel(mp->pos, cur->pose, uv);
+                    next_xy_[2 * g] = (float)uv[0]; next_xy_[2 * g + 1] = (float)uv[1];
+                    has_mp_[g] = 1;
+                    xyz_[3 * g] = mp->pos[0]; xyz_[3 * g + 1] = mp->pos[1]; xyz_[3 * g + 2] = mp->pos[2];
+                } else {
+                    next_xy_[2 * g] = f.x; next_xy_[2 * g + 1] = f.y;
+                    has_mp_[g] = 0;
+                    xyz_[3 * g] = 0; xyz_[3 * g + 1] = 0; xyz_[3 * g + 2] = 1;
+                }
+                ++g;
+            }
+        });
+        st_[1] += now_ns() - t_p;
         svslam_lk_params prm = { 3, 30, 0.01, 1e-4, 1 };            // :353-357
         { KTimer kt_(cnt_); check(k_.track(n, jobs_track_.data(), imgs_.data(), strides_.data(), is_device, ofs, cam_l_,
                        prev_xy_.data(), next_xy_.data(), has_mp_.data(), xyz_.data(), status_.data(),
                        outlier_.data(), &prm, 5.991), "track"); }
         cnt_.track_pts += ofs; cnt_.pyr_left += n;
-        track_order_ = TS;
     }
 
-    // returns true if the frame became a keyframe
-    bool TrackFinish(int s)
+    // sets st.is_new_kf if the frame became a keyframe
+    void TrackFinish(int s, int i)
     {
         Stream &st = *streams_[s];
-        int i = (int)(std::find(track_order_.begin(), track_order_.end(), s) - track_order_.begin());
         const svslam_track_job &j = jobs_track_[i];
         Frame *cur = st.current, *last = st.last;
         // TrackLastFrame :361-381 (status already includes the in-image test)
         int n_edges = 0, n_outlier = 0;
+        cur->left.reserve((size_t)j.npts + (size_t)cfg_.num_features);
         for (int p = 0; p < j.npts; ++p) {
             const int g = j.pt_ofs + p;
             if (!status_[g]) continue;
@@ -419,14 +469,14 @@ private:
             }
             cur->left.push_back(f);
         }
-        cnt_.pose_edges += n_edges;
+        st.c_pose_edges += n_edges;
         cur->pose = SE3(j.pose);                                   // :542
         st.tracking_inliers = n_edges - n_outlier;                 // :556
         if (st.tracking_inliers > cfg_.num_features_tracking) st.status = FrontendStatus::TRACKING_GOOD;
         else if (st.tracking_inliers > cfg_.num_features_tracking_bad) st.status = FrontendStatus::TRACKING_BAD;
         else st.status = FrontendStatus::LOST;                     // :665-679
         // InsertKeyframe :576-616
-        if (st.tracking_inliers >= cfg_.num_features_needed_for_keyframe) return false;
+        if (st.tracking_inliers >= cfg_.num_features_needed_for_keyframe) return;
         MakeKeyFrame(st);
         st.frontend_prev_kf = st.frontend_current_kf;
         st.frontend_current_kf = cur;
@@ -436,7 +486,6 @@ private:
         for (size_t k = 0; k < cur->left.size(); ++k)
             if (cur->left[k].mp >= 0) st.map.AddObservation(st.map.point(cur->left[k].mp), ObsRef{ cur, (int)k, true });
         st.is_new_kf = true;
-        return true;
     }
 
     void MakeKeyFrame(Stream &st)
@@ -446,7 +495,7 @@ private:
         cur->keyframe_id = st.kf_factory_id++;
         st.kf_store.push_back(std::move(st.cur_owned));            // Map::keyframes_ keeps it alive
         st.map.InsertKeyFrame(cur);
-        cnt_.keyframes++;
+        st.c_keyframes++;
     }
 
     void BuildPyramids(const std::vector<int> &IS, const std::vector<int> &DS, const void *const *left,
@@ -468,25 +517,30 @@ private:
     // Frontend::DetectFeatures :36-70
     void DetectFeatures(const std::vector<int> &DS)
     {
+        long long t_h3 = now_ns();
         const int n = (int)DS.size();
         jobs_gftt_.resize(n);
-        rects_.clear();
         int ofs = 0;
         for (int i = 0; i < n; ++i) {
             Stream &st = *streams_[DS[i]];
             jobs_gftt_[i].slot = st.slot_cur;
             jobs_gftt_[i].rect_ofs = ofs;
             jobs_gftt_[i].nrect = (int)st.current->left.size();
-            for (const Feature &f : st.current->left) { rects_.push_back(f.x); rects_.push_back(f.y); }
             ofs += jobs_gftt_[i].nrect;
-            st.n_before_detect = (int)st.current->left.size();
         }
-        if (rects_.empty()) rects_.resize(2);
+        rects_.resize(2 * (size_t)std::max(ofs, 1));
+        pool_.parallel_for(n, [&](int i) {
+            Stream &st = *streams_[DS[i]];
+            size_t g = (size_t)jobs_gftt_[i].rect_ofs;
+            for (const Feature &f : st.current->left) { rects_[2 * g] = f.x; rects_[2 * g + 1] = f.y; ++g; }
+        });
         corners_.assign((size_t)n * cfg_.num_features * 2, 0.f);
         ncorners_.assign((size_t)n, 0);
+        st_[3] += now_ns() - t_h3;
         { KTimer kt_(cnt_); check(k_.gftt(n, jobs_gftt_.data(), ofs, rects_.data(), cfg_.num_features, 0.01, 20.0, corners_.data(),
-                      ncorners_.data()), "gftt"); }  // :24
-        for (int i = 0; i < n; ++i) {
+                      ncorners_.data()), "gftt"); }                 // :24
+        t_h3 = now_ns();
+        pool_.parallel_for(n, [&](int i) {
             Stream &st = *streams_[DS[i]];
             for (int c = 0; c < ncorners_[i]; ++c) {
                 Feature f;
@@ -494,40 +548,48 @@ private:
                 f.y = corners_[((size_t)i * cfg_.num_features + c) * 2 + 1];
                 st.current->left.push_back(f);
             }
-            cnt_.corners += ncorners_[i];
-        }
+            st.c_corners += ncorners_[i];
+        });
         cnt_.gftt_calls += n; cnt_.gftt_rects += ofs;
+        st_[3] += now_ns() - t_h3;
     }
 
     // Frontend::FindFeaturesInRight :72-141
     void FindFeaturesInRight(const std::vector<int> &DS)
     {
+        long long t_h4 = now_ns();
         const int n = (int)DS.size();
         jobs_lk_.resize(n);
-        prev_xy_.clear(); next_xy_.clear();
         int ofs = 0;
         for (int i = 0; i < n; ++i) {
             Stream &st = *streams_[DS[i]];
-            Frame *cur = st.current;
             jobs_lk_[i].prev_slot = st.slot_cur; jobs_lk_[i].next_slot = st.slot_right;
-            jobs_lk_[i].pt_ofs = ofs; jobs_lk_[i].npts = (int)cur->left.size();
+            jobs_lk_[i].pt_ofs = ofs; jobs_lk_[i].npts = (int)st.current->left.size();
+            ofs += jobs_lk_[i].npts;
+        }
+        const size_t tot = (size_t)std::max(ofs, 1);
+        prev_xy_.resize(2 * tot); next_xy_.resize(2 * tot);
+        status_.assign(tot, 0); err_.assign(tot, 0.f);
+        pool_.parallel_for(n, [&](int i) {
+            Stream &st = *streams_[DS[i]];
+            Frame *cur = st.current;
+            size_t g = (size_t)jobs_lk_[i].pt_ofs;
             for (const Feature &f : cur->left) {
-                prev_xy_.push_back(f.x); prev_xy_.push_back(f.y);
+                prev_xy_[2 * g] = f.x; prev_xy_[2 * g + 1] = f.y;
                 MapPoint *mp = st.map.point(f.mp);
                 if (mp) {
                     double uv[2];
                     cfg_.cam_r.world2pixel(mp->pos, cur->pose, uv);
-                    next_xy_.push_back((float)uv[0]); next_xy_.push_back((float)uv[1]);
-                } else { next_xy_.push_back(f.x); next_xy_.push_back(f.y); }
+                    next_xy_[2 * g] = (float)uv[0]; next_xy_[2 * g + 1] = (float)uv[1];
+                } else { next_xy_[2 * g] = f.x; next_xy_[2 * g + 1] = f.y; }
+                ++g;
             }
-            ofs += jobs_lk_[i].npts;
-        }
-        status_.assign((size_t)std::max(ofs, 1), 0);
-        err_.assign((size_t)std::max(ofs, 1), 0.f);
-        if (prev_xy_.empty()) { prev_xy_.resize(2); next_xy_.resize(2); }
+        });
+        st_[4] += now_ns() - t_h4;
         svslam_lk_params prm = { 3, 30, 0.01, 1e-4, 1 };            // :105-109
         { KTimer kt_(cnt_); check(k_.lk(n, jobs_lk_.data(), ofs, prev_xy_.data(), next_xy_.data(), status_.data(), err_.data(), &prm), "lk"); }
-        for (int i = 0; i < n; ++i) {
+        t_h4 = now_ns();
+        pool_.parallel_for(n, [&](int i) {
             Stream &st = *streams_[DS[i]];
             Frame *cur = st.current;
             cur->right.assign(cur->left.size(), Feature());
@@ -540,54 +602,71 @@ private:
                     cur->right_ok[p] = 1;
                 }
             }
-        }
+        });
         cnt_.right_pts += ofs;
+        st_[4] += now_ns() - t_h4;
     }
 
     // BuildInitMap :143-214 / TriangulateNewPoints :251-320
     void Triangulate(const std::vector<int> &MS)
     {
+        long long t_h5 = now_ns();
         const int n = (int)MS.size();
         jobs_tri_.resize(n);
-        uv_l_.clear(); uv_r_.clear(); tri_idx_.clear();
-        int ofs = 0;
-        for (int i = 0; i < n; ++i) {
+        // which pairs go in: decided per stream, then laid out
+        pool_.parallel_for(n, [&](int i) {
             Stream &st = *streams_[MS[i]];
             Frame *cur = st.current;
             const bool init = !st.is_new_kf;
-            svslam_tri_job &j = jobs_tri_[i];
-            j.pt_ofs = ofs; j.npts = 0;
-            SE3 Twc = init ? SE3() : cur->pose.inverse();           // :261
-            std::memcpy(j.T_wc, Twc.v, sizeof(j.T_wc));
-            j.zmax = init ? 0.0 : cfg_.max_triangulation_depth;     // :174 vs :286-288
+            st.tri_idx.clear();
             for (size_t p = 0; p < cur->left.size(); ++p) {
                 if (!cur->right_ok[p]) continue;
                 if (!init && cur->left[p].mp >= 0) continue;        // :272
-                uv_l_.push_back(cur->left[p].x); uv_l_.push_back(cur->left[p].y);
-                uv_r_.push_back(cur->right[p].x); uv_r_.push_back(cur->right[p].y);
-                tri_idx_.push_back((int)p);
-                ++j.npts;
+                st.tri_idx.push_back((int)p);
             }
+        });
+        int ofs = 0;
+        for (int i = 0; i < n; ++i) {
+            Stream &st = *streams_[MS[i]];
+            const bool init = !st.is_new_kf;
+            svslam_tri_job &j = jobs_tri_[i];
+            j.pt_ofs = ofs; j.npts = (int)st.tri_idx.size();
+            SE3 Twc = init ? SE3() : st.current->pose.inverse();    // :261
+            std::memcpy(j.T_wc, Twc.v, sizeof(j.T_wc));
+            j.zmax = init ? 0.0 : cfg_.max_triangulation_depth;     // :174 vs :286-288
             ofs += j.npts;
         }
-        tri_xyz_.assign((size_t)std::max(ofs, 1) * 3, 0.0);
-        tri_ok_.assign((size_t)std::max(ofs, 1), 0);
-        if (ofs > 0)
-            { KTimer kt_(cnt_); check(k_.triangulate(n, jobs_tri_.data(), ofs, cam_l_, cfg_.cam_l.pose.v, cam_r_, cfg_.cam_r.pose.v,
-                                 uv_l_.data(), uv_r_.data(), tri_xyz_.data(), tri_ok_.data()), "triangulate"); }
+        const size_t tot = (size_t)std::max(ofs, 1);
+        uv_l_.resize(2 * tot); uv_r_.resize(2 * tot);
+        tri_xyz_.assign(3 * tot, 0.0); tri_ok_.assign(tot, 0);
+        pool_.parallel_for(n, [&](int i) {
+            Stream &st = *streams_[MS[i]];
+            Frame *cur = st.current;
+            size_t g = (size_t)jobs_tri_[i].pt_ofs;
+            for (int p : st.tri_idx) {
+                uv_l_[2 * g] = cur->left[p].x; uv_l_[2 * g + 1] = cur->left[p].y;
+                uv_r_[2 * g] = cur->right[p].x; uv_r_[2 * g + 1] = cur->right[p].y;
+                ++g;
+            }
+        });
+        st_[5] += now_ns() - t_h5;
+        if (ofs > 0) {
+            KTimer kt_(cnt_);
+            check(k_.triangulate(n, jobs_tri_.data(), ofs, cam_l_, cfg_.cam_l.pose.v, cam_r_, cfg_.cam_r.pose.v,
+                                 uv_l_.data(), uv_r_.data(), tri_xyz_.data(), tri_ok_.data()), "triangulate");
+        }
         cnt_.tri_pts += ofs;
-        for (int i = 0; i < n; ++i) {
+        t_h5 = now_ns();
+        pool_.parallel_for(n, [&](int i) {
             Stream &st = *streams_[MS[i]];
             Frame *cur = st.current;
             const bool init = !st.is_new_kf;
             for (int q = 0; q < jobs_tri_[i].npts; ++q) {
                 const int g = jobs_tri_[i].pt_ofs + q;
                 if (!tri_ok_[g]) continue;
-                const int p = tri_idx_[g];
+                const int p = st.tri_idx[q];
                 MapPoint *mp = st.map.CreateNewMappoint();
                 mp->pos[0] = tri_xyz_[3 * g]; mp->pos[1] = tri_xyz_[3 * g + 1]; mp->pos[2] = tri_xyz_[3 * g + 2];
-                // the frame object is stable from here on only once it is a keyframe; for the init
-                // frame MakeKeyFrame below moves ownership without moving the object
                 st.map.AddObservation(mp, ObsRef{ cur, p, true });
                 st.map.AddObservation(mp, ObsRef{ cur, p, false });
                 cur->left[p].mp = mp->id;
@@ -600,29 +679,27 @@ private:
                 MakeKeyFrame(st);
                 st.status = FrontendStatus::TRACKING_GOOD;
             }
-        }
+        });
+        st_[5] += now_ns() - t_h5;
     }
 
     // Backend::UpdateMap -> Optimize, synchronously (src/backend.cpp:9-248)
     void RunBackend(const std::vector<int> &MS)
     {
+        long long t_h6 = now_ns();
         const int n = (int)MS.size();
         jobs_ba_.resize(n);
-        gathers_.assign((size_t)n, BaGather());
-        ba_poses_.clear(); ba_pts_.clear(); ba_okf_.clear(); ba_olm_.clear(); ba_right_.clear(); ba_uv_.clear();
-        int ko = 0, lo = 0, oo = 0;
-        for (int i = 0; i < n; ++i) {
+        // gather per stream (:39-160), in parallel, into the stream's own buffers
+        pool_.parallel_for(n, [&](int i) {
             Stream &st = *streams_[MS[i]];
-            BaGather &g = gathers_[i];
-            svslam_ba_job &j = jobs_ba_[i];
-            std::map<long, int> kf_local;
-            for (auto &kv : st.map.active_keyframes_) {              // :39-66
-                kf_local[kv.first] = (int)g.kfs.size();
-                g.kfs.push_back(kv.second);
-                for (int t = 0; t < 7; ++t) ba_poses_.push_back(kv.second->pose.v[t]);
+            BaGather &g = st.ba;
+            g.clear();
+            for (Frame *kf : st.map.active_keyframes_) {             // :39-66
+                kf->ba_local = (int)g.kfs.size();
+                g.kfs.push_back(kf);
+                for (int t = 0; t < 7; ++t) g.poses.push_back(kf->pose.v[t]);
             }
-            for (auto &kv : st.map.active_landmarks_) {              // :83-160
-                MapPoint *mp = kv.second;
+            for (MapPoint *mp : st.map.active_landmarks_) {          // :83-160
                 if (mp->is_outlier) continue;
                 int lm_local = -1;
                 for (const ObsRef &ob : mp->observations) {
@@ -631,34 +708,57 @@ private:
                     if (lm_local < 0) {                              // vertex even if no edge follows (:118-130)
                         lm_local = (int)g.lms.size();
                         g.lms.push_back(mp);
-                        ba_pts_.push_back(mp->pos[0]); ba_pts_.push_back(mp->pos[1]); ba_pts_.push_back(mp->pos[2]);
+                        g.pts.push_back(mp->pos[0]); g.pts.push_back(mp->pos[1]); g.pts.push_back(mp->pos[2]);
                     }
-                    auto it = ob.frame->is_keyframe ? kf_local.find(ob.frame->keyframe_id) : kf_local.end();
-                    if (it == kf_local.end()) continue;              // :133
-                    ba_okf_.push_back(it->second); ba_olm_.push_back(lm_local);
-                    ba_right_.push_back(ob.is_left ? 0 : 1);
-                    ba_uv_.push_back(ft.x); ba_uv_.push_back(ft.y);
+                    if (ob.frame->ba_local < 0) continue;            // frame not in the active window (:133)
+                    g.okf.push_back(ob.frame->ba_local); g.olm.push_back(lm_local);
+                    g.right.push_back(ob.is_left ? 0 : 1);
+                    g.uv.push_back(ft.x); g.uv.push_back(ft.y);
                     g.edge_feat.push_back(ob);
                 }
             }
+            for (Frame *kf : g.kfs) kf->ba_local = -1;
+        });
+        int ko = 0, lo = 0, oo = 0;
+        for (int i = 0; i < n; ++i) {
+            BaGather &g = streams_[MS[i]]->ba;
+            svslam_ba_job &j = jobs_ba_[i];
             j.kf_ofs = ko; j.nkf = (int)g.kfs.size();
             j.lm_ofs = lo; j.nlm = (int)g.lms.size();
             j.obs_ofs = oo; j.nobs = (int)g.edge_feat.size();
             j.iters_done = 0; j.reserved = 0;
             ko += j.nkf; lo += j.nlm; oo += j.nobs;
         }
+        ba_poses_.resize(7 * (size_t)std::max(ko, 1)); ba_pts_.resize(3 * (size_t)std::max(lo, 1));
+        ba_okf_.resize((size_t)std::max(oo, 1)); ba_olm_.resize((size_t)std::max(oo, 1));
+        ba_right_.resize((size_t)std::max(oo, 1)); ba_uv_.resize(2 * (size_t)std::max(oo, 1));
         ba_chi2_.assign((size_t)std::max(oo, 1), 0.0);
-        if (ba_pts_.empty()) ba_pts_.resize(3);
-        if (ba_okf_.empty()) { ba_okf_.resize(1); ba_olm_.resize(1); ba_right_.resize(1); ba_uv_.resize(2); }
+        pool_.parallel_for(n, [&](int i) {
+            const BaGather &g = streams_[MS[i]]->ba;
+            const svslam_ba_job &j = jobs_ba_[i];
+            if (j.nkf) std::memcpy(&ba_poses_[7 * (size_t)j.kf_ofs], g.poses.data(), sizeof(double) * 7 * j.nkf);
+            if (j.nlm) std::memcpy(&ba_pts_[3 * (size_t)j.lm_ofs], g.pts.data(), sizeof(double) * 3 * j.nlm);
+            if (j.nobs) {
+                std::memcpy(&ba_okf_[(size_t)j.obs_ofs], g.okf.data(), sizeof(int) * j.nobs);
+                std::memcpy(&ba_olm_[(size_t)j.obs_ofs], g.olm.data(), sizeof(int) * j.nobs);
+                std::memcpy(&ba_right_[(size_t)j.obs_ofs], g.right.data(), (size_t)j.nobs);
+                std::memcpy(&ba_uv_[2 * (size_t)j.obs_ofs], g.uv.data(), sizeof(float) * 2 * j.nobs);
+            }
+        });
+        st_[6] += now_ns() - t_h6;
         { KTimer kt_(cnt_); check(k_.local_ba(n, jobs_ba_.data(), cam_l_, cfg_.cam_l.pose.v, cam_r_, cfg_.cam_r.pose.v, ko,
                           ba_poses_.data(), lo, ba_pts_.data(), oo, ba_okf_.data(), ba_olm_.data(), ba_right_.data(),
-                          ba_uv_.data(), cfg_.chi2_th, 10, ba_chi2_.data()), "local_ba"); }  // :150-164
+                          ba_uv_.data(), cfg_.chi2_th, 10, ba_chi2_.data()), "local_ba"); }   // :150-164
+        t_h6 = now_ns();
         for (int i = 0; i < n; ++i) {
-            Stream &st = *streams_[MS[i]];
-            BaGather &g = gathers_[i];
             const svslam_ba_job &j = jobs_ba_[i];
             cnt_.ba_calls++; cnt_.ba_edges += j.nobs; cnt_.ba_kf += j.nkf; cnt_.ba_lm += j.nlm;
             cnt_.ba_iters += j.iters_done;
+        }
+        pool_.parallel_for(n, [&](int i) {
+            Stream &st = *streams_[MS[i]];
+            BaGather &g = st.ba;
+            const svslam_ba_job &j = jobs_ba_[i];
             // :167-193 threshold doubling
             double chi2_th = cfg_.chi2_th;
             int cnt_outlier = 0, cnt_inlier = 0, iteration = 0;
@@ -689,11 +789,14 @@ private:
                 if (kf->keyframe_id == 0) continue;
                 if (kf->prev_keyframe) kf->relative_pose_pkf = kf->pose * kf->prev_keyframe->pose.inverse();
             }
-        }
+        });
+        st_[7] += now_ns() - t_h6;
     }
 
+    long long st_[12] = { 0 };   // 0 begin 1 track-prep 2 track-finish 3 detect 4 right 5 tri 6 ba-gather 7 ba-scatter 8 end
     Config cfg_;
     K &k_;
+    ThreadPool pool_;
     std::vector<std::unique_ptr<Stream>> streams_;
     Counters cnt_;
     double cam_l_[4], cam_r_[4];
@@ -703,14 +806,12 @@ private:
     std::vector<svslam_gftt_job> jobs_gftt_;
     std::vector<svslam_tri_job> jobs_tri_;
     std::vector<svslam_ba_job> jobs_ba_;
-    std::vector<BaGather> gathers_;
-    std::vector<int> track_order_;
     std::vector<const void *> imgs_;
     std::vector<int> strides_;
     std::vector<float> prev_xy_, next_xy_, rects_, corners_, uv_l_, uv_r_, err_, ba_uv_;
     std::vector<uint8_t> has_mp_, status_, outlier_, tri_ok_, ba_right_;
     std::vector<double> xyz_, tri_xyz_, ba_poses_, ba_pts_, ba_chi2_;
-    std::vector<int> ncorners_, tri_idx_, ba_okf_, ba_olm_;
+    std::vector<int> ncorners_, ba_okf_, ba_olm_;
 };
 
 } // namespace svs

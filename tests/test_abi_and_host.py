@@ -85,6 +85,11 @@ def test_host_pipeline_tracks_and_is_deterministic(svs):
         assert m["status"][0] == (1 if m["n_inliers"][0] > 50 else 2 if m["n_inliers"][0] > 20 else 3)
     est2, meta2, _ = _run_twin(svs, [5], N)
     assert np.array_equal(est, est2)                       # BA runs synchronously: no thread race
+    # host bookkeeping on 4 threads gives the same result as on 1
+    pl_cfg = pl.default_config(host_threads=4)
+    est5, _, _ = _run_twin(svs, [5, 6, 7], 12, pl_cfg)
+    est6, _, _ = _run_twin(svs, [5, 6, 7], 12)
+    assert np.array_equal(est5, est6)
     # two streams in lockstep == the same streams run alone
     est3, _, _ = _run_twin(svs, [5, 6], 12)
     est4, _, _ = _run_twin(svs, [6], 12)
