@@ -120,6 +120,10 @@ __device__ __forceinline__ double wave_max_f64(double v)
     return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 
+// The f64 geometry below is compared to the oracle at a stated tolerance, not bit for bit,
+// so FMA contraction is allowed for it (halves the f64 op count); the integer / f32 code
+// above and in k_pyramid/k_lk/k_gftt stays strictly un-contracted.
+#pragma clang fp contract(fast)
 // ---- SE(3), Sophus layout qx qy qz qw tx ty tz (mirrors oracle/orc_geom.c) ----
 __device__ __forceinline__ void d_quat_rot(const double *q, const double *v, double *o)
 {
@@ -208,3 +212,4 @@ __device__ __forceinline__ void d_huber(double e2, double delta, double &rho0, d
     if (e2 <= dsqr) { rho0 = e2; rho1 = 1.0; }
     else { double sq = sqrt(e2); rho0 = 2 * sq * delta - dsqr; rho1 = delta / sq; }
 }
+#pragma clang fp contract(off)

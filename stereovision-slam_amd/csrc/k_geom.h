@@ -7,6 +7,8 @@
 // order, so agreement is to rounding (tolerances in tests/).
 #pragma once
 #include "dev_common.h"
+// f64 LM kernels: tolerance-level parity, FMA contraction allowed (see dev_common.h)
+#pragma clang fp contract(fast)
 
 // ------------------------------------------------------------------ triangulation
 struct TriJob { int pt_ofs, npts; double T_wc[7]; double zmax; };
