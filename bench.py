@@ -50,6 +50,22 @@ def algorithmic_bytes(fam, cnt, launches):
     return 0
 
 
+def measured_traffic(fam, cnt, launches):
+    """HBM bytes per launch of the family from the committed PMC passes (profiles/pmc_traffic.json,
+    collected with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs); None if unknown."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(fam)
+    except (OSError, ValueError):
+        return None
+    if not t or not t.get("bytes"):
+        return None
+    units = {"local_ba": cnt["ba_calls"], "lk": cnt["track_pts"] + cnt["right_pts"], "pose_only": cnt["frames"],
+             "gftt": cnt["gftt_calls"]}.get(fam)
+    if not units or not launches:
+        return None
+    return t["bytes"] * units / launches
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,7 +202,8 @@ def main():
                        "keyframes_in_timed_region": cnt["keyframes"], "tracked_ok_fraction": ok_frames / (S * K),
                        "parallelism": "%d independent streams/GPU x %d GPU(s), no collective" % (S, world)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                         "traffic": measured_traffic(dom, cnt, launches),
                          "avg_launch_us": round(avg_s * 1e6, 2), "launches": launches,
                          "algorithmic_bytes_per_launch": round(abytes / max(launches, 1), 1)},
             "kernel_ms": {f: round(fam_t[f][0], 3) for f in fam_t},

@@ -39,17 +39,18 @@ struct LkParams {
 __device__ __forceinline__ void lk_weights(float a, float b, int &w00, int &w01, int &w10, int &w11)
 {
     // cvRound == round-half-even == rintf
-    w00 = (int)rintf((1.f - a) * (1.f - b) * (float)(1 << LK_W_BITS));
-    w01 = (int)rintf(a * (1.f - b) * (float)(1 << LK_W_BITS));
-    w10 = (int)rintf((1.f - a) * b * (float)(1 << LK_W_BITS));
+    // the inputs are wave-uniform: keep the weights in SGPRs
+    w00 = __builtin_amdgcn_readfirstlane((int)rintf((1.f - a) * (1.f - b) * (float)(1 << LK_W_BITS)));
+    w01 = __builtin_amdgcn_readfirstlane((int)rintf(a * (1.f - b) * (float)(1 << LK_W_BITS)));
+    w10 = __builtin_amdgcn_readfirstlane((int)rintf((1.f - a) * b * (float)(1 << LK_W_BITS)));
     w11 = (1 << LK_W_BITS) - w00 - w01 - w10;
 }
 
 __device__ __forceinline__ void lk_stage_J(uint32_t *sJ, const uint8_t *J0, int pitch, int w, int h,
                                            int cx, int cy, int lane, int &rx0, int &ry0)
 {
-    rx0 = (cx - 10) & ~3;
-    ry0 = cy - 10;
+    rx0 = __builtin_amdgcn_readfirstlane((cx - 10) & ~3);
+    ry0 = __builtin_amdgcn_readfirstlane(cy - 10);
     const int gxmax = (w + SVS_BORDER - 4) & ~3;
 #pragma unroll
     for (int i = lane; i < LK_REG * (LK_REG / 4); i += 64) {
@@ -119,7 +120,7 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
         nextp.x = nx; nextp.y = ny;
 
         px -= 5.f; py -= 5.f;
-        const int ipx = (int)floorf(px), ipy = (int)floorf(py);
+        const int ipx = __builtin_amdgcn_readfirstlane((int)floorf(px)), ipy = __builtin_amdgcn_readfirstlane((int)floorf(py));
         if (ipx < -LK_WIN || ipx >= w || ipy < -LK_WIN || ipy >= h) {
             if (level == 0) { st = false; errv = 0.f; }
             continue;
@@ -193,7 +194,7 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
         lk_stage_J(sJ, J0, pitch, w, h, (int)floorf(nx), (int)floorf(ny), lane, rx0, ry0);
 
         for (int j = 0; j < prm.max_count; ++j) {
-            const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+            const int inx = __builtin_amdgcn_readfirstlane((int)floorf(nx)), iny = __builtin_amdgcn_readfirstlane((int)floorf(ny));
             if (inx < -LK_WIN || inx >= w || iny < -LK_WIN || iny >= h) {
                 if (level == 0) st = false;
                 break;
