@@ -71,12 +71,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("SVS_BENCH_STREAMS", "1536")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("SVS_BENCH_STREAMS", "2048")),
                     help="independent stereo streams per GPU, advanced in lockstep")
-    ap.add_argument("--groups", type=int, default=int(os.environ.get("SVS_BENCH_GROUPS", "3")),
+    ap.add_argument("--groups", type=int, default=int(os.environ.get("SVS_BENCH_GROUPS", "4")),
                     help="host threads per GPU, each driving streams/groups streams through its own "
                          "svslam context (own HIP stream): one group's BA overlaps the others' tracking")
-    ap.add_argument("--host-threads", type=int, default=int(os.environ.get("SVS_BENCH_HOST_THREADS", "16")),
+    ap.add_argument("--host-threads", type=int, default=int(os.environ.get("SVS_BENCH_HOST_THREADS", "0")),
                     help="threads per group for the per-stream host bookkeeping (Frontend/Map/Backend glue)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=1500, help="bound of the CPU baseline sample")
@@ -96,6 +96,9 @@ def main():
     G = max(1, min(args.groups, S))
     while S % G:
         G -= 1
+    if args.host_threads <= 0:        # auto: share the box's cores between the ranks of this node
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        args.host_threads = max(2, min(12, (os.cpu_count() or 8) // max(1, local_world * G)))
     Sg = S // G
     F = Wm + K
     cfg = pl.default_config(W, H, host_threads=max(1, args.host_threads))

@@ -132,10 +132,16 @@ struct BaHostStruct {        // scratch reused across jobs
         const int *okf = obs_kf + j.obs_ofs, *olm = obs_lm + j.obs_ofs;
         order.resize(nobs);
         for (int e = 0; e < nobs; ++e) order[e] = e;
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-            if (olm[a] != olm[b]) return olm[a] < olm[b];
-            return okf[a] < okf[b];
-        });
+        // the host pipeline gathers landmark by landmark with observations in keyframe order,
+        // so the edges normally arrive sorted already: check in O(E), sort only if needed
+        bool sorted = true;
+        for (int e = 1; e < nobs && sorted; ++e)
+            sorted = (olm[e - 1] < olm[e]) || (olm[e - 1] == olm[e] && okf[e - 1] <= okf[e]);
+        if (!sorted)
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+                if (olm[a] != olm[b]) return olm[a] < olm[b];
+                return okf[a] < okf[b];
+            });
         lm_estart.assign((size_t)nlm + 1, 0);
         for (int e = 0; e < nobs; ++e) lm_estart[olm[e] + 1]++;
         for (int i = 0; i < nlm; ++i) lm_estart[i + 1] += lm_estart[i];
