@@ -625,11 +625,8 @@ int svslam_local_ba_batch(svslam_ctx *c, int njobs, svslam_ba_job *jobs, const d
             j.lm_ofs + j.nlm > total_lm || j.obs_ofs < 0 || j.obs_ofs + j.nobs > total_obs)
             return fail(c, "local_ba: job %d exceeds limits (kf %d/%d lm %d/%d obs %d/%d)", i, j.nkf,
                         c->lim.max_kf, j.nlm, c->lim.max_lm, j.nobs, c->lim.max_obs);
-        for (int e = 0; e < j.nobs; ++e) {
-            int k = obs_kf[j.obs_ofs + e], l = obs_lm[j.obs_ofs + e];
-            if (k < 0 || k >= j.nkf || l < 0 || l >= j.nlm) return fail(c, "local_ba: job %d edge %d index out of range", i, e);
-        }
     }
+    const long long t_prep0 = now_ns();
     c->ar.reset();
     static_assert(sizeof(BaJob) == sizeof(svslam_ba_job), "job layout");
     // host-side structure of every problem (edge / block / pose-pair lists)
@@ -637,13 +634,20 @@ int svslam_local_ba_batch(svslam_ctx *c, int njobs, svslam_ba_job *jobs, const d
     if ((int)hs.size() < njobs) hs.resize(njobs);
     size_t aux_total = 0;
     {
+        std::vector<int> bad((size_t)njobs, 0);
         auto build_one = [&](int i) {
             BaJob bj;
             memcpy(&bj, &jobs[i], sizeof(bj));
+            for (int e = 0; e < bj.nobs; ++e) {      // index validation, per problem
+                const int k = obs_kf[bj.obs_ofs + e], l = obs_lm[bj.obs_ofs + e];
+                if (k < 0 || k >= bj.nkf || l < 0 || l >= bj.nlm) { bad[(size_t)i] = 1; return; }
+            }
             hs[i].build(bj, obs_kf, obs_lm);
         };
         if (c->pool && njobs > 1) c->pool->parallel_for(njobs, build_one);
         else for (int i = 0; i < njobs; ++i) build_one(i);
+        for (int i = 0; i < njobs; ++i)
+            if (bad[(size_t)i]) return fail(c, "local_ba: job %d has an edge index out of range", i);
         for (int i = 0; i < njobs; ++i) {
             BaJob bj;
             memcpy(&bj, &jobs[i], sizeof(bj));
@@ -693,6 +697,7 @@ int svslam_local_ba_batch(svslam_ctx *c, int njobs, svslam_ba_job *jobs, const d
     }
     if (total_kf > 0) memcpy(hp<void>(c, oposes), poses, sizeof(double) * 7 * total_kf);
     if (total_lm > 0) memcpy(hp<void>(c, opts), pts, sizeof(double) * 3 * total_lm);
+    c->host_ns[4] += now_ns() - t_prep0;
     if (h2d(c, 0, in_end)) return -1;
     tm_begin(c, FAM_BA, njobs);
     hipLaunchKernelGGL(k_local_ba, dim3(njobs), dim3(BA_THREADS), ba_lds_bytes(c->lim.max_kf), c->stream,

@@ -1,0 +1,124 @@
+"""GPU tests for the edges of the C ABI: limits, error returns, ragged batches,
+maximum sizes, and the >64-row reduced camera system."""
+import numpy as np
+import pytest
+
+import common as cm
+
+pytestmark = pytest.mark.gpu
+
+
+def test_error_returns_not_crashes(svs):
+    c = svs.Context(cm.W, cm.H, max_slots=2, max_jobs=2, max_pts=64, max_corners=50, max_kf=3, max_lm=64, max_obs=256)
+    img = np.zeros((cm.H, cm.W), np.uint8)
+    with pytest.raises(RuntimeError, match="slot"):
+        c.pyramid([5], [img])
+    with pytest.raises(RuntimeError, match="jobs"):
+        c.pyramid([0, 1, 0], [img, img, img])
+    c.pyramid([0, 1], [img, img])
+    p = np.zeros((10, 2), np.float32)
+    with pytest.raises(RuntimeError, match="slot"):
+        c.lk([(0, 7, p, p)])
+    with pytest.raises(RuntimeError):
+        c.gftt([(0, None)], max_corners=51)                      # above the context's max_corners
+    big = np.zeros((65, 3)); uv = np.zeros((65, 2), np.float32)
+    with pytest.raises(RuntimeError, match="pose_only"):
+        c.pose_only([(cm.EXT_L, big, uv)], cm.CAM)              # 65 points > max_pts
+    rng = np.random.default_rng(0)
+    pr = cm.make_ba_problem(rng, 3, 40)
+    bad_kf = pr["okf"].copy(); bad_kf[3] = 9
+    with pytest.raises(RuntimeError, match="out of range"):
+        c.local_ba([(pr["poses0"], pr["pts0"], bad_kf, pr["olm"], pr["ori"], pr["ouv"])], cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R)
+    pr2 = cm.make_ba_problem(rng, 4, 40)
+    with pytest.raises(RuntimeError, match="limits"):
+        c.local_ba([(pr2["poses0"], pr2["pts0"], pr2["okf"], pr2["olm"], pr2["ori"], pr2["ouv"])], cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R)
+    # the context is still usable after errors
+    res = c.local_ba([(pr["poses0"], pr["pts0"], pr["okf"], pr["olm"], pr["ori"], pr["ouv"])], cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R)
+    assert res[0][3] >= 1
+    c.close()
+    with pytest.raises(RuntimeError):
+        svs.Context(8, 8)                                        # below the minimum image size
+    with pytest.raises(RuntimeError):
+        svs.Context(cm.W, cm.H, max_pts=4096)                    # above what the pose-only kernel holds
+
+
+def test_ragged_batch_and_max_sizes(svs, orc):
+    l0, r0 = svs.synth_pair(31, 0)
+    l1, _ = svs.synth_pair(31, 1)
+    c = svs.Context(cm.W, cm.H, max_slots=4, max_jobs=6, max_pts=512, max_corners=1024, max_kf=2, max_lm=8, max_obs=8)
+    c.pyramid([0, 1, 2], [l0, r0, l1])
+    many = orc.gftt(l0, None, 1024, 0.0005, 2.0)
+    assert len(many) >= 512
+    pts512 = many[:512]
+    sizes = [512, 1, 0, 77, 3, 512]
+    jobs = [(0, 2 if i % 2 else 1, pts512[:n], pts512[:n] + 0.5) for i, n in enumerate(sizes)]
+    res = c.lk(jobs)
+    for (q, st, err), (ps, ns, p, g) in zip(res, jobs):
+        q_ref, st_ref, err_ref = orc.lk(l0, l1 if ns == 2 else r0, p, g)
+        assert np.array_equal(st, st_ref) and np.array_equal(q.view(np.uint32), q_ref.view(np.uint32))
+    # GFTT with the largest corner budget and a tiny min distance
+    (cr,) = c.gftt([(0, None)], max_corners=1024, quality=0.0005, min_dist=2.0)
+    assert np.array_equal(cr, many[:len(cr)]) and len(cr) == min(1024, len(many))
+    # pose-only at the 512-edge limit
+    rng = np.random.default_rng(1)
+    P = np.stack([rng.uniform(-8, 8, 512), rng.uniform(-3, 1.5, 512), rng.uniform(5, 50, 512)], 1)
+    T_true = cm.random_pose(rng, 0.5, 0.03)
+    uv, _ = cm.project(cm.CAM, T_true, cm.EXT_L, P)
+    uv = (uv + rng.normal(0, 0.4, uv.shape)).astype(np.float32)
+    (T, outl, ninl), (T2, o2, n2) = c.pose_only([(cm.EXT_L, P, uv), (cm.EXT_L, P[:1], uv[:1])], cm.CAM)
+    T_ref, outl_ref, ninl_ref = orc.pose_only(cm.CAM, cm.EXT_L, P, uv)
+    assert np.allclose(T, T_ref, atol=1e-6) and np.array_equal(outl, outl_ref) and ninl == ninl_ref
+    T2r, o2r, n2r = orc.pose_only(cm.CAM, cm.EXT_L, P[:1], uv[:1])
+    assert np.allclose(T2, T2r, atol=1e-6) and n2 == n2r
+    c.close()
+
+
+def test_ba_more_than_64_rows_and_inactive_vertices(svs, orc):
+    rng = np.random.default_rng(2)
+    c = svs.Context(cm.W, cm.H, max_slots=1, max_jobs=3, max_kf=12, max_lm=3000, max_obs=20000)
+    big = cm.make_ba_problem(rng, 12, 2500)            # np = 72 > 64 rows; 2500 landmarks
+    keep = rng.random(len(big["okf"])) < 0.25
+    small = cm.make_ba_problem(rng, 2, 6)
+    gap = cm.make_ba_problem(rng, 6, 200)              # remove all edges of one pose and a few landmarks
+    m = (gap["okf"] != 2) & (gap["olm"] % 17 != 0)
+    jobs = [(big["poses0"], big["pts0"], big["okf"][keep], big["olm"][keep], big["ori"][keep], big["ouv"][keep]),
+            (small["poses0"], small["pts0"], small["okf"], small["olm"], small["ori"], small["ouv"]),
+            (gap["poses0"], gap["pts0"], gap["okf"][m], gap["olm"][m], gap["ori"][m], gap["ouv"][m])]
+    res = c.local_ba(jobs, cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R)
+    for (poses, pts, chi2, it), job in zip(res, jobs):
+        pa, xa, ca, ia = orc.local_ba(cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R, *job, jac_mode=0)
+        assert it == ia
+        assert np.allclose(poses[:, 4:], pa[:, 4:], atol=1e-6) and np.allclose(poses[:, :4], pa[:, :4], atol=1e-7)
+        assert np.allclose(pts, xa, rtol=1e-6, atol=1e-6)
+        assert np.allclose(chi2, ca, rtol=1e-5, atol=1e-6)
+    # vertices without edges are untouched (g2o: not part of the active problem)
+    assert np.array_equal(res[2][0][2], gap["poses0"][2])
+    assert np.array_equal(res[2][1][0], gap["pts0"][0]) and np.array_equal(res[2][1][17], gap["pts0"][17])
+    # zero-edge job
+    (p0, x0, ch0, it0), = c.local_ba([(small["poses0"], small["pts0"], np.zeros(0, np.int32), np.zeros(0, np.int32),
+                                       np.zeros(0, np.uint8), np.zeros((0, 2), np.float32))], cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R)
+    assert it0 == 0 and np.array_equal(p0, small["poses0"]) and np.array_equal(x0, small["pts0"])
+    c.close()
+
+
+def test_full_resolution_decimating_path_matches_host_decimation(svs, orc):
+    """f3: 1241x376 frames, the reference's 1/2 INTER_NEAREST resize fused into the level-0 write"""
+    rng = np.random.default_rng(3)
+    from scipy import ndimage
+    full = ndimage.gaussian_filter(rng.random((376, 1241)), 1.5)
+    full = np.clip((full - full.min()) / (full.max() - full.min()) * 255, 0, 255).astype(np.uint8)
+    c = svs.Context(620, 188, max_slots=2, max_jobs=2, max_kf=0, max_lm=0, max_obs=0)
+    c.pyramid([0], [full], decimate_from=(1241, 376))
+    dec = orc.decimate(full)
+    c.pyramid([1], [dec])
+    for lvl in range(4):
+        assert np.array_equal(c.pyramid_read(0, lvl), c.pyramid_read(1, lvl))
+    (a, b) = c.gftt([(0, None), (1, None)])
+    assert np.array_equal(a, b) and np.array_equal(a, orc.gftt(dec))
+    # device-resident source
+    d = c.dev_alloc(full.size)
+    c.dev_upload(d, full)
+    c.pyramid([0], [d], device=True, strides=[1241], decimate_from=(1241, 376))
+    assert np.array_equal(c.pyramid_read(0, 2), orc.pyramid(dec)[2])
+    c.dev_free(d)
+    c.close()
