@@ -187,16 +187,28 @@ int launch_pyramid(svslam_ctx *c, const PyrJob *djobs, int n, bool decimate, int
 {
     const PyrGeom &g = c->geom;
     tm_begin(c, FAM_PYR, n);
-    {
+    auto fast_ok = [](int w, int h) { return w >= 18 && h >= 18; };
+    if (fast_ok(g.w[0], g.h[0])) {
+        dim3 blk(16, 16);
+        dim3 grd(cdiv(cdiv(g.w[0], 16), 16), cdiv(g.h[0], 16), n);
+        if (decimate) hipLaunchKernelGGL(k_pyr_level0_fast<true>, grd, blk, 0, c->stream, djobs, c->d_pyr, g, src_w, src_h);
+        else hipLaunchKernelGGL(k_pyr_level0_fast<false>, grd, blk, 0, c->stream, djobs, c->d_pyr, g, src_w, src_h);
+    } else {
         dim3 blk(64, 4);
         dim3 grd(cdiv((g.w[0] + 2 * SVS_BORDER + 3) / 4, 64), cdiv(g.h[0] + 2 * SVS_BORDER, 4), n);
         if (decimate) hipLaunchKernelGGL(k_pyr_level0<true>, grd, blk, 0, c->stream, djobs, c->d_pyr, g, src_w, src_h);
         else hipLaunchKernelGGL(k_pyr_level0<false>, grd, blk, 0, c->stream, djobs, c->d_pyr, g, src_w, src_h);
     }
     for (int l = 1; l < g.nlevels; ++l) {
-        dim3 blk(64, 4);
-        dim3 grd(cdiv(g.w[l] + 2 * SVS_BORDER, 64), cdiv(g.h[l] + 2 * SVS_BORDER, 4), n);
-        hipLaunchKernelGGL(k_pyr_down, grd, blk, 0, c->stream, djobs, c->d_pyr, g, l);
+        if (fast_ok(g.w[l], g.h[l])) {
+            dim3 blk(32, 8);
+            dim3 grd(cdiv(cdiv(g.w[l], 4), 32), cdiv(g.h[l], 8), n);
+            hipLaunchKernelGGL(k_pyr_down_fast, grd, blk, 0, c->stream, djobs, c->d_pyr, g, l);
+        } else {
+            dim3 blk(64, 4);
+            dim3 grd(cdiv(g.w[l] + 2 * SVS_BORDER, 64), cdiv(g.h[l] + 2 * SVS_BORDER, 4), n);
+            hipLaunchKernelGGL(k_pyr_down, grd, blk, 0, c->stream, djobs, c->d_pyr, g, l);
+        }
     }
     tm_end(c);
     HIPCHK(c, hipGetLastError());
