@@ -66,6 +66,18 @@ def measured_traffic(fam, cnt, launches):
     return t["bytes"] * units / launches
 
 
+def effective_cpus():
+    """CPUs this process may actually burn: min(affinity, cgroup v2 cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -98,7 +110,7 @@ def main():
         G -= 1
     if args.host_threads <= 0:        # auto: share the box's cores between the ranks of this node
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-        args.host_threads = max(2, min(12, (os.cpu_count() or 8) // max(1, local_world * G)))
+        args.host_threads = max(2, min(12, effective_cpus() // max(1, local_world * G)))
     Sg = S // G
     F = Wm + K
     cfg = pl.default_config(W, H, host_threads=max(1, args.host_threads))
@@ -160,11 +172,15 @@ def main():
     for c in ctxs:
         c.timing(True)
     barrier()
+    import resource
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
     res_g = run_all(Wm, K, True)
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     t1 = time.perf_counter()
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    cpu_busy = ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / max(t1 - t0, 1e-9)
     barrier()
     elapsed = rk.max_over_ranks(t1 - t0)
     c1 = counters_sum()
@@ -213,7 +229,8 @@ def main():
             "host_ms_per_step": {"in_step": round(cnt["ns_step"] / 1e6 / K / G, 3),
                                  "in_abi_calls": round(cnt["ns_kernel_calls"] / 1e6 / K / G, 3),
                                  "h2d_enqueue": round(hostns[0] / 1e6 / K / G, 3), "d2h_enqueue": round(hostns[1] / 1e6 / K / G, 3),
-                                 "stream_wait": round(hostns[2] / 1e6 / K / G, 3), "event_collect": round(hostns[5] / 1e6 / K / G, 3), "ba_host_prep": round(hostns[4] / 1e6 / K / G, 3)},
+                                 "stream_wait": round(hostns[2] / 1e6 / K / G, 3), "event_collect": round(hostns[5] / 1e6 / K / G, 3), "ba_host_prep": round(hostns[4] / 1e6 / K / G, 3),
+                                 "cpus_busy": round(cpu_busy, 2), "cpus_allowed": effective_cpus()},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(svs, pl, ctx, cfg, d_left, F, img, S, min(args.cpu_frames, S * F),

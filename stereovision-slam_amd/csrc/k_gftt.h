@@ -20,13 +20,14 @@
 #pragma once
 #include "dev_common.h"
 
+#define GF_CNT_STRIDE 32
 struct GfttJob { int slot, rect_ofs, nrect; };
 
 struct GfttWork {            // per-job scratch in HBM
     float *eig;              // [jobs][w*h]
     uint8_t *mask;           // [jobs][w*h]
     unsigned long long *keys;// [jobs][cap]
-    unsigned int *counters;  // [jobs][4]: 0 = ordered max, 1 = ncand
+    unsigned int *counters;  // [jobs][GF_CNT_STRIDE]: 0 = ordered max, 1 = ncand (one 128 B line per job)
     int cap;                 // key capacity per job (power of two >= w*h)
 };
 
@@ -50,7 +51,7 @@ __global__ void k_gftt_init(GfttWork wk, int w, int h, int njobs)
     const size_t n4 = (P + 3) >> 2;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
         m[i] = 0xffffffffu;
-    if (blockIdx.x == 0 && threadIdx.x < 4) wk.counters[job * 4 + threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < 4) wk.counters[job * GF_CNT_STRIDE + threadIdx.x] = 0;
 }
 
 // one block per rectangle (grid.x = max nrect over jobs, grid.y = job)
@@ -159,37 +160,73 @@ k_gftt_eig(const GfttJob *jobs, const uint8_t *pyr, PyrGeom g, GfttWork wk)
     __syncthreads();
     if (tid == 0) {
         best = max(max(sMax[0], sMax[1]), max(sMax[2], sMax[3]));
-        if (best) atomicMax(&wk.counters[job * 4 + 0], best);
+        if (best) atomicMax(&wk.counters[job * GF_CNT_STRIDE + 0], best);
     }
 }
 
+// thread = 4 consecutive pixels of one row; candidates are compacted with one LDS atomic per
+// thread and ONE global atomic per block (a per-candidate global atomic serialises ~3000
+// same-address operations per image).  The key order is irrelevant: k_gftt_select sorts.
 __global__ void __launch_bounds__(256)
 k_gftt_cand(GfttWork wk, int w, int h, double quality)
 {
+    __shared__ unsigned int sCnt, sBase;
     const int job = blockIdx.z;
     const size_t P = (size_t)w * h;
     const float *eig = wk.eig + (size_t)job * P;
     const uint8_t *mask = wk.mask + (size_t)job * ((P + 3) & ~(size_t)3);
-    const unsigned int mk = wk.counters[job * 4 + 0];
+    const unsigned int mk = wk.counters[job * GF_CNT_STRIDE + 0];
     const double maxVal = mk ? (double)f32_from_ordered(mk) : 0.0;
     const float thr = (float)(maxVal * quality);
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1) return;
-    const size_t i = (size_t)y * w + x;
-    const float v = eig[i];
-    if (!(v > thr) || v == 0.f || !mask[i]) return;
+    if (tid == 0) sCnt = 0;
+    __syncthreads();
+    float v[4] = { 0.f, 0.f, 0.f, 0.f };
+    unsigned int pm = 0;
+    if (y >= 1 && y < h - 1 && x < w) {
+        // thresholded 3 x 6 neighbourhood (columns x-1 .. x+4, clamped loads; the clamped
+        // positions are only ever neighbours of pixels that are skipped anyway)
+        float t[3][6];
 #pragma unroll
-    for (int j = -1; j <= 1; ++j)
+        for (int j = 0; j < 3; ++j)
 #pragma unroll
-        for (int k = -1; k <= 1; ++k) {
-            float u = eig[i + (ptrdiff_t)j * w + k];
-            float ut = u > thr ? u : 0.f;
-            if (ut > v) return;
+            for (int k = 0; k < 6; ++k) {
+                const int xx = min(max(x - 1 + k, 0), w - 1);
+                const float u = eig[(size_t)(y - 1 + j) * w + xx];
+                t[j][k] = u > thr ? u : 0.f;
+                if (j == 1 && k >= 1 && k <= 4) v[k - 1] = u;
+            }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int xx = x + k;
+            bool pass = xx >= 1 && xx < w - 1 && v[k] > thr && v[k] != 0.f;
+            if (pass) pass = mask[(size_t)y * w + xx] != 0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) pass = pass && !(t[j][k + q] > v[k]);
+            pm |= (unsigned int)pass << k;
         }
-    unsigned int slot = atomicAdd(&wk.counters[job * 4 + 1], 1u);
-    if (slot < (unsigned int)wk.cap)
-        wk.keys[(size_t)job * wk.cap + slot] = ((unsigned long long)f32_ordered(v) << 32) | (unsigned int)i;
+    }
+    unsigned int off = 0;
+    const unsigned int np = __popc(pm);
+    if (np) off = atomicAdd(&sCnt, np);
+    __syncthreads();
+    if (tid == 0) sBase = sCnt ? atomicAdd(&wk.counters[job * GF_CNT_STRIDE + 1], sCnt) : 0u;
+    __syncthreads();
+    if (np) {
+        unsigned int slot = sBase + off;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if ((pm >> k) & 1u) {
+                if (slot < (unsigned int)wk.cap)
+                    wk.keys[(size_t)job * wk.cap + slot] =
+                        ((unsigned long long)f32_ordered(v[k]) << 32) | (unsigned int)((size_t)y * w + x + k);
+                ++slot;
+            }
+    }
 }
 
 #define GF_SEL_THREADS 1024
@@ -227,7 +264,7 @@ k_gftt_select(GfttWork wk, int w, int max_corners, double min_dist, float2 *out_
 
     const int job = blockIdx.x;
     const int tid = threadIdx.x;
-    unsigned int n = wk.counters[job * 4 + 1];
+    unsigned int n = wk.counters[job * GF_CNT_STRIDE + 1];
     if (n > (unsigned int)wk.cap) n = wk.cap;
     unsigned long long *gkeys = wk.keys + (size_t)job * wk.cap;
     float2 *out = out_xy + (size_t)job * out_stride;

@@ -10,6 +10,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
+#include <sys/prctl.h>
 #include <new>
 #include <string>
 #include <vector>
@@ -71,6 +73,7 @@ struct svslam_ctx {
     long long *d_ba_prof = nullptr;
     // host-side wall time (ns): 0 h2d enqueue, 1 d2h enqueue, 2 stream wait, 3 launches, 4 staging memcpy/prep
     long long host_ns[8] = { 0 };
+    bool wait_poll = true;
     // timing
     bool timing = false;
     Timing tm;
@@ -152,6 +155,23 @@ inline long long now_ns()
 {
     return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
+// Wait for the context's stream.  The runtime's own wait spins; with thousands of streams
+// the host bookkeeping needs every core that would burn, so the default here is a short
+// spin followed by sleep-polling (SVSLAM_WAIT=spin restores hipStreamSynchronize).
+hipError_t wait_stream(svslam_ctx *c)
+{
+    if (!c->wait_poll) return hipStreamSynchronize(c->stream);
+    static thread_local bool slack_set = false;
+    if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0); slack_set = true; }
+    const long long t0 = now_ns();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(c->stream);
+        if (e != hipErrorNotReady) return e;
+        if (now_ns() - t0 < 15000) continue;
+        struct timespec ts = { 0, 20000 };
+        nanosleep(&ts, nullptr);
+    }
+}
 int h2d(svslam_ctx *c, size_t from, size_t to)
 {
     const long long t0 = now_ns();
@@ -165,7 +185,7 @@ int d2h_sync(svslam_ctx *c, size_t from, size_t to)
     if (to > from) HIPCHK(c, hipMemcpyAsync(c->ar.h + from, c->ar.d + from, to - from, hipMemcpyDeviceToHost, c->stream));
     long long t1 = now_ns();
     c->host_ns[1] += t1 - t0;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, wait_stream(c));
     t0 = now_ns();
     c->host_ns[2] += t0 - t1;
     tm_collect(c);
@@ -289,6 +309,10 @@ int svslam_create(const svslam_limits *lim, svslam_ctx **out)
     c->device = lim->device;
     *out = c; // returned even on failure so the caller can read the error
     HIPCHK(c, hipSetDevice(c->device));
+    {
+        const char *wm = std::getenv("SVSLAM_WAIT");        // spin | poll (default)
+        c->wait_poll = !(wm && std::strcmp(wm, "spin") == 0);
+    }
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (int i = 0; i < 16; ++i) HIPCHK(c, hipEventCreate(&c->ev[i]));
     make_geom(c->geom, lim->width, lim->height);
@@ -313,7 +337,7 @@ int svslam_create(const svslam_limits *lim, svslam_ctx **out)
     HIPCHK(c, hipMalloc(&c->gw.eig, sizeof(float) * P * J));
     HIPCHK(c, hipMalloc(&c->gw.mask, ((P + 3) & ~(size_t)3) * J));
     HIPCHK(c, hipMalloc(&c->gw.keys, sizeof(unsigned long long) * (size_t)cap * J));
-    HIPCHK(c, hipMalloc(&c->gw.counters, sizeof(unsigned int) * 4 * J));
+    HIPCHK(c, hipMalloc(&c->gw.counters, sizeof(unsigned int) * GF_CNT_STRIDE * J));
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_gftt_select),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, GF_SEL_LDS_BYTES));
     // BA scratch
@@ -478,7 +502,7 @@ static int launch_gftt(svslam_ctx *c, int njobs, const GfttJob *djobs, int max_n
         hipLaunchKernelGGL(k_gftt_mask, dim3(max_nrect, njobs), dim3(256), 0, c->stream, djobs, c->gw, drects, w, h);
     hipLaunchKernelGGL(k_gftt_eig, dim3(cdiv(w, GF_TW), cdiv(h, GF_TH), njobs), dim3(256), 0, c->stream, djobs,
                        c->d_pyr, c->geom, c->gw);
-    hipLaunchKernelGGL(k_gftt_cand, dim3(cdiv(w, 64), cdiv(h, 4), njobs), dim3(64, 4), 0, c->stream, c->gw, w, h,
+    hipLaunchKernelGGL(k_gftt_cand, dim3(cdiv(w, 256), cdiv(h, 4), njobs), dim3(64, 4), 0, c->stream, c->gw, w, h,
                        quality);
     hipLaunchKernelGGL(k_gftt_select, dim3(njobs), dim3(GF_SEL_THREADS), GF_SEL_LDS_BYTES, c->stream, c->gw, w,
                        max_corners, min_dist, dout, dn, max_corners);
