@@ -89,6 +89,22 @@ __device__ __forceinline__ double row_sum_f64(double v)
     v += dpp_f64<SVS_DPP_MIRROR>(v);
     return v;
 }
+__device__ __forceinline__ int row_sum_i32(int v)     // every lane: sum over its 16-lane DPP row
+{
+    v += dpp_i32<SVS_DPP_XOR1>(v);
+    v += dpp_i32<SVS_DPP_XOR2>(v);
+    v += dpp_i32<SVS_DPP_HALF_MIRROR>(v);
+    v += dpp_i32<SVS_DPP_MIRROR>(v);
+    return v;
+}
+// int32 lanes whose 16-lane partial sums fit int32 but whose total may not: row sums on the
+// VALU (4 fused DPP adds), the last 4-term sum in 64-bit scalar arithmetic
+__device__ __forceinline__ long long wave_sum_i32_wide(int v)
+{
+    v = row_sum_i32(v);
+    return ((long long)__builtin_amdgcn_readlane(v, 0) + (long long)__builtin_amdgcn_readlane(v, 16)) +
+           ((long long)__builtin_amdgcn_readlane(v, 32) + (long long)__builtin_amdgcn_readlane(v, 48));
+}
 __device__ __forceinline__ int wave_sum_i32(int v)
 {
     v += dpp_i32<SVS_DPP_XOR1>(v);

@@ -6,17 +6,26 @@
 // the result bit-exact against the oracle.
 //
 // Mapping: window 11x11 = 121 pixels -> 2 pixels per lane.  Per level the wave
-//   1. stages the 14x14 I neighbourhood (HBM -> LDS, rows of the stored-border
-//      pyramid, no index arithmetic),
-//   2. computes the Scharr derivatives of the 12x12 inner positions on the fly
-//      (the reference materialises a full int16x2 derivative image per level —
-//      5.3 bytes/pixel of HBM traffic that is never needed),
-//   3. interpolates its two I/Ix/Iy samples (Q14 weights) into registers and
-//      wave-reduces A11,A12,A22 (int32, exact),
+//   1. stages the 14 x 20 I neighbourhood (aligned dword loads from the
+//      stored-border pyramid -> LDS, no index arithmetic),
+//   2. computes the Scharr derivatives of the 12x12 inner positions on the fly,
+//      3 horizontally adjacent positions per lane so the vertical [3 10 3] /
+//      [-1 0 1] passes are shared (the reference materialises a full int16x2
+//      derivative image per level — 5.3 bytes/pixel of HBM traffic never needed),
+//   3. interpolates its two I/Ix/Iy samples (Q14 weights, v_dot2_i32_i16) into
+//      registers and wave-reduces A11,A12,A22 (int32, exact),
 //   4. stages a 32x32 J search region into LDS with aligned dword loads and
 //      iterates entirely out of LDS (re-staging only if the window leaves the
-//      region), wave-reducing b1,b2 as exact int64.
-// All control flow is wave-uniform; waves never synchronise with each other.
+//      region); b1,b2 are reduced as int32 DPP row sums + a 64-bit scalar tail.
+// LDS discipline: every LDS access is a naturally aligned dword (pairs via
+// ds_read2_b32); bytes at arbitrary offsets are extracted with v_perm_b32 /
+// v_alignbyte_b32 using a per-lane selector.  A misaligned ds_read_u16/b32 is
+// legal on gfx950 but is replayed lane by lane (measured ~40 LDS-pipe cycles
+// per wave instruction, tools/ubench2.hip) and made an earlier version of this
+// kernel LDS-pipe bound.  Beyond that the kernel is VALU-issue bound (the
+// per-iteration arithmetic is mostly wave-uniform bookkeeping), so it uses 16-bit
+// dot products for the bilinear taps, 24-bit multiplies and no 64-bit vector
+// arithmetic.  All control flow is wave-uniform; waves never synchronise.
 #pragma once
 #include "dev_common.h"
 
@@ -32,18 +41,51 @@ struct LkParams {
 #define LK_WIN 11
 #define LK_NPIX 121
 #define LK_W_BITS 14
-#define LK_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
 #define LK_REG 32
 #define LK_WAVES_PER_BLOCK 4
+#define LK_IROW 20            // bytes per staged I row (5 aligned dwords)
 
-__device__ __forceinline__ void lk_weights(float a, float b, int &w00, int &w01, int &w10, int &w11)
+typedef uint32_t lk_u32_ua __attribute__((aligned(1)));
+typedef uint16_t lk_u16_ua __attribute__((aligned(1)));
+typedef short lk_s2 __attribute__((ext_vector_type(2)));
+
+// a.lo*b.lo + a.hi*b.hi + c on signed 16-bit halves (v_dot2_i32_i16): one bilinear tap pair
+__device__ __forceinline__ int lk_dot2(uint32_t a, uint32_t b, int c)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_s2, a), __builtin_bit_cast(lk_s2, b), c, false);
+}
+// Bytes (a, a+1) of an LDS byte array, any a, widened to two u16 halves: one aligned
+// ds_read2_b32 + one v_perm_b32 with the per-lane selector lk_pair_sel(a).
+#define LK_PAIR_SEL0 0x0c010c00u
+__device__ __forceinline__ uint32_t lk_pair_sel(int a) { return LK_PAIR_SEL0 + (uint32_t)(a & 3) * 0x00010001u; }
+__device__ __forceinline__ uint32_t lk_pair_at(const uint32_t *base32, int a, uint32_t sel)
+{
+    const uint32_t *q = base32 + (a >> 2);
+    return __builtin_amdgcn_perm(q[1], q[0], sel);
+}
+
+struct LkW { uint32_t top, bot; };   // (w00 | w01 << 16), (w10 | w11 << 16); w11 may be -1 (kept signed)
+
+__device__ __forceinline__ LkW lk_weights(float a, float b)
 {
     // cvRound == round-half-even == rintf
-    // the inputs are wave-uniform: keep the weights in SGPRs
-    w00 = __builtin_amdgcn_readfirstlane((int)rintf((1.f - a) * (1.f - b) * (float)(1 << LK_W_BITS)));
-    w01 = __builtin_amdgcn_readfirstlane((int)rintf(a * (1.f - b) * (float)(1 << LK_W_BITS)));
-    w10 = __builtin_amdgcn_readfirstlane((int)rintf((1.f - a) * b * (float)(1 << LK_W_BITS)));
-    w11 = (1 << LK_W_BITS) - w00 - w01 - w10;
+    const int w00 = (int)rintf((1.f - a) * (1.f - b) * (float)(1 << LK_W_BITS));
+    const int w01 = (int)rintf(a * (1.f - b) * (float)(1 << LK_W_BITS));
+    const int w10 = (int)rintf((1.f - a) * b * (float)(1 << LK_W_BITS));
+    const int w11 = (1 << LK_W_BITS) - w00 - w01 - w10;
+    LkW w;
+    w.top = ((uint32_t)w00 & 0xffffu) | ((uint32_t)w01 << 16);
+    w.bot = ((uint32_t)w10 & 0xffffu) | ((uint32_t)w11 << 16);
+    return w;
+}
+
+// bilinear sample of a u8 patch held in LDS (dword view base32, byte offset a of the top-left
+// tap, row stride in bytes a multiple of 4), Q5 output: CV_DESCALE(sum, W_BITS - 5)
+__device__ __forceinline__ int lk_sample_u8(const uint32_t *base32, int a, int row_stride, LkW w)
+{
+    const uint32_t sel = lk_pair_sel(a);
+    const uint32_t t = lk_pair_at(base32, a, sel), b = lk_pair_at(base32, a + row_stride, sel);
+    return lk_dot2(t, w.top, lk_dot2(b, w.bot, 1 << (LK_W_BITS - 5 - 1))) >> (LK_W_BITS - 5);
 }
 
 __device__ __forceinline__ void lk_stage_J(uint32_t *sJ, const uint8_t *J0, int pitch, int w, int h,
@@ -51,42 +93,49 @@ __device__ __forceinline__ void lk_stage_J(uint32_t *sJ, const uint8_t *J0, int 
 {
     rx0 = __builtin_amdgcn_readfirstlane((cx - 10) & ~3);
     ry0 = __builtin_amdgcn_readfirstlane(cy - 10);
-    const int gxmax = (w + SVS_BORDER - 4) & ~3;
+    const int r = lane >> 3, c4 = lane & 7;
+    if (rx0 >= -SVS_BORDER && rx0 + LK_REG <= w + SVS_BORDER && ry0 >= -SVS_BORDER && ry0 + LK_REG <= h + SVS_BORDER) {
+        const uint8_t *p = J0 + (ptrdiff_t)(ry0 + r) * pitch + (rx0 + c4 * 4);
 #pragma unroll
-    for (int i = lane; i < LK_REG * (LK_REG / 4); i += 64) {
-        int r = i >> 3, c4 = i & 7;
-        int gy = ry0 + r, gx = rx0 + c4 * 4;
-        gy = max(-SVS_BORDER, min(gy, h + SVS_BORDER - 1));
-        gx = max(-SVS_BORDER, min(gx, gxmax));
-        sJ[i] = *reinterpret_cast<const uint32_t *>(J0 + (ptrdiff_t)gy * pitch + gx);
+        for (int k = 0; k < 4; ++k)
+            sJ[lane + 64 * k] = *reinterpret_cast<const uint32_t *>(p + (ptrdiff_t)(8 * k) * pitch);
+    } else {
+        const int gxmax = (w + SVS_BORDER - 4) & ~3;
+        const int gx = max(-SVS_BORDER, min(rx0 + c4 * 4, gxmax));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int gy = max(-SVS_BORDER, min(ry0 + r + 8 * k, h + SVS_BORDER - 1));
+            sJ[lane + 64 * k] = *reinterpret_cast<const uint32_t *>(J0 + (ptrdiff_t)gy * pitch + gx);
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ int lk_sample_J(const uint8_t *sJb, int o, int w00, int w01, int w10, int w11)
+// exact int64 -> f32 (round to nearest even); the sums fit int32 except for adversarial patches
+__device__ __forceinline__ float lk_i64_to_f32(long long s)
 {
-    int v = sJb[o] * w00 + sJb[o + 1] * w01 + sJb[o + LK_REG] * w10 + sJb[o + LK_REG + 1] * w11;
-    return LK_DESCALE(v, LK_W_BITS - 5);
+    const int lo = (int)s;
+    if ((long long)lo == s) return (float)lo;
+    return (float)(double)s;
 }
 
 __global__ void __launch_bounds__(64 * LK_WAVES_PER_BLOCK)
 k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, float2 *next_xy,
      uint8_t *status, float *err, LkParams prm)
 {
-    __shared__ uint8_t sI_all[LK_WAVES_PER_BLOCK][14 * 16];
+    __shared__ uint32_t sI_all[LK_WAVES_PER_BLOCK][14 * LK_IROW / 4 + 2];
     __shared__ uint32_t sD_all[LK_WAVES_PER_BLOCK][144];
-    __shared__ uint32_t sJ_all[LK_WAVES_PER_BLOCK][LK_REG * LK_REG / 4];
+    __shared__ uint32_t sJ_all[LK_WAVES_PER_BLOCK][LK_REG * LK_REG / 4 + 8];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const LkJob jb = jobs[blockIdx.y];
     const int pi = blockIdx.x * LK_WAVES_PER_BLOCK + wave;
     if (pi >= jb.npts) return;
     const int pt = jb.pt_ofs + pi;
-    uint8_t *sI = sI_all[wave];
+    uint32_t *sI32 = sI_all[wave];
     uint32_t *sD = sD_all[wave];
     uint32_t *sJ = sJ_all[wave];
-    const uint8_t *sJb = reinterpret_cast<const uint8_t *>(sJ);
 
     const uint8_t *slotI = pyr + (size_t)jb.prev_slot * g.slot_bytes;
     const uint8_t *slotJ = pyr + (size_t)jb.next_slot * g.slot_bytes;
@@ -96,11 +145,17 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
     bool st = true;
     float errv = 0.f;
 
-    // this lane's two window pixels
+    // this lane's two window pixels (lanes >= 57 have only one; their second pixel is
+    // aliased to pixel 0 and its I/Ix/Iy forced to zero so it drops out of every sum)
     const int p0 = lane, p1 = lane + 64;
-    const int wy0 = p0 / LK_WIN, wx0 = p0 - wy0 * LK_WIN;
-    const int wy1 = p1 / LK_WIN, wx1 = p1 - wy1 * LK_WIN;
     const bool has1 = p1 < LK_NPIX;
+    const int wy0 = p0 / LK_WIN, wx0 = p0 - wy0 * LK_WIN;
+    const int wy1 = has1 ? p1 / LK_WIN : 0, wx1 = has1 ? p1 - wy1 * LK_WIN : 0;
+    const int oI0 = (wy0 + 1) * LK_IROW + wx0 + 1, oI1 = (wy1 + 1) * LK_IROW + wx1 + 1;
+    const int oD0 = wy0 * 12 + wx0, oD1 = wy1 * 12 + wx1;
+    const int oJ0 = wy0 * LK_REG + wx0, oJ1 = wy1 * LK_REG + wx1;
+    // Scharr work split: lanes 0..47 -> row lane/4, columns 3*(lane%4) .. +2
+    const int sr = lane >> 2, sc = (lane & 3) * 3;
     const float FLT_SCALE = 1.f / (float)(1 << 20);
 
     int max_level = prm.max_level;
@@ -125,60 +180,77 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
             if (level == 0) { st = false; errv = 0.f; }
             continue;
         }
-        int iw00, iw01, iw10, iw11;
-        lk_weights(px - (float)ipx, py - (float)ipy, iw00, iw01, iw10, iw11);
+        const LkW iw = lk_weights(px - (float)ipx, py - (float)ipy);
 
-        // 1. stage I neighbourhood: rows ipy-1..ipy+12, cols ipx-1..ipx+12
+        // 1. stage I neighbourhood: rows ipy-1..ipy+12, 20 bytes from the aligned column xs <= ipx-1
+        const int xs = (ipx - 1) & ~3, a0 = (ipx - 1) & 3;   // patch byte (r, c) lives at r*LK_IROW + a0 + c
         __builtin_amdgcn_wave_barrier();
-        for (int i = lane; i < 14 * 14; i += 64) {
-            int r = i / 14, c = i - r * 14;
-            sI[r * 16 + c] = I0[(ptrdiff_t)(ipy - 1 + r) * pitch + (ipx - 1 + c)];
+        {
+            const uint8_t *Ib = I0 + (ptrdiff_t)(ipy - 1) * pitch + xs;
+            uint32_t v0 = 0, v1 = 0;
+            if (lane < 56) v0 = *reinterpret_cast<const uint32_t *>(Ib + (ptrdiff_t)(lane >> 2) * pitch + (lane & 3) * 4);
+            if (lane < 14) v1 = *reinterpret_cast<const uint32_t *>(Ib + (ptrdiff_t)lane * pitch + 16);
+            if (lane < 56) sI32[(lane >> 2) * (LK_IROW / 4) + (lane & 3)] = v0;
+            if (lane < 14) sI32[lane * (LK_IROW / 4) + 4] = v1;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // 2. Scharr at the 12x12 positions (ipx+c, ipy+r); zero outside the image
-        for (int i = lane; i < 144; i += 64) {
-            int r = i / 12, c = i - r * 12;
-            const uint8_t *q = sI + r * 16 + c; // top-left of the 3x3 around (r+1,c+1)
-            int a0 = q[0], a1 = q[1], a2 = q[2];
-            int b0 = q[16], b2 = q[18];
-            int c0 = q[32], c1 = q[33], c2 = q[34];
-            int t0m = (a0 + c0) * 3 + b0 * 10;
-            int t0p = (a2 + c2) * 3 + b2 * 10;
-            int t1m = c0 - a0, t1c = c1 - a1, t1p = c2 - a2;
-            int dx = t0p - t0m;
-            int dy = (t1p + t1m) * 3 + t1c * 10;
-            int gx = ipx + c, gy = ipy + r;
-            if (gx < 0 || gx >= w || gy < 0 || gy >= h) { dx = 0; dy = 0; }
-            sD[i] = ((uint32_t)dx & 0xffffu) | ((uint32_t)dy << 16);
+        if (lane < 48) {
+            const int ab = sr * LK_IROW + a0 + sc;      // top-left byte of the 3x5 block
+            const int k8 = (ab & 3) * 8;
+            const uint32_t *q = sI32 + (ab >> 2);
+            int t0[5], t1[5];
+            {
+                const uint32_t al = q[0], ah = q[1], bl = q[LK_IROW / 4], bh = q[LK_IROW / 4 + 1],
+                               cl = q[2 * (LK_IROW / 4)], ch = q[2 * (LK_IROW / 4) + 1];
+                const uint32_t a4 = __builtin_amdgcn_alignbyte(ah, al, ab & 3), b4 = __builtin_amdgcn_alignbyte(bh, bl, ab & 3),
+                               c4 = __builtin_amdgcn_alignbyte(ch, cl, ab & 3);
+                const int a5 = (int)((ah >> k8) & 0xff), b5 = (int)((bh >> k8) & 0xff), c5 = (int)((ch >> k8) & 0xff);
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const int a = k < 4 ? (int)((a4 >> (8 * k)) & 0xff) : a5;
+                    const int b = k < 4 ? (int)((b4 >> (8 * k)) & 0xff) : b5;
+                    const int c = k < 4 ? (int)((c4 >> (8 * k)) & 0xff) : c5;
+                    t0[k] = (a + c) * 3 + b * 10;
+                    t1[k] = c - a;
+                }
+            }
+            const int gy = ipy + sr;
+            const bool rowin = gy >= 0 && gy < h;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                int dx = t0[k + 2] - t0[k];
+                int dy = (t1[k + 2] + t1[k]) * 3 + t1[k + 1] * 10;
+                const int gx = ipx + sc + k;
+                if (!(rowin && gx >= 0 && gx < w)) { dx = 0; dy = 0; }
+                sD[sr * 12 + sc + k] = ((uint32_t)dx & 0xffffu) | ((uint32_t)dy << 16);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // 3. interpolate the two samples of this lane
-        int iv0, ix0, iy0, iv1 = 0, ix1 = 0, iy1 = 0;
+        int iv0, ix0, iy0, iv1, ix1, iy1;
         {
-            const uint8_t *q = sI + (wy0 + 1) * 16 + wx0 + 1;
-            iv0 = LK_DESCALE(q[0] * iw00 + q[1] * iw01 + q[16] * iw10 + q[17] * iw11, LK_W_BITS - 5);
-            uint32_t d00 = sD[wy0 * 12 + wx0], d01 = sD[wy0 * 12 + wx0 + 1];
-            uint32_t d10 = sD[(wy0 + 1) * 12 + wx0], d11 = sD[(wy0 + 1) * 12 + wx0 + 1];
-            ix0 = LK_DESCALE((int)(short)(d00 & 0xffff) * iw00 + (int)(short)(d01 & 0xffff) * iw01 +
-                             (int)(short)(d10 & 0xffff) * iw10 + (int)(short)(d11 & 0xffff) * iw11, LK_W_BITS);
-            iy0 = LK_DESCALE(((int)d00 >> 16) * iw00 + ((int)d01 >> 16) * iw01 +
-                             ((int)d10 >> 16) * iw10 + ((int)d11 >> 16) * iw11, LK_W_BITS);
+            iv0 = lk_sample_u8(sI32, oI0 + a0, LK_IROW, iw);
+            const uint32_t d00 = sD[oD0], d01 = sD[oD0 + 1], d10 = sD[oD0 + 12], d11 = sD[oD0 + 13];
+            ix0 = lk_dot2(__builtin_amdgcn_perm(d01, d00, 0x05040100u), iw.top,
+                          lk_dot2(__builtin_amdgcn_perm(d11, d10, 0x05040100u), iw.bot, 1 << (LK_W_BITS - 1))) >> LK_W_BITS;
+            iy0 = lk_dot2(__builtin_amdgcn_perm(d01, d00, 0x07060302u), iw.top,
+                          lk_dot2(__builtin_amdgcn_perm(d11, d10, 0x07060302u), iw.bot, 1 << (LK_W_BITS - 1))) >> LK_W_BITS;
         }
-        if (has1) {
-            const uint8_t *q = sI + (wy1 + 1) * 16 + wx1 + 1;
-            iv1 = LK_DESCALE(q[0] * iw00 + q[1] * iw01 + q[16] * iw10 + q[17] * iw11, LK_W_BITS - 5);
-            uint32_t d00 = sD[wy1 * 12 + wx1], d01 = sD[wy1 * 12 + wx1 + 1];
-            uint32_t d10 = sD[(wy1 + 1) * 12 + wx1], d11 = sD[(wy1 + 1) * 12 + wx1 + 1];
-            ix1 = LK_DESCALE((int)(short)(d00 & 0xffff) * iw00 + (int)(short)(d01 & 0xffff) * iw01 +
-                             (int)(short)(d10 & 0xffff) * iw10 + (int)(short)(d11 & 0xffff) * iw11, LK_W_BITS);
-            iy1 = LK_DESCALE(((int)d00 >> 16) * iw00 + ((int)d01 >> 16) * iw01 +
-                             ((int)d10 >> 16) * iw10 + ((int)d11 >> 16) * iw11, LK_W_BITS);
+        {
+            iv1 = lk_sample_u8(sI32, oI1 + a0, LK_IROW, iw);
+            const uint32_t d00 = sD[oD1], d01 = sD[oD1 + 1], d10 = sD[oD1 + 12], d11 = sD[oD1 + 13];
+            ix1 = lk_dot2(__builtin_amdgcn_perm(d01, d00, 0x05040100u), iw.top,
+                          lk_dot2(__builtin_amdgcn_perm(d11, d10, 0x05040100u), iw.bot, 1 << (LK_W_BITS - 1))) >> LK_W_BITS;
+            iy1 = lk_dot2(__builtin_amdgcn_perm(d01, d00, 0x07060302u), iw.top,
+                          lk_dot2(__builtin_amdgcn_perm(d11, d10, 0x07060302u), iw.bot, 1 << (LK_W_BITS - 1))) >> LK_W_BITS;
+            if (!has1) { ix1 = 0; iy1 = 0; }
         }
-        const int sA11 = wave_sum_i32(ix0 * ix0 + ix1 * ix1);
-        const int sA12 = wave_sum_i32(ix0 * iy0 + ix1 * iy1);
-        const int sA22 = wave_sum_i32(iy0 * iy0 + iy1 * iy1);
+        const int sA11 = wave_sum_i32(__mul24(ix0, ix0) + __mul24(ix1, ix1));
+        const int sA12 = wave_sum_i32(__mul24(ix0, iy0) + __mul24(ix1, iy1));
+        const int sA22 = wave_sum_i32(__mul24(iy0, iy0) + __mul24(iy1, iy1));
         const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         const float dd = A11 - A22;
@@ -204,22 +276,23 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
                 lk_stage_J(sJ, J0, pitch, w, h, inx, iny, lane, rx0, ry0);
                 ox = inx - rx0; oy = iny - ry0;
             }
-            lk_weights(nx - (float)inx, ny - (float)iny, iw00, iw01, iw10, iw11);
-            int d0 = lk_sample_J(sJb, (oy + wy0) * LK_REG + ox + wx0, iw00, iw01, iw10, iw11) - iv0;
-            int pb1 = d0 * ix0, pb2 = d0 * iy0;
-            if (has1) {
-                int d1 = lk_sample_J(sJb, (oy + wy1) * LK_REG + ox + wx1, iw00, iw01, iw10, iw11) - iv1;
-                pb1 += d1 * ix1; pb2 += d1 * iy1;
-            }
-            const long long sb1 = wave_sum_i64((long long)pb1);
-            const long long sb2 = wave_sum_i64((long long)pb2);
-            const float b1 = (float)(double)sb1 * FLT_SCALE, b2 = (float)(double)sb2 * FLT_SCALE;
+            const LkW jw = lk_weights(nx - (float)inx, ny - (float)iny);
+            const int jo = oy * LK_REG + ox;
+            const int d0 = lk_sample_u8(sJ, jo + oJ0, LK_REG, jw) - iv0;
+            const int d1 = lk_sample_u8(sJ, jo + oJ1, LK_REG, jw) - iv1;
+            // |d| < 2^14, |Ix|,|Iy| < 2^13: 24-bit multiplies, 16-lane row sums fit int32
+            const int pb1 = __mul24(d0, ix0) + __mul24(d1, ix1);
+            const int pb2 = __mul24(d0, iy0) + __mul24(d1, iy1);
+            const long long sb1 = wave_sum_i32_wide(pb1);
+            const long long sb2 = wave_sum_i32_wide(pb2);
+            const float b1 = lk_i64_to_f32(sb1) * FLT_SCALE, b2 = lk_i64_to_f32(sb2) * FLT_SCALE;
             const float dx = (A12 * b2 - A22 * b1) * D;
             const float dy = (A12 * b1 - A11 * b2) * D;
             nx += dx; ny += dy;
             nextp.x = nx + 5.f; nextp.y = ny + 5.f;
             if ((double)dx * (double)dx + (double)dy * (double)dy <= prm.eps2) break;
-            if (j > 0 && (double)fabsf(dx + pdx) < 0.01 && (double)fabsf(dy + pdy) < 0.01) {
+            // (double)|v| < 0.01  <=>  |v| <= 0.01f  (0.01f is the largest float below 0.01)
+            if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
                 nextp.x -= dx * 0.5f; nextp.y -= dy * 0.5f;
                 break;
             }
@@ -229,7 +302,7 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
         if (st && level == 0) {
             // level-0 residual ("err" output); can still clear status
             const float fx = nextp.x - 5.f, fy = nextp.y - 5.f;
-            const int inx = (int)floorf(fx), iny = (int)floorf(fy);
+            const int inx = __builtin_amdgcn_readfirstlane((int)floorf(fx)), iny = __builtin_amdgcn_readfirstlane((int)floorf(fy));
             if (inx < -LK_WIN || inx >= w || iny < -LK_WIN || iny >= h) {
                 st = false;
                 continue;
@@ -239,13 +312,11 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
                 lk_stage_J(sJ, J0, pitch, w, h, inx, iny, lane, rx0, ry0);
                 ox = inx - rx0; oy = iny - ry0;
             }
-            lk_weights(fx - (float)inx, fy - (float)iny, iw00, iw01, iw10, iw11);
-            int d0 = lk_sample_J(sJb, (oy + wy0) * LK_REG + ox + wx0, iw00, iw01, iw10, iw11) - iv0;
-            int e = d0 < 0 ? -d0 : d0;
-            if (has1) {
-                int d1 = lk_sample_J(sJb, (oy + wy1) * LK_REG + ox + wx1, iw00, iw01, iw10, iw11) - iv1;
-                e += d1 < 0 ? -d1 : d1;
-            }
+            const LkW jw = lk_weights(fx - (float)inx, fy - (float)iny);
+            const int jo = oy * LK_REG + ox;
+            const int d0 = lk_sample_u8(sJ, jo + oJ0, LK_REG, jw) - iv0;
+            const int d1 = lk_sample_u8(sJ, jo + oJ1, LK_REG, jw) - iv1;
+            const int e = (d0 < 0 ? -d0 : d0) + (has1 ? (d1 < 0 ? -d1 : d1) : 0);
             const int serr = wave_sum_i32(e);
             errv = (float)serr * 1.f / (float)(32 * LK_WIN * LK_WIN);
         }

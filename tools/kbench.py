@@ -61,6 +61,28 @@ def frontend(nj=1, npts=230):
     c.close()
 
 
+def lkbench(nj=512, npts=150):
+    """LK throughput at bench scale: nj jobs x npts points, temporal and stereo pairs, by iteration cap."""
+    l0, r0 = svs.synth_pair(3, 0); l1, _ = svs.synth_pair(3, 1)
+    import oracle_lib as orc
+    pts = orc.gftt(l0, max_corners=npts, min_dist=20.0)
+    c = svs.Context(cm.W, cm.H, max_slots=3, max_jobs=nj, max_pts=max(len(pts), 8), max_kf=0, max_lm=0, max_obs=0)
+    c.pyramid([0, 1, 2], [l0, r0, l1])
+    for name, dst in (("temporal", 2), ("stereo", 1)):
+        for mc in (1, 2, 4, 30):
+            prm = svs.LkParams(3, mc, 0.01, 1e-4, 1)
+            c.lk([(0, dst, pts, pts)] * nj, prm)
+            c.timing_reset() if hasattr(c, "timing_reset") else None
+            c.timing(True)
+            for r in range(5):
+                out = c.lk([(0, dst, pts, pts)] * nj, prm)
+            t = c.timing_get("lk")
+            print("lk %s jobs=%d pts=%d max_count=%2d: %.1f us/launch (%.2f ns/point), ok %.2f" %
+                  (name, nj, len(pts), mc, 1e3 * t[0] / max(t[1], 1), 1e6 * t[0] / max(t[1], 1) / (nj * len(pts)), out[0][1].mean()))
+            c.timing(False)
+    c.close()
+
+
 def clock():
     import ctypes as C
     c = svs.Context(cm.W, cm.H, max_slots=1, max_jobs=1, max_kf=0, max_lm=0, max_obs=0)
@@ -73,6 +95,8 @@ def clock():
 
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what == "lk":
+        lkbench(); sys.exit(0)
     if what in ("clock", "all"):
         clock()
     if what in ("ba", "all"):
