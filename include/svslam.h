@@ -179,6 +179,24 @@ int svslam_local_ba_batch(svslam_ctx *ctx, int njobs, svslam_ba_job *jobs,
                           const float *obs_uv, double huber_delta, int iters,
                           double *edge_chi2);
 
+/* The same call split in two, for a backend that runs beside the frontend the way
+ * the reference's Backend thread does (src/backend.cpp:345-367, BackendLoop woken by
+ * UpdateMap): submit copies the inputs, enqueues the solve on the context's stream
+ * and returns; collect waits for it and writes poses / pts / edge_chi2 /
+ * jobs[i].iters_done.  Between the two the context's staging memory belongs to the
+ * batch: every other batched call on the same context fails until collect (use a
+ * second context for the frontend).  collect takes the same njobs / totals.    */
+int svslam_local_ba_submit(svslam_ctx *ctx, int njobs, const svslam_ba_job *jobs,
+                           const double cam_l[4], const double ext_l[7],
+                           const double cam_r[4], const double ext_r[7],
+                           int total_kf, const double *poses, int total_lm,
+                           const double *pts, int total_obs, const int *obs_kf,
+                           const int *obs_lm, const uint8_t *obs_is_right,
+                           const float *obs_uv, double huber_delta, int iters);
+int svslam_local_ba_collect(svslam_ctx *ctx, int njobs, svslam_ba_job *jobs,
+                            int total_kf, double *poses, int total_lm, double *pts,
+                            int total_obs, double *edge_chi2);
+
 /* test hook: accumulated per-phase ticks (wall_clock64, 100 MHz) of BA job 0;
  * out12[11] = LM trials.  enable=1 allocates the counters, out12 != NULL reads
  * and clears them.                                                            */

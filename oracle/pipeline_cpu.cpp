@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "svs_oracle.h"
@@ -119,7 +120,35 @@ public:
         return 0;
     }
 
+    // the CPU twin has no second device queue: submit solves at once and parks the result
+    void enable_backend_context(const svslam_limits &) {}
+    int local_ba_submit(int n, const svslam_ba_job *jobs, const double *cam_l, const double *ext_l, const double *cam_r,
+                        const double *ext_r, int total_kf, const double *poses, int total_lm, const double *pts,
+                        int total_obs, const int *okf, const int *olm, const uint8_t *oright, const float *ouv,
+                        double delta, int iters)
+    {
+        ba_jobs_.assign(jobs, jobs + n);
+        ba_poses_.assign(poses, poses + 7 * (size_t)total_kf);
+        ba_pts_.assign(pts, pts + 3 * (size_t)total_lm);
+        ba_chi2_.assign((size_t)std::max(total_obs, 1), 0.0);
+        return local_ba(n, ba_jobs_.data(), cam_l, ext_l, cam_r, ext_r, total_kf, ba_poses_.data(), total_lm,
+                        ba_pts_.data(), total_obs, okf, olm, oright, ouv, delta, iters, ba_chi2_.data());
+    }
+    int local_ba_collect(int n, svslam_ba_job *jobs, int total_kf, double *poses, int total_lm, double *pts,
+                         int total_obs, double *chi2)
+    {
+        if ((int)ba_jobs_.size() != n) { err_ = "local_ba_collect: nothing submitted"; return -1; }
+        for (int i = 0; i < n; ++i) jobs[i].iters_done = ba_jobs_[i].iters_done;
+        std::copy(ba_poses_.begin(), ba_poses_.begin() + 7 * (size_t)total_kf, poses);
+        std::copy(ba_pts_.begin(), ba_pts_.begin() + 3 * (size_t)total_lm, pts);
+        std::copy(ba_chi2_.begin(), ba_chi2_.begin() + (size_t)total_obs, chi2);
+        ba_jobs_.clear();
+        return 0;
+    }
+
 private:
+    std::vector<svslam_ba_job> ba_jobs_;
+    std::vector<double> ba_poses_, ba_pts_, ba_chi2_;
     int w_, h_;
     std::vector<std::vector<uint8_t>> slots_;
     int jac_mode_ = 1;
@@ -134,3 +163,4 @@ private:
 #include "../stereovision-slam_amd/host/pipeline_capi_impl.h"
 
 extern "C" void *svs_pipe_kernel_ctx(void *) { return nullptr; }
+extern "C" void *svs_pipe_backend_ctx(void *) { return nullptr; }

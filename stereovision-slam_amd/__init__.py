@@ -20,7 +20,8 @@ ABI_SYMBOLS = [
     "svslam_create", "svslam_destroy", "svslam_last_error", "svslam_build_info",
     "svslam_pyramid_batch", "svslam_pyramid_decimate_batch", "svslam_pyramid_read",
     "svslam_lk_batch", "svslam_gftt_batch", "svslam_gftt_eigmap", "svslam_triangulate_batch",
-    "svslam_pose_only_batch", "svslam_local_ba_batch", "svslam_track_batch",
+    "svslam_pose_only_batch", "svslam_local_ba_batch", "svslam_local_ba_submit", "svslam_local_ba_collect",
+    "svslam_track_batch",
     "svslam_dev_alloc", "svslam_dev_free", "svslam_dev_upload", "svslam_dev_download", "svslam_sync",
     "svslam_timing_enable", "svslam_timing_reset", "svslam_timing_get", "svslam_ba_profile",
     "svslam_set_host_threads", "svslam_debug_host_ns", "svslam_debug_clock_mhz",
@@ -308,9 +309,10 @@ class Context:
         return [(np.array(j.pose[:]), outl[j.pt_ofs:j.pt_ofs + j.npts].copy(), j.n_inlier) for j in arr]
 
     # ---- local BA ------------------------------------------------------------
-    def local_ba(self, jobs, cam_l, ext_l, cam_r, ext_r, huber_delta=5.991, iters=10):
+    def local_ba(self, jobs, cam_l, ext_l, cam_r, ext_r, huber_delta=5.991, iters=10, split=False, between=None):
         """jobs: list of (poses[k,7], pts[m,3], obs_kf, obs_lm, obs_is_right, obs_uv).
-        returns list of (poses, pts, edge_chi2, iters_done)."""
+        returns list of (poses, pts, edge_chi2, iters_done).  split=True goes through
+        svslam_local_ba_submit / _collect (between() runs while the batch is in flight)."""
         n = len(jobs)
         arr = (BaJob * n)()
         P, X, K_, L_, R_, U = [], [], [], [], [], []
@@ -327,9 +329,17 @@ class Context:
         K_ = np.ascontiguousarray(np.concatenate(K_)); L_ = np.ascontiguousarray(np.concatenate(L_))
         R_ = np.ascontiguousarray(np.concatenate(R_)); U = np.ascontiguousarray(np.concatenate(U))
         chi2 = np.zeros(max(oo, 1))
-        self._chk(self.L.svslam_local_ba_batch(self.h, n, arr, _p(_d(cam_l)), _p(_d(ext_l)), _p(_d(cam_r)),
-                                               _p(_d(ext_r)), ko, _p(P), lo, _p(X), oo, _p(K_), _p(L_), _p(R_),
-                                               _p(U), C.c_double(huber_delta), iters, _p(chi2)), "local_ba")
+        if split:
+            self._chk(self.L.svslam_local_ba_submit(self.h, n, arr, _p(_d(cam_l)), _p(_d(ext_l)), _p(_d(cam_r)),
+                                                    _p(_d(ext_r)), ko, _p(P), lo, _p(X), oo, _p(K_), _p(L_), _p(R_),
+                                                    _p(U), C.c_double(huber_delta), iters), "local_ba_submit")
+            if between is not None:
+                between()
+            self._chk(self.L.svslam_local_ba_collect(self.h, n, arr, ko, _p(P), lo, _p(X), oo, _p(chi2)), "local_ba_collect")
+        else:
+            self._chk(self.L.svslam_local_ba_batch(self.h, n, arr, _p(_d(cam_l)), _p(_d(ext_l)), _p(_d(cam_r)),
+                                                   _p(_d(ext_r)), ko, _p(P), lo, _p(X), oo, _p(K_), _p(L_), _p(R_),
+                                                   _p(U), C.c_double(huber_delta), iters, _p(chi2)), "local_ba")
         out = []
         for j in arr:
             out.append((P[j.kf_ofs:j.kf_ofs + j.nkf].copy(), X[j.lm_ofs:j.lm_ofs + j.nlm].copy(),

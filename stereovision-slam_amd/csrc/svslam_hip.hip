@@ -74,6 +74,9 @@ struct svslam_ctx {
     // host-side wall time (ns): 0 h2d enqueue, 1 d2h enqueue, 2 stream wait, 3 launches, 4 staging memcpy/prep
     long long host_ns[8] = { 0 };
     bool wait_poll = true;
+    // a submitted, not yet collected local-BA batch owns the staging arena
+    struct { bool active = false; int njobs = 0, total_kf = 0, total_lm = 0, total_obs = 0;
+             size_t ojobs = 0, oposes = 0, opts = 0, ochi = 0; } ba_pending;
     // timing
     bool timing = false;
     Timing tm;
@@ -179,18 +182,27 @@ int h2d(svslam_ctx *c, size_t from, size_t to)
     c->host_ns[0] += now_ns() - t0;
     return 0;
 }
-int d2h_sync(svslam_ctx *c, size_t from, size_t to)
+int d2h_enqueue(svslam_ctx *c, size_t from, size_t to)
 {
-    long long t0 = now_ns();
+    const long long t0 = now_ns();
     if (to > from) HIPCHK(c, hipMemcpyAsync(c->ar.h + from, c->ar.d + from, to - from, hipMemcpyDeviceToHost, c->stream));
-    long long t1 = now_ns();
-    c->host_ns[1] += t1 - t0;
+    c->host_ns[1] += now_ns() - t0;
+    return 0;
+}
+int finish(svslam_ctx *c)
+{
+    const long long t1 = now_ns();
     HIPCHK(c, wait_stream(c));
-    t0 = now_ns();
+    const long long t0 = now_ns();
     c->host_ns[2] += t0 - t1;
     tm_collect(c);
     c->host_ns[5] += now_ns() - t0;
     return 0;
+}
+int d2h_sync(svslam_ctx *c, size_t from, size_t to)
+{
+    if (d2h_enqueue(c, from, to)) return -1;
+    return finish(c);
 }
 
 template <typename T> T *hp(svslam_ctx *c, size_t off) { return reinterpret_cast<T *>(c->ar.h + off); }
@@ -242,6 +254,7 @@ int pyramid_common(svslam_ctx *c, int n, const int *slots, const void *const *im
     if (n > c->lim.max_jobs) return fail(c, "pyramid: %d jobs > max_jobs %d", n, c->lim.max_jobs);
     for (int i = 0; i < n; ++i) if (check_slot(c, slots[i])) return -1;
     const int iw = decimate ? src_w : c->geom.w[0], ih = decimate ? src_h : c->geom.h[0];
+    if (c->ba_pending.active) return fail(c, "a submitted local-BA batch owns this context: call svslam_local_ba_collect first");
     c->ar.reset();
     size_t ojobs = c->ar.take(sizeof(PyrJob) * n);
     PyrJob *hj = hp<PyrJob>(c, ojobs);
@@ -463,6 +476,7 @@ int svslam_lk_batch(svslam_ctx *c, int njobs, const svslam_lk_job *jobs, int tot
             return fail(c, "lk: job %d point range out of bounds", i);
         maxn = std::max(maxn, jobs[i].npts);
     }
+    if (c->ba_pending.active) return fail(c, "a submitted local-BA batch owns this context: call svslam_local_ba_collect first");
     c->ar.reset();
     size_t ojobs = c->ar.take(sizeof(LkJob) * njobs);
     size_t oprev = c->ar.take(sizeof(float) * 2 * total_pts);
@@ -526,6 +540,7 @@ int svslam_gftt_batch(svslam_ctx *c, int njobs, const svslam_gftt_job *jobs, int
             return fail(c, "gftt: job %d rect range out of bounds", i);
         max_nrect = std::max(max_nrect, jobs[i].nrect);
     }
+    if (c->ba_pending.active) return fail(c, "a submitted local-BA batch owns this context: call svslam_local_ba_collect first");
     c->ar.reset();
     size_t ojobs = c->ar.take(sizeof(GfttJob) * njobs);
     size_t orect = c->ar.take(sizeof(float) * 2 * std::max(total_rects, 1));
@@ -547,6 +562,7 @@ int svslam_gftt_batch(svslam_ctx *c, int njobs, const svslam_gftt_job *jobs, int
 int svslam_gftt_eigmap(svslam_ctx *c, int slot, float *out)
 {
     if (check_slot(c, slot)) return -1;
+    if (c->ba_pending.active) return fail(c, "a submitted local-BA batch owns this context: call svslam_local_ba_collect first");
     c->ar.reset();
     size_t ojobs = c->ar.take(sizeof(GfttJob));
     GfttJob *j = hp<GfttJob>(c, ojobs);
@@ -577,6 +593,7 @@ int svslam_triangulate_batch(svslam_ctx *c, int njobs, const svslam_tri_job *job
             return fail(c, "triangulate: job %d point range out of bounds", i);
         maxn = std::max(maxn, jobs[i].npts);
     }
+    if (c->ba_pending.active) return fail(c, "a submitted local-BA batch owns this context: call svslam_local_ba_collect first");
     c->ar.reset();
     static_assert(sizeof(TriJob) == sizeof(svslam_tri_job), "job layout");
     size_t ojobs = c->ar.take(sizeof(TriJob) * njobs);
@@ -618,6 +635,7 @@ int svslam_pose_only_batch(svslam_ctx *c, int njobs, svslam_pose_job *jobs, int 
             jobs[i].pt_ofs + jobs[i].npts > total_pts)
             return fail(c, "pose_only: job %d point range out of bounds", i);
     }
+    if (c->ba_pending.active) return fail(c, "a submitted local-BA batch owns this context: call svslam_local_ba_collect first");
     c->ar.reset();
     static_assert(sizeof(PoseJob) == sizeof(svslam_pose_job), "job layout");
     size_t ocam = c->ar.take(32);
@@ -646,11 +664,11 @@ int svslam_pose_only_batch(svslam_ctx *c, int njobs, svslam_pose_job *jobs, int 
 }
 
 // ------------------------------------------------------------------ local BA
-int svslam_local_ba_batch(svslam_ctx *c, int njobs, svslam_ba_job *jobs, const double cam_l[4],
-                          const double ext_l[7], const double cam_r[4], const double ext_r[7],
-                          int total_kf, double *poses, int total_lm, double *pts, int total_obs,
-                          const int *obs_kf, const int *obs_lm, const uint8_t *obs_is_right,
-                          const float *obs_uv, double huber_delta, int iters, double *edge_chi2)
+int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, const double cam_l[4],
+                           const double ext_l[7], const double cam_r[4], const double ext_r[7],
+                           int total_kf, const double *poses, int total_lm, const double *pts, int total_obs,
+                           const int *obs_kf, const int *obs_lm, const uint8_t *obs_is_right,
+                           const float *obs_uv, double huber_delta, int iters)
 {
     if (njobs <= 0) return 0;
     if (njobs > c->lim.max_jobs) return fail(c, "local_ba: %d jobs > max_jobs", njobs);
@@ -663,6 +681,7 @@ int svslam_local_ba_batch(svslam_ctx *c, int njobs, svslam_ba_job *jobs, const d
                         c->lim.max_kf, j.nlm, c->lim.max_lm, j.nobs, c->lim.max_obs);
     }
     const long long t_prep0 = now_ns();
+    if (c->ba_pending.active) return fail(c, "a submitted local-BA batch owns this context: call svslam_local_ba_collect first");
     c->ar.reset();
     static_assert(sizeof(BaJob) == sizeof(svslam_ba_job), "job layout");
     // host-side structure of every problem (edge / block / pose-pair lists)
@@ -742,12 +761,41 @@ int svslam_local_ba_batch(svslam_ctx *c, int njobs, svslam_ba_job *jobs, const d
                        dp<int>(c, oaux), c->bw, huber_delta, iters, dp<double>(c, ochi), c->d_ba_prof);
     tm_end(c);
     HIPCHK(c, hipGetLastError());
-    if (d2h_sync(c, ojobs, c->ar.off)) return -1;
-    for (int i = 0; i < njobs; ++i) jobs[i].iters_done = dj[i].iters_done;
-    if (total_kf > 0) memcpy(poses, hp<void>(c, oposes), sizeof(double) * 7 * total_kf);
-    if (total_lm > 0) memcpy(pts, hp<void>(c, opts), sizeof(double) * 3 * total_lm);
-    if (total_obs > 0) memcpy(edge_chi2, hp<void>(c, ochi), sizeof(double) * total_obs);
+    if (d2h_enqueue(c, ojobs, c->ar.off)) return -1;
+    c->ba_pending.active = true; c->ba_pending.njobs = njobs;
+    c->ba_pending.total_kf = total_kf; c->ba_pending.total_lm = total_lm; c->ba_pending.total_obs = total_obs;
+    c->ba_pending.ojobs = ojobs; c->ba_pending.oposes = oposes; c->ba_pending.opts = opts; c->ba_pending.ochi = ochi;
     return 0;
+}
+
+int svslam_local_ba_collect(svslam_ctx *c, int njobs, svslam_ba_job *jobs, int total_kf, double *poses,
+                            int total_lm, double *pts, int total_obs, double *edge_chi2)
+{
+    if (!c->ba_pending.active) return njobs <= 0 ? 0 : fail(c, "local_ba_collect: nothing submitted");
+    if (njobs != c->ba_pending.njobs || total_kf != c->ba_pending.total_kf || total_lm != c->ba_pending.total_lm ||
+        total_obs != c->ba_pending.total_obs)
+        return fail(c, "local_ba_collect: sizes differ from the submitted batch");
+    c->ba_pending.active = false;
+    if (finish(c)) return -1;
+    const BaDev *dj = hp<BaDev>(c, c->ba_pending.ojobs);
+    for (int i = 0; i < njobs; ++i) jobs[i].iters_done = dj[i].iters_done;
+    if (total_kf > 0) memcpy(poses, hp<void>(c, c->ba_pending.oposes), sizeof(double) * 7 * total_kf);
+    if (total_lm > 0) memcpy(pts, hp<void>(c, c->ba_pending.opts), sizeof(double) * 3 * total_lm);
+    if (total_obs > 0) memcpy(edge_chi2, hp<void>(c, c->ba_pending.ochi), sizeof(double) * total_obs);
+    return 0;
+}
+
+int svslam_local_ba_batch(svslam_ctx *c, int njobs, svslam_ba_job *jobs, const double cam_l[4],
+                          const double ext_l[7], const double cam_r[4], const double ext_r[7],
+                          int total_kf, double *poses, int total_lm, double *pts, int total_obs,
+                          const int *obs_kf, const int *obs_lm, const uint8_t *obs_is_right,
+                          const float *obs_uv, double huber_delta, int iters, double *edge_chi2)
+{
+    if (njobs <= 0) return 0;
+    if (int rc = svslam_local_ba_submit(c, njobs, jobs, cam_l, ext_l, cam_r, ext_r, total_kf, poses, total_lm, pts,
+                                        total_obs, obs_kf, obs_lm, obs_is_right, obs_uv, huber_delta, iters))
+        return rc;
+    return svslam_local_ba_collect(c, njobs, jobs, total_kf, poses, total_lm, pts, total_obs, edge_chi2);
 }
 
 // number of host threads the library may use to prepare batched calls (BA structure

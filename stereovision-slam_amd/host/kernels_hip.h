@@ -19,13 +19,34 @@ public:
             throw std::runtime_error("svslam_create failed: " + msg);
         }
     }
-    ~HipKernels() { if (ctx_) svslam_destroy(ctx_); }
+    ~HipKernels() { if (ba_ctx_) svslam_destroy(ba_ctx_); if (ctx_) svslam_destroy(ctx_); }
+
+    // A second context (own HIP stream + staging memory) for the backend, so a submitted
+    // local-BA batch runs beside the frontend's calls the way the reference's Backend
+    // thread runs beside Frontend (src/backend.cpp:345-367).
+    void enable_backend_context(const svslam_limits &frontend_lim)
+    {
+        if (ba_ctx_) return;
+        svslam_limits l = frontend_lim;
+        l.max_slots = 1; l.max_pts = 8; l.max_corners = 8;
+        if (svslam_create(&l, &ba_ctx_) != 0) {
+            std::string msg = ba_ctx_ ? svslam_last_error(ba_ctx_) : "svslam_create";
+            if (ba_ctx_) svslam_destroy(ba_ctx_);
+            ba_ctx_ = nullptr;
+            throw std::runtime_error("backend context: " + msg);
+        }
+    }
     HipKernels(const HipKernels &) = delete;
     HipKernels &operator=(const HipKernels &) = delete;
 
     svslam_ctx *ctx() { return ctx_; }
-    void set_host_threads(int n) { svslam_set_host_threads(ctx_, n); }
-    const char *last_error() { return svslam_last_error(ctx_); }
+    void set_host_threads(int n) { svslam_set_host_threads(ctx_, n); if (ba_ctx_) svslam_set_host_threads(ba_ctx_, n); }
+    const char *last_error()
+    {
+        if (ba_ctx_ && ba_failed_) return svslam_last_error(ba_ctx_);
+        return svslam_last_error(ctx_);
+    }
+    svslam_ctx *backend_ctx() { return ba_ctx_ ? ba_ctx_ : ctx_; }
 
     int pyramid(int n, const int *slots, const void *const *imgs, const int *strides, int is_device)
     { return svslam_pyramid_batch(ctx_, n, slots, imgs, strides, is_device); }
@@ -49,8 +70,27 @@ public:
                  int iters, double *chi2)
     { return svslam_local_ba_batch(ctx_, n, jobs, cam_l, ext_l, cam_r, ext_r, total_kf, poses, total_lm, pts, total_obs, okf, olm, oright, ouv, delta, iters, chi2); }
 
+    int local_ba_submit(int n, const svslam_ba_job *jobs, const double *cam_l, const double *ext_l, const double *cam_r,
+                        const double *ext_r, int total_kf, const double *poses, int total_lm, const double *pts,
+                        int total_obs, const int *okf, const int *olm, const uint8_t *oright, const float *ouv,
+                        double delta, int iters)
+    {
+        int rc = svslam_local_ba_submit(backend_ctx(), n, jobs, cam_l, ext_l, cam_r, ext_r, total_kf, poses, total_lm, pts, total_obs, okf, olm, oright, ouv, delta, iters);
+        ba_failed_ = rc != 0;
+        return rc;
+    }
+    int local_ba_collect(int n, svslam_ba_job *jobs, int total_kf, double *poses, int total_lm, double *pts,
+                         int total_obs, double *chi2)
+    {
+        int rc = svslam_local_ba_collect(backend_ctx(), n, jobs, total_kf, poses, total_lm, pts, total_obs, chi2);
+        ba_failed_ = rc != 0;
+        return rc;
+    }
+
 private:
     svslam_ctx *ctx_ = nullptr;
+    svslam_ctx *ba_ctx_ = nullptr;
+    bool ba_failed_ = false;
 };
 
 } // namespace svs

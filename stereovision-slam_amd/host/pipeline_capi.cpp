@@ -7,3 +7,4 @@
 #include "pipeline_capi_impl.h"
 
 extern "C" void *svs_pipe_kernel_ctx(void *p) { return static_cast<PipeHandle *>(p)->kernels->ctx(); }
+extern "C" void *svs_pipe_backend_ctx(void *p) { return static_cast<PipeHandle *>(p)->kernels->backend_ctx(); }

@@ -11,7 +11,8 @@ typedef struct svs_pipe_config {
     int num_features, num_features_init, num_features_tracking, num_features_tracking_bad;
     int num_features_needed_for_keyframe;
     double max_triangulation_depth;
-    int num_active_keyframes, backend_on;
+    int num_active_keyframes, backend_on;   /* backend_on: 0 off, 1 BA completes before the next frame,
+                                               2 BA runs beside the next frame, result lands one frame late */
     double chi2_th;
     int width, height;
     double cam_l[4], ext_l[7], cam_r[4], ext_r[7];
@@ -34,6 +35,8 @@ typedef struct svs_pipe_counters {
 void *svs_pipe_create(const svs_pipe_config *cfg, int nstreams, int device);
 void svs_pipe_destroy(void *p);
 const char *svs_pipe_last_error(void);
+/* completes a backend optimisation still in flight (backend_on 2) */
+int svs_pipe_flush(void *p);
 /* one frame for every stream; left/right: nstreams image pointers (host or device) */
 int svs_pipe_step(void *p, const void *const *left, const void *const *right, int is_device,
                   svs_frame_result *out);
@@ -46,6 +49,8 @@ int svs_pipe_counters_get(void *p, svs_pipe_counters *out);
 int svs_pipe_save_outputs(void *p, int stream, const char *dir, const char *dataset_dir, int left_cam_index);
 /* underlying svslam_ctx (product build) or NULL (CPU twin) */
 void *svs_pipe_kernel_ctx(void *p);
+/* context the backend's local BA runs on: a second one when backend_on == 2, else the same */
+void *svs_pipe_backend_ctx(void *p);
 
 #ifdef __cplusplus
 }

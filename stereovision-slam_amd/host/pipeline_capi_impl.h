@@ -48,7 +48,14 @@ void *svs_pipe_create(const svs_pipe_config *cfg, int nstreams, int device)
         lim.max_slots = 3 * nstreams; lim.max_jobs = 2 * nstreams; // one call may build left+right pyramids
         lim.max_pts = 512; lim.max_corners = cfg->num_features;
         lim.max_kf = cfg->num_active_keyframes + 1; lim.max_lm = cfg->max_lm; lim.max_obs = cfg->max_obs;
-        h->kernels.reset(SVS_PIPE_MAKE_KERNELS(lim));
+        svslam_limits lim_front = lim;
+        if (cfg->backend_on >= 2) { lim_front.max_kf = 0; lim_front.max_lm = 0; lim_front.max_obs = 0; }   // BA lives in its own context
+        h->kernels.reset(SVS_PIPE_MAKE_KERNELS(lim_front));
+        if (cfg->backend_on >= 2) {
+            svslam_limits lim_ba = lim;
+            lim_ba.max_jobs = nstreams;
+            h->kernels->enable_backend_context(lim_ba);
+        }
         h->kernels->set_host_threads(cfg->host_threads > 0 ? cfg->host_threads : 1);
         h->pipe.reset(new svs::Pipeline<SVS_PIPE_KERNELS>(to_config(*cfg), *h->kernels, nstreams,
                                                              cfg->host_threads > 0 ? cfg->host_threads : 1));
@@ -109,10 +116,22 @@ int svs_pipe_run_device(void *p, const void *left_base, const void *right_base, 
     }
 }
 
+int svs_pipe_flush(void *p)
+{
+    try {
+        static_cast<PipeHandle *>(p)->pipe->Flush();
+        return 0;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
 int svs_pipe_save_outputs(void *p, int stream, const char *dir, const char *dataset_dir, int left_cam_index)
 {
     PipeHandle *h = static_cast<PipeHandle *>(p);
     if (stream < 0 || stream >= h->pipe->nstreams()) return -1;
+    if (svs_pipe_flush(p)) return -3;
     return h->pipe->SaveOutputs(stream, dir, dataset_dir, left_cam_index) ? 0 : -2;
 }
 

@@ -295,11 +295,11 @@ public:
         }
         std::vector<int> DS = IS;                 // streams that detect this frame
         DS.insert(DS.end(), KS.begin(), KS.end());
+        std::vector<int> MS;                      // streams that triangulate + BA
         if (!DS.empty()) {
             BuildPyramids(IS, DS, left, right, strides, is_device);
             DetectFeatures(DS);
             FindFeaturesInRight(DS);
-            std::vector<int> MS;                  // streams that triangulate + BA
             for (int s : IS) {
                 Stream &st = *streams_[s];
                 int good = 0;
@@ -307,10 +307,18 @@ public:
                 if (good >= cfg_.num_features_init) { st.init_ok = true; MS.push_back(s); }   // :227
             }
             MS.insert(MS.end(), KS.begin(), KS.end());
-            if (!MS.empty()) {
-                Triangulate(MS);
-                if (cfg_.backend_on) RunBackend(MS);
-            }
+            if (!MS.empty()) Triangulate(MS);
+        }
+        // Backend::UpdateMap (src/frontend.cpp:281 / src/backend.cpp:14-18).  backend_on 1: the
+        // optimisation completes before the next frame (deterministic stand-in for "the backend
+        // thread was fast").  backend_on 2: it runs beside the next frame's Track() like the
+        // reference's Backend thread, and its result lands after that frame — always exactly one
+        // frame late, so runs stay reproducible.
+        if (cfg_.backend_on == 1) {
+            if (!MS.empty()) { BackendSubmit(MS); BackendCollect(); }
+        } else if (cfg_.backend_on >= 2) {
+            BackendCollect();
+            if (!MS.empty()) BackendSubmit(MS);
         }
         long long t_e = now_ns();
         for (int s : TS) {
@@ -683,10 +691,11 @@ private:
         st_[5] += now_ns() - t_h5;
     }
 
-    // Backend::UpdateMap -> Optimize, synchronously (src/backend.cpp:9-248)
-    void RunBackend(const std::vector<int> &MS)
+    // Backend::UpdateMap -> Optimize (src/backend.cpp:9-248): gather + enqueue ...
+    void BackendSubmit(const std::vector<int> &MS)
     {
         long long t_h6 = now_ns();
+        ba_ms_ = MS;
         const int n = (int)MS.size();
         jobs_ba_.resize(n);
         // gather per stream (:39-160), in parallel, into the stream's own buffers
@@ -746,10 +755,23 @@ private:
             }
         });
         st_[6] += now_ns() - t_h6;
-        { KTimer kt_(cnt_); check(k_.local_ba(n, jobs_ba_.data(), cam_l_, cfg_.cam_l.pose.v, cam_r_, cfg_.cam_r.pose.v, ko,
+        { KTimer kt_(cnt_); check(k_.local_ba_submit(n, jobs_ba_.data(), cam_l_, cfg_.cam_l.pose.v, cam_r_, cfg_.cam_r.pose.v, ko,
                           ba_poses_.data(), lo, ba_pts_.data(), oo, ba_okf_.data(), ba_olm_.data(), ba_right_.data(),
-                          ba_uv_.data(), cfg_.chi2_th, 10, ba_chi2_.data()), "local_ba"); }   // :150-164
-        t_h6 = now_ns();
+                          ba_uv_.data(), cfg_.chi2_th, 10), "local_ba_submit"); }   // :150-164
+        ba_ko_ = ko; ba_lo_ = lo; ba_oo_ = oo;
+        ba_inflight_ = true;
+    }
+
+    // ... wait for the solve and write it back to the map (src/backend.cpp:167-246)
+    void BackendCollect()
+    {
+        if (!ba_inflight_) return;
+        ba_inflight_ = false;
+        const std::vector<int> &MS = ba_ms_;
+        const int n = (int)MS.size();
+        { KTimer kt_(cnt_); check(k_.local_ba_collect(n, jobs_ba_.data(), ba_ko_, ba_poses_.data(), ba_lo_, ba_pts_.data(),
+                          ba_oo_, ba_chi2_.data()), "local_ba_collect"); }
+        long long t_h6 = now_ns();
         for (int i = 0; i < n; ++i) {
             const svslam_ba_job &j = jobs_ba_[i];
             cnt_.ba_calls++; cnt_.ba_edges += j.nobs; cnt_.ba_kf += j.nkf; cnt_.ba_lm += j.nlm;
@@ -793,6 +815,13 @@ private:
         st_[7] += now_ns() - t_h6;
     }
 
+public:
+    // completes a backend optimisation that is still in flight (backend_on 2)
+    void Flush() { BackendCollect(); }
+private:
+    std::vector<int> ba_ms_;
+    bool ba_inflight_ = false;
+    int ba_ko_ = 0, ba_lo_ = 0, ba_oo_ = 0;
     long long st_[12] = { 0 };   // 0 begin 1 track-prep 2 track-finish 3 detect 4 right 5 tri 6 ba-gather 7 ba-scatter 8 end
     Config cfg_;
     K &k_;

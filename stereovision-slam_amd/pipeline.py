@@ -85,6 +85,9 @@ def _bind(L):
                                       C.c_int, C.c_void_p]
     L.svs_pipe_counters_get.argtypes = [C.c_void_p, C.POINTER(Counters)]
     L.svs_pipe_save_outputs.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int]
+    L.svs_pipe_flush.argtypes = [C.c_void_p]
+    L.svs_pipe_backend_ctx.restype = C.c_void_p
+    L.svs_pipe_backend_ctx.argtypes = [C.c_void_p]
     L.svs_pipe_kernel_ctx.restype = C.c_void_p
     L.svs_pipe_kernel_ctx.argtypes = [C.c_void_p]
     return L
@@ -148,6 +151,11 @@ class Pipeline:
             raise RuntimeError("svs_pipe_run_device failed: " + self.L.svs_pipe_last_error().decode())
         return out
 
+    def flush(self):
+        """complete a backend optimisation that is still in flight (backend_on == 2)"""
+        if self.L.svs_pipe_flush(self.h) != 0:
+            raise RuntimeError("svs_pipe_flush failed: " + self.L.svs_pipe_last_error().decode())
+
     def counters(self):
         c = Counters()
         self.L.svs_pipe_counters_get(self.h, C.byref(c))
@@ -161,6 +169,9 @@ class Pipeline:
 
     def kernel_ctx(self):
         return self.L.svs_pipe_kernel_ctx(self.h)
+
+    def backend_ctx(self):
+        return self.L.svs_pipe_backend_ctx(self.h)
 
 
 # ---- trajectory error (the reference has no evaluator) -----------------
