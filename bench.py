@@ -228,7 +228,13 @@ def main():
                                                    "runs beside the next frame like the reference's backend thread, "
                                                    "lands one frame late, all of it inside the timed region"),
                        "streams_per_gpu": S, "host_threads_per_gpu": G, "bookkeeping_threads_per_group": args.host_threads, "frame": "%dx%d u8 stereo pair" % (W, H),
-                       "keyframes_in_timed_region": cnt["keyframes"], "tracked_ok_fraction": ok_frames / (S * K),
+                       "keyframes_in_timed_region": cnt["keyframes"],
+                       "ba_problem_mean": {"keyframes": round(cnt["ba_kf"] / max(cnt["ba_calls"], 1), 1),
+                                           "landmarks": round(cnt["ba_lm"] / max(cnt["ba_calls"], 1), 1),
+                                           "edges": round(cnt["ba_edges"] / max(cnt["ba_calls"], 1), 1),
+                                           "lm_iterations": round(cnt["ba_iters"] / max(cnt["ba_calls"], 1), 2)},
+                       "per_frame_mean": {"tracked_points": round(cnt["track_pts"] / max(cnt["frames"], 1), 1),
+                                          "pose_edges": round(cnt["pose_edges"] / max(cnt["frames"], 1), 1)}, "tracked_ok_fraction": ok_frames / (S * K),
                        "parallelism": "%d independent streams/GPU x %d GPU(s), no collective" % (S, world)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),

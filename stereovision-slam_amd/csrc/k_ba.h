@@ -1,5 +1,5 @@
 // k_ba.h — local bundle adjustment: Levenberg-Marquardt with Schur complement,
-// one persistent 1024-thread workgroup per problem, no host round trip per
+// one persistent 512-thread workgroup per problem, no host round trip per
 // iteration.  Replaces optimizer.initializeOptimization(); optimizer.optimize(10)
 // of Backend::Optimize (reference src/backend.cpp:22-164): g2o BlockSolver_6_3 +
 // LinearSolverDense + OptimizationAlgorithmLevenberg, VertexXYZ marginalised,
@@ -8,16 +8,24 @@
 // lets g2o differentiate numerically; see DESIGN.md for the tolerance).
 //
 // Data flow per LM iteration (every sum has a fixed order -> deterministic):
-//   edge pass      e, rho', Jp(2x6), Jl(2x3) per edge               thread / edge
-//   landmark pass  Hll_j, bl_j, W_kj = sum w Jp^T Jl                thread / landmark
-//   pose pass      Hpp_k, bp_k (kept in LDS)                        wave / pose
+//   landmark pass  thread / landmark walks its edge records (sorted landmark-major by the
+//                  host): residual, rho', Jp(2x6), Jl(2x3) on the fly -> Hll_j, bl_j and
+//                  the 6x3 blocks W_kj = sum w Jp^T Jl.  Jacobians are never stored.
+//   pose pass      16-lane rows over the pose-major edge records recompute Jp ->
+//                  Hpp_k, bp_k (kept in LDS)
 //   per LM trial:
-//     Dinv_j, db_j, Y_kj = W_kj Dinv_j                              thread / block
-//     S_ab = Hpp + lambda I - sum_j Y_aj W_bj^T  (S lives in LDS)   16-lane row /
-//       the (Y,W) block pairs of every pose pair are listed by the  (pose pair, half)
-//       host once per call, so the assembly is a gather with DPP row reductions
+//     Dinv_j, db_j                                                  thread / landmark
+//     S_ab = Hpp + lambda I - sum_j (W_aj Dinv_j) W_bj^T (S in LDS) 16-lane row / pose pair
+//       the block pairs of every pose pair are listed by the host once per call; Y = W Dinv
+//       is formed in registers, never stored
 //     Cholesky + triangular solves of the 6K x 6K system in LDS     one wave
-//     back-substitution, update, new errors, rho test
+//     back-substitution, update, new errors (landmark-major records), rho test
+// Rotations / translations of the active poses and both cameras live in an LDS table that
+// is rebuilt whenever the state changes, so a projection costs no global gather.
+// Why this shape: the kernel is bound by L1/TA transactions (one per lane for every
+// 16-byte access to an array-of-blocks: PMC TCP_TOTAL_CACHE_ACCESSES ~ 37 per VMEM
+// instruction in the previous version, which stored Jp/Jl/Y), not by f64 arithmetic, so
+// recomputing a Jacobian (~70 FMA) is cheaper than one round trip of its 18 doubles.
 // The reduced camera system is 60x60 f64 at K=10: MFMA does not apply.
 #pragma once
 #include "dev_common.h"
@@ -27,6 +35,9 @@
 
 #ifndef BA_THREADS
 #define BA_THREADS 512
+#ifndef BA_MIN_WAVES_PER_SIMD
+#define BA_MIN_WAVES_PER_SIMD 2
+#endif
 #endif
 #define BA_WAVES (BA_THREADS / 64)
 #define BA_ROWS (BA_THREADS / 16)
@@ -35,23 +46,23 @@
 struct BaJob { int kf_ofs, nkf, lm_ofs, nlm, obs_ofs, nobs, iters_done, reserved; };
 struct BaCams { double cam[2][4]; double ext[2][7]; };
 
+// edge record, 16 bytes: measurement, landmark | (active pose << 1 | camera) << 24, block id
+struct BaRec { float u, v; int lmkc; int blk; };
+#define BA_LM_MASK 0x00ffffff
+
 struct BaDev {               // device-side job descriptor (built on the host)
     int kf_ofs, nkf, lm_ofs, nlm, obs_ofs, nobs;
     int nblk, na;            // unique (kf,lm) blocks, active poses
     int ncontrib;            // (Y,W) block pairs
     int aux_ofs;             // offset into the int aux buffer
     int iters_done;
-    int pad;
+    int rec_ofs;             // offset (records) of this job's 2*nobs records: landmark-major, then pose-major
 };
 
 struct BaWork {              // per-job HBM scratch, strided by the context limits
     int max_kf = 0, max_lm = 0, max_obs = 0;
-    double *err = nullptr;   // [2*max_obs]
-    double *Jp = nullptr;    // [12*max_obs]
-    double *Jl = nullptr;    // [6*max_obs]
-    double *wgt = nullptr;   // [max_obs]
+    double *err = nullptr;   // [2*max_obs]  residuals of the last evaluation, landmark-major edge order
     double *W = nullptr;     // [18*max_obs]
-    double *Y = nullptr;     // [18*max_obs]
     double *Hll = nullptr;   // [9*max_lm]
     double *Dinv = nullptr;  // [9*max_lm]
     double *bl = nullptr;    // [3*max_lm]
@@ -66,17 +77,13 @@ static inline hipError_t ba_work_alloc(BaWork &w, int jobs, int max_kf, int max_
     w.max_kf = max_kf; w.max_lm = max_lm; w.max_obs = max_obs;
     if (max_kf <= 0 || max_lm <= 0 || max_obs <= 0) return hipSuccess;
     size_t J = jobs;
-    size_t nd = J * ((size_t)max_obs * (2 + 12 + 6 + 1 + 18 + 18) + (size_t)max_kf * 7 +
+    size_t nd = J * ((size_t)max_obs * (2 + 18) + (size_t)max_kf * 7 +
                      (size_t)max_lm * (9 + 9 + 3 + 3 + 3));
     hipError_t e = hipMalloc(&w.all, nd * sizeof(double));
     if (e != hipSuccess) return e;
     double *p = static_cast<double *>(w.all);
     w.err = p; p += J * 2 * max_obs;
-    w.Jp = p; p += J * 12 * max_obs;
-    w.Jl = p; p += J * 6 * max_obs;
-    w.wgt = p; p += J * max_obs;
     w.W = p; p += J * 18 * max_obs;
-    w.Y = p; p += J * 18 * max_obs;
     w.poses_b = p; p += J * 7 * max_kf;
     w.Hll = p; p += J * 9 * max_lm;
     w.Dinv = p; p += J * 9 * max_lm;
@@ -91,10 +98,10 @@ static inline void ba_work_free(BaWork &w) { if (w.all) (void)hipFree(w.all); w.
 // aux layout per job (ints), offsets from ba_aux_layout():
 //   lm_estart[nlm+1] lm_edges[nobs] kf_estart[nkf+1] kf_edges[nobs] eblk[nobs]
 //   lm_bstart[nlm+1] blk_kf[nblk] blk_lm[nblk] kf_pidx[nkf] act_kf[nkf]
-//   pc_start[npairs+1] pc_y[ncontrib] pc_w[ncontrib] pb_start[na+1] pb_blk[nblk]
+//   pc_start[npairs+1] pc_y[ncontrib] pc_w[ncontrib] pc_lm[ncontrib] pb_start[na+1] pb_blk[nblk]
 struct BaAuxLayout {
     size_t lm_estart, lm_edges, kf_estart, kf_edges, eblk, lm_bstart, blk_kf, blk_lm, kf_pidx, act_kf;
-    size_t pc_start, pc_y, pc_w, pb_start, pb_blk, total;
+    size_t pc_start, pc_y, pc_w, pc_lm, pb_start, pb_blk, total;
 };
 __host__ __device__ inline BaAuxLayout ba_aux_layout(int nkf, int nlm, int nobs, int nblk, int na, int ncontrib)
 {
@@ -113,6 +120,7 @@ __host__ __device__ inline BaAuxLayout ba_aux_layout(int nkf, int nlm, int nobs,
     L.pc_start = o; o += (size_t)na * (na + 1) / 2 + 1;
     L.pc_y = o; o += ncontrib;
     L.pc_w = o; o += ncontrib;
+    L.pc_lm = o; o += ncontrib;
     L.pb_start = o; o += (size_t)na + 1;
     L.pb_blk = o; o += nblk;
     L.total = o;
@@ -123,10 +131,11 @@ __host__ __device__ inline int ba_pair_index(int a, int b, int na) { return a * 
 
 struct BaHostStruct {        // scratch reused across jobs
     std::vector<int> order, lm_estart, lm_edges, kf_estart, kf_edges, eblk, lm_bstart, blk_kf, blk_lm, kf_pidx,
-        act_kf, pc_start, pc_y, pc_w, pb_start, pb_blk, fill;
+        act_kf, pc_start, pc_y, pc_w, pc_lm, pb_start, pb_blk, fill;
+    std::vector<BaRec> recs;     // [0,nobs) landmark-major (= lm_edges order), [nobs,2nobs) pose-major
     int nblk = 0, na = 0, ncontrib = 0;
 
-    void build(const BaJob &j, const int *obs_kf, const int *obs_lm)
+    void build(const BaJob &j, const int *obs_kf, const int *obs_lm, const uint8_t *obs_right, const float *obs_uv)
     {
         const int nkf = j.nkf, nlm = j.nlm, nobs = j.nobs;
         const int *okf = obs_kf + j.obs_ofs, *olm = obs_lm + j.obs_ofs;
@@ -180,13 +189,13 @@ struct BaHostStruct {        // scratch reused across jobs
                     pc_start[ba_pair_index(kf_pidx[blk_kf[u]], kf_pidx[blk_kf[v]], na) + 1]++;
         for (int p = 0; p < npairs; ++p) pc_start[p + 1] += pc_start[p];
         ncontrib = pc_start[npairs];
-        pc_y.resize(ncontrib); pc_w.resize(ncontrib);
+        pc_y.resize(ncontrib); pc_w.resize(ncontrib); pc_lm.resize(ncontrib);
         fill.assign(pc_start.begin(), pc_start.begin() + npairs);
         for (int l = 0; l < nlm; ++l)
             for (int u = lm_bstart[l]; u < lm_bstart[l + 1]; ++u)
                 for (int v = u; v < lm_bstart[l + 1]; ++v) {
                     int p = ba_pair_index(kf_pidx[blk_kf[u]], kf_pidx[blk_kf[v]], na);
-                    pc_y[fill[p]] = u; pc_w[fill[p]] = v; fill[p]++;
+                    pc_y[fill[p]] = u; pc_w[fill[p]] = v; pc_lm[fill[p]] = l; fill[p]++;
                 }
         // blocks per active pose (landmark-ascending)
         pb_start.assign((size_t)na + 1, 0);
@@ -195,10 +204,31 @@ struct BaHostStruct {        // scratch reused across jobs
         pb_blk.resize(nblk);
         fill.assign(pb_start.begin(), pb_start.begin() + na);
         for (int b = 0; b < nblk; ++b) pb_blk[fill[kf_pidx[blk_kf[b]]]++] = b;
+        // edge records in both orders
+        const uint8_t *ori = obs_right + j.obs_ofs;
+        const float *ouv = obs_uv + 2 * (size_t)j.obs_ofs;
+        recs.resize(2 * (size_t)nobs);
+        for (int i = 0; i < nobs; ++i) {
+            const int e = lm_edges[i];
+            BaRec r;
+            r.u = ouv[2 * e]; r.v = ouv[2 * e + 1];
+            r.lmkc = olm[e] | (((kf_pidx[okf[e]] << 1) | (ori[e] ? 1 : 0)) << 24);
+            r.blk = eblk[e];
+            recs[(size_t)i] = r;
+        }
+        for (int i = 0; i < nobs; ++i) {
+            const int e = kf_edges[i];
+            BaRec r;
+            r.u = ouv[2 * e]; r.v = ouv[2 * e + 1];
+            r.lmkc = olm[e] | (((kf_pidx[okf[e]] << 1) | (ori[e] ? 1 : 0)) << 24);
+            r.blk = eblk[e];
+            recs[(size_t)nobs + i] = r;
+        }
     }
     size_t aux_ints(const BaJob &j) const { return ba_aux_layout(j.nkf, j.nlm, j.nobs, nblk, na, ncontrib).total; }
-    void write(const BaJob &j, int *aux, BaDev &d) const
+    void write(const BaJob &j, int *aux, BaRec *rec_out, BaDev &d) const
     {
+        if (j.nobs) std::memcpy(rec_out, recs.data(), sizeof(BaRec) * 2 * (size_t)j.nobs);
         BaAuxLayout L = ba_aux_layout(j.nkf, j.nlm, j.nobs, nblk, na, ncontrib);
         auto cp = [&](size_t off, const std::vector<int> &v, size_t n) { if (n) std::memcpy(aux + off, v.data(), n * sizeof(int)); };
         cp(L.lm_estart, lm_estart, (size_t)j.nlm + 1); cp(L.lm_edges, lm_edges, j.nobs);
@@ -207,9 +237,10 @@ struct BaHostStruct {        // scratch reused across jobs
         cp(L.blk_kf, blk_kf, nblk); cp(L.blk_lm, blk_lm, nblk);
         cp(L.kf_pidx, kf_pidx, j.nkf); cp(L.act_kf, act_kf, j.nkf);
         cp(L.pc_start, pc_start, (size_t)na * (na + 1) / 2 + 1); cp(L.pc_y, pc_y, ncontrib); cp(L.pc_w, pc_w, ncontrib);
+        cp(L.pc_lm, pc_lm, ncontrib);
         cp(L.pb_start, pb_start, (size_t)na + 1); cp(L.pb_blk, pb_blk, nblk);
         d.kf_ofs = j.kf_ofs; d.nkf = j.nkf; d.lm_ofs = j.lm_ofs; d.nlm = j.nlm; d.obs_ofs = j.obs_ofs; d.nobs = j.nobs;
-        d.nblk = nblk; d.na = na; d.ncontrib = ncontrib; d.iters_done = 0; d.pad = 0;
+        d.nblk = nblk; d.na = na; d.ncontrib = ncontrib; d.iters_done = 0; d.rec_ofs = 0;
     }
 };
 
@@ -268,10 +299,45 @@ __device__ __forceinline__ void st_block18(double *p, const double *o)
 #define BA_PROF_N 12
 #define BA_PROF(i) do { if (prof && tid == 0) { long long t_ = wall_clock64(); prof[i] += t_ - tprev; tprev = t_; } } while (0)
 
-__global__ void __launch_bounds__(BA_THREADS)
-k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all, const int *obs_kf_all,
-           const int *obs_lm_all, const uint8_t *obs_right_all, const float2 *obs_uv_all, const int *aux_all,
-           BaWork wk, double delta, int iters, double *edge_chi2_all, long long *prof_all)
+// LDS pose table entry: R (9, row major) then t (3); cameras: Re (9), te (3), K (4)
+#define BA_PT 12
+#define BA_CT 16
+
+// projection of landmark X seen from table pose PT through table camera CT
+struct BaProj { double q[3], p[3], zi, ex, ey; };
+__device__ __forceinline__ void ba_project(const double *PT, const double *CT, const double *X, float u, float v, BaProj &o)
+{
+#pragma unroll
+    for (int r = 0; r < 3; ++r) o.q[r] = PT[3 * r] * X[0] + PT[3 * r + 1] * X[1] + PT[3 * r + 2] * X[2] + PT[9 + r];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) o.p[r] = CT[3 * r] * o.q[0] + CT[3 * r + 1] * o.q[1] + CT[3 * r + 2] * o.q[2] + CT[9 + r];
+    o.zi = 1.0 / o.p[2];
+    const double px = CT[12] * o.p[0] + CT[14] * o.p[2], py = CT[13] * o.p[1] + CT[15] * o.p[2];
+    o.ex = (double)u - px * o.zi; o.ey = (double)v - py * o.zi;
+}
+// M = d(e)/d(p) * Re (2x3) and the pose Jacobian Jp = M [I | -q^] (2x6), g2o_types.h:188-215
+__device__ __forceinline__ void ba_jac_pose(const double *CT, const BaProj &o, double *M, double *jp)
+{
+    const double zi2 = o.zi * o.zi;
+    const double e00 = -CT[12] * o.zi, e02 = CT[12] * o.p[0] * zi2, e11 = -CT[13] * o.zi, e12 = CT[13] * o.p[1] * zi2;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        M[c] = e00 * CT[c] + e02 * CT[6 + c];
+        M[3 + c] = e11 * CT[3 + c] + e12 * CT[6 + c];
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const double m0 = M[3 * r], m1 = M[3 * r + 1], m2 = M[3 * r + 2];
+        jp[6 * r + 0] = m0; jp[6 * r + 1] = m1; jp[6 * r + 2] = m2;
+        jp[6 * r + 3] = m2 * o.q[1] - m1 * o.q[2];
+        jp[6 * r + 4] = m0 * o.q[2] - m2 * o.q[0];
+        jp[6 * r + 5] = m1 * o.q[0] - m0 * o.q[1];
+    }
+}
+
+__global__ void __launch_bounds__(BA_THREADS, BA_MIN_WAVES_PER_SIMD)
+k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all, const BaRec *recs_all,
+           const int *aux_all, BaWork wk, double delta, int iters, double *edge_chi2_all, long long *prof_all)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int job = blockIdx.x;
@@ -281,7 +347,7 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
     if (nobs <= 0 || na <= 0) { if (tid == 0) jd.iters_done = 0; return; }
     long long *prof = (prof_all && job == 0) ? prof_all : nullptr;
     long long tprev = prof ? wall_clock64() : 0;
-    // LDS carve (all dynamic): S[(np+1)*(np+1)] | bs[np] | xp[np] | Hpp[36*na] | bp[np] | red[16] | flag
+    // LDS carve (all dynamic): S[(np+1)*(np+1)] | bs[np] | xp[np] | Hpp[36*na] | bp[np] | red[W] | PT[12 na] | CT[32] | flag
     const int ld = np + 1;   // odd row stride (in doubles): spreads LDS banks
     double *S = reinterpret_cast<double *>(smem);
     double *bs = S + (size_t)(np + 1) * ld;    // row np of S carries the right-hand side
@@ -289,32 +355,30 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
     double *Hpp = xp + np;
     double *bp = Hpp + 36 * na;
     double *red = bp + np;
-    int *iflag = reinterpret_cast<int *>(red + BA_WAVES);
+    double *PTab = red + BA_WAVES;
+    double *CTab = PTab + BA_PT * na;
+    double *part = CTab + 2 * BA_CT;               // [BA_ROWS][27] pose-pass partial sums
+    int *iflag = reinterpret_cast<int *>(part + 27 * BA_ROWS);
 
     const BaCams &cams = *camsp;
     double *poses = poses_all + (size_t)jd.kf_ofs * 7;
     double *pts = pts_all + (size_t)jd.lm_ofs * 3;
-    const int *okf = obs_kf_all + jd.obs_ofs, *olm = obs_lm_all + jd.obs_ofs;
-    const uint8_t *oright = obs_right_all + jd.obs_ofs;
-    const float2 *ouv = obs_uv_all + jd.obs_ofs;
     double *edge_chi2 = edge_chi2_all + jd.obs_ofs;
+    const BaRec *recL = recs_all + jd.rec_ofs;       // landmark-major
+    const BaRec *recP = recL + nobs;                   // pose-major
     const int *aux = aux_all + jd.aux_ofs;
     const BaAuxLayout AL = ba_aux_layout(nkf, nlm, nobs, nblk, na, jd.ncontrib);
     const int *lm_estart = aux + AL.lm_estart, *lm_edges = aux + AL.lm_edges;
-    const int *kf_estart = aux + AL.kf_estart, *kf_edges = aux + AL.kf_edges;
-    const int *eblk = aux + AL.eblk, *lm_bstart = aux + AL.lm_bstart;
+    const int *kf_estart = aux + AL.kf_estart;
+    const int *lm_bstart = aux + AL.lm_bstart;
     const int *blk_kf = aux + AL.blk_kf, *blk_lm = aux + AL.blk_lm;
     const int *kf_pidx = aux + AL.kf_pidx, *act_kf = aux + AL.act_kf;
-    const int *pc_start = aux + AL.pc_start, *pc_y = aux + AL.pc_y, *pc_w = aux + AL.pc_w;
+    const int *pc_start = aux + AL.pc_start, *pc_y = aux + AL.pc_y, *pc_w = aux + AL.pc_w, *pc_lm = aux + AL.pc_lm;
     const int *pb_start = aux + AL.pb_start, *pb_blk = aux + AL.pb_blk;
 
     const size_t J = job;
     double *err = wk.err + J * 2 * wk.max_obs;
-    double *Jp = wk.Jp + J * 12 * wk.max_obs;
-    double *Jl = wk.Jl + J * 6 * wk.max_obs;
-    double *wgt = wk.wgt + J * wk.max_obs;
     double *W = wk.W + J * 18 * wk.max_obs;
-    double *Y = wk.Y + J * 18 * wk.max_obs;
     double *Hll = wk.Hll + J * 9 * wk.max_lm;
     double *Dinv = wk.Dinv + J * 9 * wk.max_lm;
     double *bl = wk.bl + J * 3 * wk.max_lm;
@@ -322,54 +386,40 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
     double *poses_b = wk.poses_b + J * 7 * wk.max_kf;
     double *pts_b = wk.pts_b + J * 3 * wk.max_lm;
 
-    // errors (+ optionally Jacobians and robust weights) at the current state
-    auto edge_pass = [&](bool with_jac) -> double {
+    // camera table (constant) and pose table (rebuilt whenever the poses change)
+    if (tid < 2) {
+        double *CT = CTab + BA_CT * tid;
+        d_quat_to_R(cams.ext[tid], CT);
+        CT[9] = cams.ext[tid][4]; CT[10] = cams.ext[tid][5]; CT[11] = cams.ext[tid][6];
+        CT[12] = cams.cam[tid][0]; CT[13] = cams.cam[tid][1]; CT[14] = cams.cam[tid][2]; CT[15] = cams.cam[tid][3];
+    }
+    auto pose_table = [&]() {
+        __syncthreads();
+        if (tid < na) {
+            const double *T = poses + 7 * act_kf[tid];
+            double *PT = PTab + BA_PT * tid;
+            d_quat_to_R(T, PT);
+            PT[9] = T[4]; PT[10] = T[5]; PT[11] = T[6];
+        }
+        __syncthreads();
+    };
+
+    // errors at the current state: thread per edge in landmark-major order (coalesced records,
+    // near-coalesced landmark reads, poses from the LDS table)
+    auto error_pass = [&]() -> double {
+        pose_table();
         double chi = 0;
-        for (int e = tid; e < nobs; e += BA_THREADS) {
-            const int cam = oright[e] ? 1 : 0;
-            const double *T = poses + 7 * okf[e];
-            const double *ext = cams.ext[cam];
-            const double *K = cams.cam[cam];
-            double q[3], p[3];
-            d_se3_act(T, pts + 3 * olm[e], q);
-            d_se3_act(ext, q, p);
-            const double zi = 1.0 / p[2];
-            const double px = K[0] * p[0] + K[2] * p[2], py = K[1] * p[1] + K[3] * p[2];
-            const double ex = (double)ouv[e].x - px * zi, ey = (double)ouv[e].y - py * zi;
-            err[2 * e] = ex; err[2 * e + 1] = ey;
+        for (int i = tid; i < nobs; i += BA_THREADS) {
+            const BaRec rc = recL[i];
+            const int kc = (unsigned)rc.lmkc >> 24;
+            const double *Xp = pts + 3 * (size_t)(rc.lmkc & BA_LM_MASK);
+            const double X[3] = { Xp[0], Xp[1], Xp[2] };
+            BaProj o;
+            ba_project(PTab + BA_PT * (kc >> 1), CTab + BA_CT * (kc & 1), X, rc.u, rc.v, o);
+            err[2 * i] = o.ex; err[2 * i + 1] = o.ey;
             double r0, r1;
-            d_huber(ex * ex + ey * ey, delta, r0, r1);
+            d_huber(o.ex * o.ex + o.ey * o.ey, delta, r0, r1);
             chi += r0;
-            if (with_jac) {
-                wgt[e] = r1;
-                // de/dp (2x3) times Re -> M; Jp = M [I | -q^]; Jl = M R
-                const double zi2 = zi * zi;
-                const double e00 = -K[0] * zi, e02 = K[0] * p[0] * zi2, e11 = -K[1] * zi, e12 = K[1] * p[1] * zi2;
-                double Re[9];
-                d_quat_to_R(ext, Re);
-                double M[6];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    M[c] = e00 * Re[c] + e02 * Re[6 + c];
-                    M[3 + c] = e11 * Re[3 + c] + e12 * Re[6 + c];
-                }
-                double *jp = Jp + 12 * (size_t)e, *jl = Jl + 6 * (size_t)e;
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const double m0 = M[3 * r], m1 = M[3 * r + 1], m2 = M[3 * r + 2];
-                    jp[6 * r + 0] = m0; jp[6 * r + 1] = m1; jp[6 * r + 2] = m2;
-                    jp[6 * r + 3] = m2 * q[1] - m1 * q[2];
-                    jp[6 * r + 4] = m0 * q[2] - m2 * q[0];
-                    jp[6 * r + 5] = m1 * q[0] - m0 * q[1];
-                }
-                double R[9];
-                d_quat_to_R(T, R);
-#pragma unroll
-                for (int r = 0; r < 2; ++r)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c)
-                        jl[3 * r + c] = M[3 * r] * R[c] + M[3 * r + 1] * R[3 + c] + M[3 * r + 2] * R[6 + c];
-            }
         }
         return block_sum(chi, red, tid);
     };
@@ -377,25 +427,39 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
     double lambda = 0, ni = 2;
     int it_done = 0;
     for (int it = 0; it < iters; ++it) {
-        double currentChi = edge_pass(true);
-        double tempChi = currentChi;
-        BA_PROF(0);
-        // ---- landmark pass: Hll, bl, W blocks (edges of a landmark are sorted by pose)
+        pose_table();
+        // ---- landmark pass: errors, Jacobians on the fly, Hll, bl, W blocks
+        double chi_part = 0;
         for (int j = tid; j < nlm; j += BA_THREADS) {
             double h[6] = { 0, 0, 0, 0, 0, 0 }, b3[3] = { 0, 0, 0 };
+            const double X[3] = { pts[3 * (size_t)j], pts[3 * (size_t)j + 1], pts[3 * (size_t)j + 2] };
             const int eend = lm_estart[j + 1];
             int i = lm_estart[j];
             while (i < eend) {
-                const int blk = eblk[lm_edges[i]];
+                BaRec rc = recL[i];
+                const int blk = rc.blk;
                 double wacc[18];
 #pragma unroll
                 for (int t = 0; t < 18; ++t) wacc[t] = 0;
-                while (i < eend && eblk[lm_edges[i]] == blk) {
-                    const int e = lm_edges[i];
-                    const double *jp = Jp + 12 * (size_t)e, *jl = Jl + 6 * (size_t)e;
-                    const double w = wgt[e], ex = err[2 * e], ey = err[2 * e + 1];
-                    const double l0 = jl[0], l1 = jl[1], l2 = jl[2], l3 = jl[3], l4 = jl[4], l5 = jl[5];
-                    const double wl0 = w * l0, wl1 = w * l1, wl2 = w * l2, wl3 = w * l3, wl4 = w * l4, wl5 = w * l5;
+                for (;;) {
+                    const int kc = (unsigned)rc.lmkc >> 24;
+                    const double *PT = PTab + BA_PT * (kc >> 1), *CT = CTab + BA_CT * (kc & 1);
+                    BaProj o;
+                    ba_project(PT, CT, X, rc.u, rc.v, o);
+                    err[2 * i] = o.ex; err[2 * i + 1] = o.ey;
+                    double r0, w;
+                    d_huber(o.ex * o.ex + o.ey * o.ey, delta, r0, w);
+                    chi_part += r0;
+                    double M[6], jp[12];
+                    ba_jac_pose(CT, o, M, jp);
+                    // Jl = M R
+                    double jl[6];
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            jl[3 * r + c] = M[3 * r] * PT[c] + M[3 * r + 1] * PT[3 + c] + M[3 * r + 2] * PT[6 + c];
+                    const double wl0 = w * jl[0], wl1 = w * jl[1], wl2 = w * jl[2], wl3 = w * jl[3], wl4 = w * jl[4], wl5 = w * jl[5];
 #pragma unroll
                     for (int a = 0; a < 6; ++a) {
                         const double p0 = jp[a], p1 = jp[6 + a];
@@ -403,53 +467,76 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
                         wacc[a * 3 + 1] += p0 * wl1 + p1 * wl4;
                         wacc[a * 3 + 2] += p0 * wl2 + p1 * wl5;
                     }
-                    b3[0] -= wl0 * ex + wl3 * ey; b3[1] -= wl1 * ex + wl4 * ey; b3[2] -= wl2 * ex + wl5 * ey;
-                    h[0] += wl0 * l0 + wl3 * l3; h[1] += wl0 * l1 + wl3 * l4; h[2] += wl0 * l2 + wl3 * l5;
-                    h[3] += wl1 * l1 + wl4 * l4; h[4] += wl1 * l2 + wl4 * l5; h[5] += wl2 * l2 + wl5 * l5;
+                    b3[0] -= wl0 * o.ex + wl3 * o.ey; b3[1] -= wl1 * o.ex + wl4 * o.ey; b3[2] -= wl2 * o.ex + wl5 * o.ey;
+                    h[0] += wl0 * jl[0] + wl3 * jl[3]; h[1] += wl0 * jl[1] + wl3 * jl[4]; h[2] += wl0 * jl[2] + wl3 * jl[5];
+                    h[3] += wl1 * jl[1] + wl4 * jl[4]; h[4] += wl1 * jl[2] + wl4 * jl[5]; h[5] += wl2 * jl[2] + wl5 * jl[5];
                     ++i;
+                    if (i >= eend) break;
+                    rc = recL[i];
+                    if (rc.blk != blk) break;
                 }
-#pragma unroll
-                for (int t = 0; t < 18; ++t) W[18 * (size_t)blk + t] = wacc[t];
+                st_block18(W + 18 * (size_t)blk, wacc);
             }
             double *hj = Hll + 9 * (size_t)j;
             hj[0] = h[0]; hj[1] = h[1]; hj[2] = h[2]; hj[3] = h[1]; hj[4] = h[3]; hj[5] = h[4];
             hj[6] = h[2]; hj[7] = h[4]; hj[8] = h[5];
             bl[3 * j] = b3[0]; bl[3 * j + 1] = b3[1]; bl[3 * j + 2] = b3[2];
         }
-        // ---- pose pass: Hpp (block diagonal), bp -> LDS   (wave per active pose)
-        for (int a = wv; a < na; a += BA_WAVES) {
-            const int k = act_kf[a];
+        BA_PROF(0);
+        // ---- pose pass: Hpp (block diagonal), bp -> LDS.  16-lane rows; pose a is shared by
+        // the rows a, a + na, a + 2 na ... (< BA_ROWS), partial sums combined in row order
+        {
+            const int row = tid >> 4, rl = tid & 15;
+            const int rpp = BA_ROWS / na;                 // rows per pose (>= 1: na <= 32)
             double acc[27];
 #pragma unroll
             for (int t = 0; t < 27; ++t) acc[t] = 0;
-            for (int i = kf_estart[k] + lane; i < kf_estart[k + 1]; i += 64) {
-                const int e = kf_edges[i];
-                const double *jp = Jp + 12 * (size_t)e;
-                const double w = wgt[e], ex = err[2 * e], ey = err[2 * e + 1];
-                double j0[6], j1[6];
+            const int a = row % na, sub = row / na;
+            if (sub < rpp) {
+                const int k = act_kf[a];
+                for (int i = kf_estart[k] + sub * 16 + rl; i < kf_estart[k + 1]; i += 16 * rpp) {
+                    const BaRec rc = recP[i];
+                    const int kc = (unsigned)rc.lmkc >> 24;
+                    const double *Xp = pts + 3 * (size_t)(rc.lmkc & BA_LM_MASK);
+                    const double X[3] = { Xp[0], Xp[1], Xp[2] };
+                    const double *CT = CTab + BA_CT * (kc & 1);
+                    BaProj o;
+                    ba_project(PTab + BA_PT * a, CT, X, rc.u, rc.v, o);
+                    double r0, w;
+                    d_huber(o.ex * o.ex + o.ey * o.ey, delta, r0, w);
+                    double M[6], jp[12];
+                    ba_jac_pose(CT, o, M, jp);
+                    int t = 0;
 #pragma unroll
-                for (int r = 0; r < 6; ++r) { j0[r] = jp[r]; j1[r] = jp[6 + r]; }
-                int t = 0;
+                    for (int r = 0; r < 6; ++r) {
+                        const double w0 = w * jp[r], w1 = w * jp[6 + r];
 #pragma unroll
-                for (int r = 0; r < 6; ++r) {
-                    const double w0 = w * j0[r], w1 = w * j1[r];
-#pragma unroll
-                    for (int c = r; c < 6; ++c) { acc[t] += w0 * j0[c] + w1 * j1[c]; ++t; }
-                    acc[21 + r] -= w0 * ex + w1 * ey;
+                        for (int c = r; c < 6; ++c) { acc[t] += w0 * jp[c] + w1 * jp[6 + c]; ++t; }
+                        acc[21 + r] -= w0 * o.ex + w1 * o.ey;
+                    }
                 }
             }
 #pragma unroll
-            for (int t = 0; t < 27; ++t) acc[t] = wave_sum_f64(acc[t]);
-            if (lane == 0) {
-                int t = 0;
+            for (int t = 0; t < 27; ++t) acc[t] = row_sum_f64(acc[t]);
+            if (rl == 0) {
 #pragma unroll
-                for (int r = 0; r < 6; ++r)
-#pragma unroll
-                    for (int c = r; c < 6; ++c) { Hpp[36 * a + r * 6 + c] = acc[t]; Hpp[36 * a + c * 6 + r] = acc[t]; ++t; }
-#pragma unroll
-                for (int r = 0; r < 6; ++r) bp[6 * a + r] = acc[21 + r];
+                for (int t = 0; t < 27; ++t) part[row * 27 + t] = acc[t];
+            }
+            __syncthreads();
+            for (int z = tid; z < 27 * na; z += BA_THREADS) {
+                const int a2 = z / 27, t = z - a2 * 27;
+                double v = 0;
+                for (int sb = 0; sb < rpp; ++sb) v += part[(sb * na + a2) * 27 + t];
+                if (t < 21) {
+                    int r = 0, rem = t;
+                    while (rem >= 6 - r) { rem -= 6 - r; ++r; }
+                    const int c = r + rem;
+                    Hpp[36 * a2 + r * 6 + c] = v; Hpp[36 * a2 + c * 6 + r] = v;
+                } else bp[6 * a2 + (t - 21)] = v;
             }
         }
+        double currentChi = block_sum(chi_part, red, tid);
+        double tempChi = currentChi;
         __syncthreads();
         BA_PROF(1);
         if (it == 0) {
@@ -465,33 +552,19 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
             // backup, Dinv / db / Y, S = blockdiag(Hpp) + lambda I
             for (int i = tid; i < 7 * nkf; i += BA_THREADS) poses_b[i] = poses[i];
             for (int i = tid; i < 3 * nlm; i += BA_THREADS) pts_b[i] = pts[i];
-            for (int b = tid; b < nblk; b += BA_THREADS) {
-                const int j = blk_lm[b];
+            for (int j = tid; j < nlm; j += BA_THREADS) {
                 double D[9], Di[9];
                 const double *hj = Hll + 9 * (size_t)j;
 #pragma unroll
                 for (int t = 0; t < 9; ++t) D[t] = hj[t];
                 D[0] += lambda; D[4] += lambda; D[8] += lambda;
                 d_inv3(D, Di);
-                if (b == lm_bstart[j]) {     // first block of the landmark publishes Dinv, db
-                    double *dj = Dinv + 9 * (size_t)j;
+                double *dj = Dinv + 9 * (size_t)j;
 #pragma unroll
-                    for (int t = 0; t < 9; ++t) dj[t] = Di[t];
-                    const double b0 = bl[3 * j], b1 = bl[3 * j + 1], b2 = bl[3 * j + 2];
+                for (int t = 0; t < 9; ++t) dj[t] = Di[t];
+                const double b0 = bl[3 * j], b1 = bl[3 * j + 1], b2 = bl[3 * j + 2];
 #pragma unroll
-                    for (int a = 0; a < 3; ++a) db[3 * j + a] = Di[a * 3] * b0 + Di[a * 3 + 1] * b1 + Di[a * 3 + 2] * b2;
-                }
-                // W and Y blocks are 144 B, 16-B aligned: move them as 9 x double2
-                double w1[18], y[18];
-                ld_block18(W + 18 * (size_t)b, w1);
-#pragma unroll
-                for (int a = 0; a < 6; ++a) {
-                    const double x0 = w1[a * 3], x1 = w1[a * 3 + 1], x2 = w1[a * 3 + 2];
-                    y[a * 3 + 0] = x0 * Di[0] + x1 * Di[3] + x2 * Di[6];
-                    y[a * 3 + 1] = x0 * Di[1] + x1 * Di[4] + x2 * Di[7];
-                    y[a * 3 + 2] = x0 * Di[2] + x1 * Di[5] + x2 * Di[8];
-                }
-                st_block18(Y + 18 * (size_t)b, y);
+                for (int a = 0; a < 3; ++a) db[3 * j + a] = Di[a * 3] * b0 + Di[a * 3 + 1] * b1 + Di[a * 3 + 2] * b2;
             }
             for (int i = tid; i < np * np; i += BA_THREADS) {
                 int r = i / np, c = i - r * np;
@@ -516,8 +589,20 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
                         for (int z = 0; z < 36; ++z) acc[z] = 0;
                         for (int c = pc_start[t] + rl; c < pc_start[t + 1]; c += 16) {
                             double yy[18], ww[18];
-                            ld_block18(Y + 18 * (size_t)pc_y[c], yy);
-                            ld_block18(W + 18 * (size_t)pc_w[c], ww);
+                            const int by = pc_y[c], bw = pc_w[c];
+                            ld_block18(W + 18 * (size_t)by, ww);
+                            {
+                                const double *Di = Dinv + 9 * (size_t)pc_lm[c];      // symmetric
+                                const double d00 = Di[0], d01 = Di[1], d02 = Di[2], d11 = Di[4], d12 = Di[5], d22 = Di[8];
+#pragma unroll
+                                for (int r = 0; r < 6; ++r) {
+                                    const double x0 = ww[r * 3], x1 = ww[r * 3 + 1], x2 = ww[r * 3 + 2];
+                                    yy[r * 3 + 0] = x0 * d00 + x1 * d01 + x2 * d02;
+                                    yy[r * 3 + 1] = x0 * d01 + x1 * d11 + x2 * d12;
+                                    yy[r * 3 + 2] = x0 * d02 + x1 * d12 + x2 * d22;
+                                }
+                            }
+                            if (bw != by) ld_block18(W + 18 * (size_t)bw, ww);
 #pragma unroll
                             for (int r = 0; r < 6; ++r)
 #pragma unroll
@@ -713,7 +798,7 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
             double scale = block_sum(scale_part, red, tid);
             __syncthreads();
             BA_PROF(5);
-            tempChi = edge_pass(false);
+            tempChi = error_pass();
             BA_PROF(6);
             if (!ok2) tempChi = 1.7976931348623157e308;
             rho = currentChi - tempChi;
@@ -739,12 +824,13 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
         if (qmax == 10 || rho == 0 || !isfinite(lambda)) break;
     }
     __syncthreads();
-    for (int e = tid; e < nobs; e += BA_THREADS) edge_chi2[e] = err[2 * e] * err[2 * e] + err[2 * e + 1] * err[2 * e + 1];
+    for (int i = tid; i < nobs; i += BA_THREADS) edge_chi2[lm_edges[i]] = err[2 * i] * err[2 * i] + err[2 * i + 1] * err[2 * i + 1];
     if (tid == 0) jd.iters_done = it_done;
 }
 
 static inline size_t ba_lds_bytes(int max_kf)
 {
     size_t np = 6 * (size_t)max_kf;
-    return ((np + 1) * (np + 1) + 3 * np + 36 * (size_t)max_kf + BA_WAVES) * sizeof(double) + 64;
+    return ((np + 1) * (np + 1) + 3 * np + 36 * (size_t)max_kf + BA_WAVES + BA_PT * (size_t)max_kf + 2 * BA_CT +
+            27 * BA_ROWS) * sizeof(double) + 64;
 }

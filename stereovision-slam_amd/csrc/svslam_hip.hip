@@ -697,7 +697,7 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
                 const int k = obs_kf[bj.obs_ofs + e], l = obs_lm[bj.obs_ofs + e];
                 if (k < 0 || k >= bj.nkf || l < 0 || l >= bj.nlm) { bad[(size_t)i] = 1; return; }
             }
-            hs[i].build(bj, obs_kf, obs_lm);
+            hs[i].build(bj, obs_kf, obs_lm, obs_is_right, obs_uv);
         };
         if (c->pool && njobs > 1) c->pool->parallel_for(njobs, build_one);
         else for (int i = 0; i < njobs; ++i) build_one(i);
@@ -710,10 +710,7 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
         }
     }
     size_t ocams = c->ar.take(sizeof(BaCams));
-    size_t okf = c->ar.take(sizeof(int) * std::max(total_obs, 1));
-    size_t olm = c->ar.take(sizeof(int) * std::max(total_obs, 1));
-    size_t oright = c->ar.take(std::max(total_obs, 1));
-    size_t ouv = c->ar.take(sizeof(float) * 2 * std::max(total_obs, 1));
+    size_t orecs = c->ar.take(sizeof(BaRec) * 2 * std::max(total_obs, 1));   // landmark-major + pose-major edge records
     size_t oaux = c->ar.take(sizeof(int) * std::max(aux_total, (size_t)1));
     size_t ojobs = c->ar.take(sizeof(BaDev) * njobs);
     size_t oposes = c->ar.take(sizeof(double) * 7 * std::max(total_kf, 1));
@@ -724,12 +721,6 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
     BaCams *cams = hp<BaCams>(c, ocams);
     memcpy(cams->cam[0], cam_l, 32); memcpy(cams->cam[1], cam_r, 32);
     memcpy(cams->ext[0], ext_l, 56); memcpy(cams->ext[1], ext_r, 56);
-    if (total_obs > 0) {
-        memcpy(hp<void>(c, okf), obs_kf, sizeof(int) * total_obs);
-        memcpy(hp<void>(c, olm), obs_lm, sizeof(int) * total_obs);
-        memcpy(hp<void>(c, oright), obs_is_right, total_obs);
-        memcpy(hp<void>(c, ouv), obs_uv, sizeof(float) * 2 * total_obs);
-    }
     BaDev *dj = hp<BaDev>(c, ojobs);
     {
         size_t aofs = 0;
@@ -744,8 +735,9 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
         auto write_one = [&](int i) {
             BaJob bj;
             memcpy(&bj, &jobs[i], sizeof(bj));
-            hs[i].write(bj, aux + aoff[(size_t)i], dj[i]);
+            hs[i].write(bj, aux + aoff[(size_t)i], hp<BaRec>(c, orecs) + 2 * (size_t)bj.obs_ofs, dj[i]);
             dj[i].aux_ofs = (int)aoff[(size_t)i];
+            dj[i].rec_ofs = 2 * bj.obs_ofs;
         };
         if (c->pool && njobs > 1) c->pool->parallel_for(njobs, write_one);
         else for (int i = 0; i < njobs; ++i) write_one(i);
@@ -757,8 +749,7 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
     tm_begin(c, FAM_BA, njobs);
     hipLaunchKernelGGL(k_local_ba, dim3(njobs), dim3(BA_THREADS), ba_lds_bytes(c->lim.max_kf), c->stream,
                        dp<BaDev>(c, ojobs), dp<BaCams>(c, ocams), dp<double>(c, oposes), dp<double>(c, opts),
-                       dp<int>(c, okf), dp<int>(c, olm), dp<uint8_t>(c, oright), dp<float2>(c, ouv),
-                       dp<int>(c, oaux), c->bw, huber_delta, iters, dp<double>(c, ochi), c->d_ba_prof);
+                       dp<BaRec>(c, orecs), dp<int>(c, oaux), c->bw, huber_delta, iters, dp<double>(c, ochi), c->d_ba_prof);
     tm_end(c);
     HIPCHK(c, hipGetLastError());
     if (d2h_enqueue(c, ojobs, c->ar.off)) return -1;

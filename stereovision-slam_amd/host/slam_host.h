@@ -755,11 +755,29 @@ private:
             }
         });
         st_[6] += now_ns() - t_h6;
+        if (const char *dump = std::getenv("SVS_DUMP_BA")) DumpBaProblem(dump, 0);   // development hook
         { KTimer kt_(cnt_); check(k_.local_ba_submit(n, jobs_ba_.data(), cam_l_, cfg_.cam_l.pose.v, cam_r_, cfg_.cam_r.pose.v, ko,
                           ba_poses_.data(), lo, ba_pts_.data(), oo, ba_okf_.data(), ba_olm_.data(), ba_right_.data(),
                           ba_uv_.data(), cfg_.chi2_th, 10), "local_ba_submit"); }   // :150-164
         ba_ko_ = ko; ba_lo_ = lo; ba_oo_ = oo;
         ba_inflight_ = true;
+    }
+
+    // development hook: writes job i of the batch being submitted when its window is full
+    // (int32 nkf nlm nobs | f64 poses[7 nkf] pts[3 nlm] | i32 okf[nobs] olm[nobs] | u8 right[nobs] | f32 uv[2 nobs])
+    void DumpBaProblem(const char *path, int i)
+    {
+        const svslam_ba_job &j = jobs_ba_[(size_t)i];
+        if (j.nkf < cfg_.num_active_keyframes) return;
+        std::ofstream f(path, std::ios::binary | std::ios::trunc);
+        const int hdr[3] = { j.nkf, j.nlm, j.nobs };
+        f.write(reinterpret_cast<const char *>(hdr), sizeof(hdr));
+        f.write(reinterpret_cast<const char *>(&ba_poses_[7 * (size_t)j.kf_ofs]), sizeof(double) * 7 * j.nkf);
+        f.write(reinterpret_cast<const char *>(&ba_pts_[3 * (size_t)j.lm_ofs]), sizeof(double) * 3 * j.nlm);
+        f.write(reinterpret_cast<const char *>(&ba_okf_[(size_t)j.obs_ofs]), sizeof(int) * j.nobs);
+        f.write(reinterpret_cast<const char *>(&ba_olm_[(size_t)j.obs_ofs]), sizeof(int) * j.nobs);
+        f.write(reinterpret_cast<const char *>(&ba_right_[(size_t)j.obs_ofs]), (size_t)j.nobs);
+        f.write(reinterpret_cast<const char *>(&ba_uv_[2 * (size_t)j.obs_ofs]), sizeof(float) * 2 * j.nobs);
     }
 
     // ... wait for the solve and write it back to the map (src/backend.cpp:167-246)

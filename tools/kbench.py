@@ -17,13 +17,20 @@ svs = importlib.import_module("stereovision-slam_amd")
 
 def ba(nj=1, nkf=10, nlm=700, reps=3):
     rng = np.random.default_rng(1)
-    c = svs.Context(cm.W, cm.H, max_slots=1, max_jobs=max(nj, 1), max_kf=nkf + 1, max_lm=4096, max_obs=16384)
-    probs = [cm.make_ba_problem(rng, nkf, nlm) for _ in range(nj)]
-    # thin the observations to a realistic ~4 per landmark
-    jobs = []
-    for p in probs:
-        keep = rng.random(len(p["okf"])) < 0.3
-        jobs.append((p["poses0"], p["pts0"], p["okf"][keep], p["olm"][keep], p["ori"][keep], p["ouv"][keep]))
+    c = svs.Context(cm.W, cm.H, max_slots=1, max_jobs=max(nj, 1), max_kf=max(nkf, 10) + 1, max_lm=4096, max_obs=16384)
+    if nkf == 0:
+        # a local-BA problem captured from the pipeline itself (stream seed 3, full 10-keyframe window:
+        # 1725 landmarks of which 78% are seen from one keyframe only, 4011 edges), replicated
+        d = np.load(os.path.join(ROOT, "tools", "ba_pipeline_problem.npz"))
+        jobs = [(d["poses"], d["pts"], d["okf"], d["olm"], d["ori"], d["uv"])] * nj
+        nkf, nlm = len(d["poses"]), len(d["pts"])
+    else:
+        probs = [cm.make_ba_problem(rng, nkf, nlm) for _ in range(nj)]
+        # thin the observations to a realistic ~4 per landmark
+        jobs = []
+        for p in probs:
+            keep = rng.random(len(p["okf"])) < 0.3
+            jobs.append((p["poses0"], p["pts0"], p["okf"][keep], p["olm"][keep], p["ori"][keep], p["ouv"][keep]))
     print("BA jobs=%d nkf=%d nlm=%d nobs=%d" % (nj, nkf, nlm, len(jobs[0][2])))
     c.ba_profile(True)
     c.timing(True)
@@ -97,6 +104,11 @@ if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what == "lk":
         lkbench(); sys.exit(0)
+    if what == "tput":       # chip-time per family at bench scale
+        for nj in (1, 64, 256, 512):
+            ba(nj, 0, 0, reps=2)
+        frontend(256); frontend(512)
+        sys.exit(0)
     if what in ("clock", "all"):
         clock()
     if what in ("ba", "all"):
