@@ -96,11 +96,11 @@ static inline void ba_work_free(BaWork &w) { if (w.all) (void)hipFree(w.all); w.
 
 // ---------------------------------------------------------------- host-side structure
 // aux layout per job (ints), offsets from ba_aux_layout():
-//   lm_estart[nlm+1] lm_edges[nobs] kf_estart[nkf+1] kf_edges[nobs] eblk[nobs]
+//   lm_estart[nlm+1] lm_edges[nobs] kf_estart[nkf+1]
 //   lm_bstart[nlm+1] blk_kf[nblk] blk_lm[nblk] kf_pidx[nkf] act_kf[nkf]
 //   pc_start[npairs+1] pc_y[ncontrib] pc_w[ncontrib] pc_lm[ncontrib] pb_start[na+1] pb_blk[nblk]
 struct BaAuxLayout {
-    size_t lm_estart, lm_edges, kf_estart, kf_edges, eblk, lm_bstart, blk_kf, blk_lm, kf_pidx, act_kf;
+    size_t lm_estart, lm_edges, kf_estart, lm_bstart, blk_kf, blk_lm, kf_pidx, act_kf;
     size_t pc_start, pc_y, pc_w, pc_lm, pb_start, pb_blk, total;
 };
 __host__ __device__ inline BaAuxLayout ba_aux_layout(int nkf, int nlm, int nobs, int nblk, int na, int ncontrib)
@@ -110,8 +110,6 @@ __host__ __device__ inline BaAuxLayout ba_aux_layout(int nkf, int nlm, int nobs,
     L.lm_estart = o; o += (size_t)nlm + 1;
     L.lm_edges = o; o += nobs;
     L.kf_estart = o; o += (size_t)nkf + 1;
-    L.kf_edges = o; o += nobs;
-    L.eblk = o; o += nobs;
     L.lm_bstart = o; o += (size_t)nlm + 1;
     L.blk_kf = o; o += nblk;
     L.blk_lm = o; o += nblk;
@@ -130,100 +128,101 @@ __host__ __device__ inline BaAuxLayout ba_aux_layout(int nkf, int nlm, int nobs,
 __host__ __device__ inline int ba_pair_index(int a, int b, int na) { return a * na - a * (a - 1) / 2 + (b - a); }
 
 struct BaHostStruct {        // scratch reused across jobs
-    std::vector<int> order, lm_estart, lm_edges, kf_estart, kf_edges, eblk, lm_bstart, blk_kf, blk_lm, kf_pidx,
-        act_kf, pc_start, pc_y, pc_w, pc_lm, pb_start, pb_blk, fill;
+    std::vector<int> lm_estart, lm_edges, kf_estart, lm_bstart, blk_kf, blk_lm, kf_pidx,
+        act_kf, pc_start, pc_y, pc_w, pc_lm, pb_start, pb_blk, fill, fill2;
     std::vector<BaRec> recs;     // [0,nobs) landmark-major (= lm_edges order), [nobs,2nobs) pose-major
     int nblk = 0, na = 0, ncontrib = 0;
 
-    void build(const BaJob &j, const int *obs_kf, const int *obs_lm, const uint8_t *obs_right, const float *obs_uv)
+    // Returns false if an edge index is out of range.  Two passes over the edges when they
+    // arrive landmark-major with keyframes ascending inside a landmark (the order the host
+    // pipeline gathers them in, src/backend.cpp:83-160); otherwise they are sorted first.
+    bool build(const BaJob &j, const int *obs_kf, const int *obs_lm, const uint8_t *obs_right, const float *obs_uv)
     {
         const int nkf = j.nkf, nlm = j.nlm, nobs = j.nobs;
         const int *okf = obs_kf + j.obs_ofs, *olm = obs_lm + j.obs_ofs;
-        order.resize(nobs);
-        for (int e = 0; e < nobs; ++e) order[e] = e;
-        // the host pipeline gathers landmark by landmark with observations in keyframe order,
-        // so the edges normally arrive sorted already: check in O(E), sort only if needed
+        const uint8_t *ori = obs_right + j.obs_ofs;
+        const float *ouv = obs_uv + 2 * (size_t)j.obs_ofs;
         bool sorted = true;
-        for (int e = 1; e < nobs && sorted; ++e)
-            sorted = (olm[e - 1] < olm[e]) || (olm[e - 1] == olm[e] && okf[e - 1] <= okf[e]);
+        for (int e = 0; e < nobs; ++e) {
+            const int k = okf[e], l = olm[e];
+            if (k < 0 || k >= nkf || l < 0 || l >= nlm) return false;
+            if (e && !((olm[e - 1] < l) || (olm[e - 1] == l && okf[e - 1] <= k))) sorted = false;
+        }
+        lm_edges.resize(nobs);
+        for (int e = 0; e < nobs; ++e) lm_edges[e] = e;
         if (!sorted)
-            std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+            std::stable_sort(lm_edges.begin(), lm_edges.end(), [&](int a, int b) {
                 if (olm[a] != olm[b]) return olm[a] < olm[b];
                 return okf[a] < okf[b];
             });
+        // pass 1 (landmark-major): edge ranges, blocks, landmark-major records (keyframe still raw)
         lm_estart.assign((size_t)nlm + 1, 0);
-        for (int e = 0; e < nobs; ++e) lm_estart[olm[e] + 1]++;
-        for (int i = 0; i < nlm; ++i) lm_estart[i + 1] += lm_estart[i];
+        lm_bstart.assign((size_t)nlm + 1, 0);
         kf_estart.assign((size_t)nkf + 1, 0);
-        for (int e = 0; e < nobs; ++e) kf_estart[okf[e] + 1]++;
+        blk_kf.clear(); blk_lm.clear();
+        recs.resize(2 * (size_t)nobs);
+        int prev_lm = -1, prev_kf = -1;
+        for (int i = 0; i < nobs; ++i) {
+            const int e = lm_edges[i], k = okf[e], l = olm[e];
+            lm_estart[l + 1]++; kf_estart[k + 1]++;
+            if (l != prev_lm || k != prev_kf) {
+                blk_kf.push_back(k); blk_lm.push_back(l);
+                lm_bstart[l + 1]++;
+                prev_lm = l; prev_kf = k;
+            }
+            BaRec &r = recs[(size_t)i];
+            r.u = ouv[2 * e]; r.v = ouv[2 * e + 1];
+            r.lmkc = (k << 1) | (ori[e] ? 1 : 0);      // completed in pass 2
+            r.blk = (int)blk_kf.size() - 1;
+        }
+        nblk = (int)blk_kf.size();
+        for (int i = 0; i < nlm; ++i) { lm_estart[i + 1] += lm_estart[i]; lm_bstart[i + 1] += lm_bstart[i]; }
         for (int i = 0; i < nkf; ++i) kf_estart[i + 1] += kf_estart[i];
         kf_pidx.assign(nkf, -1); act_kf.assign(nkf, -1);
         na = 0;
         for (int k = 0; k < nkf; ++k)
             if (kf_estart[k + 1] > kf_estart[k]) { kf_pidx[k] = na; act_kf[na] = k; ++na; }
-        lm_edges.resize(nobs); eblk.resize(nobs);
-        lm_bstart.assign((size_t)nlm + 1, 0);
-        blk_kf.clear(); blk_lm.clear();
-        int prev_lm = -1, prev_kf = -1;
-        for (int i = 0; i < nobs; ++i) {
-            int e = order[i];
-            lm_edges[i] = e;
-            if (olm[e] != prev_lm || okf[e] != prev_kf) {
-                blk_kf.push_back(okf[e]); blk_lm.push_back(olm[e]);
-                lm_bstart[olm[e] + 1]++;
-                prev_lm = olm[e]; prev_kf = okf[e];
-            }
-            eblk[e] = (int)blk_kf.size() - 1;
-        }
-        nblk = (int)blk_kf.size();
-        for (int i = 0; i < nlm; ++i) lm_bstart[i + 1] += lm_bstart[i];
-        kf_edges.resize(nobs);
+        // pass 2: finish the records, scatter the pose-major copy (landmark-ascending inside a pose)
         fill.assign(kf_estart.begin(), kf_estart.begin() + nkf);
-        for (int e = 0; e < nobs; ++e) kf_edges[fill[okf[e]]++] = e;
+        for (int i = 0; i < nobs; ++i) {
+            BaRec &r = recs[(size_t)i];
+            const int k = r.lmkc >> 1, cam = r.lmkc & 1;
+            r.lmkc = olm[lm_edges[i]] | (((kf_pidx[k] << 1) | cam) << 24);
+            recs[(size_t)nobs + fill[k]++] = r;
+        }
         // (Y,W) block pairs per pose pair, counting sort by pair; landmark-ascending inside a pair
         const int npairs = na * (na + 1) / 2;
         pc_start.assign((size_t)npairs + 1, 0);
-        for (int l = 0; l < nlm; ++l)
-            for (int u = lm_bstart[l]; u < lm_bstart[l + 1]; ++u)
-                for (int v = u; v < lm_bstart[l + 1]; ++v)
-                    pc_start[ba_pair_index(kf_pidx[blk_kf[u]], kf_pidx[blk_kf[v]], na) + 1]++;
+        pb_start.assign((size_t)na + 1, 0);
+        for (int l = 0; l < nlm; ++l) {
+            const int b0 = lm_bstart[l], b1 = lm_bstart[l + 1];
+            for (int u = b0; u < b1; ++u) {
+                const int pu = kf_pidx[blk_kf[u]];
+                pb_start[pu + 1]++;
+                const int base = pu * na - pu * (pu - 1) / 2 - pu;
+                for (int v = u; v < b1; ++v) pc_start[base + kf_pidx[blk_kf[v]] + 1]++;
+            }
+        }
         for (int p = 0; p < npairs; ++p) pc_start[p + 1] += pc_start[p];
+        for (int a = 0; a < na; ++a) pb_start[a + 1] += pb_start[a];
         ncontrib = pc_start[npairs];
         pc_y.resize(ncontrib); pc_w.resize(ncontrib); pc_lm.resize(ncontrib);
-        fill.assign(pc_start.begin(), pc_start.begin() + npairs);
-        for (int l = 0; l < nlm; ++l)
-            for (int u = lm_bstart[l]; u < lm_bstart[l + 1]; ++u)
-                for (int v = u; v < lm_bstart[l + 1]; ++v) {
-                    int p = ba_pair_index(kf_pidx[blk_kf[u]], kf_pidx[blk_kf[v]], na);
-                    pc_y[fill[p]] = u; pc_w[fill[p]] = v; pc_lm[fill[p]] = l; fill[p]++;
-                }
-        // blocks per active pose (landmark-ascending)
-        pb_start.assign((size_t)na + 1, 0);
-        for (int b = 0; b < nblk; ++b) pb_start[kf_pidx[blk_kf[b]] + 1]++;
-        for (int a = 0; a < na; ++a) pb_start[a + 1] += pb_start[a];
         pb_blk.resize(nblk);
-        fill.assign(pb_start.begin(), pb_start.begin() + na);
-        for (int b = 0; b < nblk; ++b) pb_blk[fill[kf_pidx[blk_kf[b]]]++] = b;
-        // edge records in both orders
-        const uint8_t *ori = obs_right + j.obs_ofs;
-        const float *ouv = obs_uv + 2 * (size_t)j.obs_ofs;
-        recs.resize(2 * (size_t)nobs);
-        for (int i = 0; i < nobs; ++i) {
-            const int e = lm_edges[i];
-            BaRec r;
-            r.u = ouv[2 * e]; r.v = ouv[2 * e + 1];
-            r.lmkc = olm[e] | (((kf_pidx[okf[e]] << 1) | (ori[e] ? 1 : 0)) << 24);
-            r.blk = eblk[e];
-            recs[(size_t)i] = r;
+        fill.assign(pc_start.begin(), pc_start.begin() + npairs);
+        fill2.assign(pb_start.begin(), pb_start.begin() + na);
+        for (int l = 0; l < nlm; ++l) {
+            const int b0 = lm_bstart[l], b1 = lm_bstart[l + 1];
+            for (int u = b0; u < b1; ++u) {
+                const int pu = kf_pidx[blk_kf[u]];
+                pb_blk[fill2[pu]++] = u;
+                const int base = pu * na - pu * (pu - 1) / 2 - pu;
+                for (int v = u; v < b1; ++v) {
+                    const int q = fill[base + kf_pidx[blk_kf[v]]]++;
+                    pc_y[q] = u; pc_w[q] = v; pc_lm[q] = l;
+                }
+            }
         }
-        for (int i = 0; i < nobs; ++i) {
-            const int e = kf_edges[i];
-            BaRec r;
-            r.u = ouv[2 * e]; r.v = ouv[2 * e + 1];
-            r.lmkc = olm[e] | (((kf_pidx[okf[e]] << 1) | (ori[e] ? 1 : 0)) << 24);
-            r.blk = eblk[e];
-            recs[(size_t)nobs + i] = r;
-        }
+        return true;
     }
     size_t aux_ints(const BaJob &j) const { return ba_aux_layout(j.nkf, j.nlm, j.nobs, nblk, na, ncontrib).total; }
     void write(const BaJob &j, int *aux, BaRec *rec_out, BaDev &d) const
@@ -232,8 +231,8 @@ struct BaHostStruct {        // scratch reused across jobs
         BaAuxLayout L = ba_aux_layout(j.nkf, j.nlm, j.nobs, nblk, na, ncontrib);
         auto cp = [&](size_t off, const std::vector<int> &v, size_t n) { if (n) std::memcpy(aux + off, v.data(), n * sizeof(int)); };
         cp(L.lm_estart, lm_estart, (size_t)j.nlm + 1); cp(L.lm_edges, lm_edges, j.nobs);
-        cp(L.kf_estart, kf_estart, (size_t)j.nkf + 1); cp(L.kf_edges, kf_edges, j.nobs);
-        cp(L.eblk, eblk, j.nobs); cp(L.lm_bstart, lm_bstart, (size_t)j.nlm + 1);
+        cp(L.kf_estart, kf_estart, (size_t)j.nkf + 1);
+        cp(L.lm_bstart, lm_bstart, (size_t)j.nlm + 1);
         cp(L.blk_kf, blk_kf, nblk); cp(L.blk_lm, blk_lm, nblk);
         cp(L.kf_pidx, kf_pidx, j.nkf); cp(L.act_kf, act_kf, j.nkf);
         cp(L.pc_start, pc_start, (size_t)na * (na + 1) / 2 + 1); cp(L.pc_y, pc_y, ncontrib); cp(L.pc_w, pc_w, ncontrib);

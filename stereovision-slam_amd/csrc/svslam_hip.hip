@@ -170,8 +170,13 @@ hipError_t wait_stream(svslam_ctx *c)
     for (;;) {
         const hipError_t e = hipStreamQuery(c->stream);
         if (e != hipErrorNotReady) return e;
-        if (now_ns() - t0 < 15000) continue;
-        struct timespec ts = { 0, 20000 };
+        const long long dt = now_ns() - t0;
+        if (dt < 10000) continue;
+        // back off with the age of the wait: a 100 us kernel is polled every ~20 us, a
+        // multi-millisecond BA batch every ~150 us (overshoot stays below ~1/8 of the wait)
+        long long nap = dt >> 3;
+        nap = nap < 20000 ? 20000 : (nap > 150000 ? 150000 : nap);
+        struct timespec ts = { 0, (long)nap };
         nanosleep(&ts, nullptr);
     }
 }
@@ -693,11 +698,7 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
         auto build_one = [&](int i) {
             BaJob bj;
             memcpy(&bj, &jobs[i], sizeof(bj));
-            for (int e = 0; e < bj.nobs; ++e) {      // index validation, per problem
-                const int k = obs_kf[bj.obs_ofs + e], l = obs_lm[bj.obs_ofs + e];
-                if (k < 0 || k >= bj.nkf || l < 0 || l >= bj.nlm) { bad[(size_t)i] = 1; return; }
-            }
-            hs[i].build(bj, obs_kf, obs_lm, obs_is_right, obs_uv);
+            if (!hs[i].build(bj, obs_kf, obs_lm, obs_is_right, obs_uv)) bad[(size_t)i] = 1;   // index out of range
         };
         if (c->pool && njobs > 1) c->pool->parallel_for(njobs, build_one);
         else for (int i = 0; i < njobs; ++i) build_one(i);
