@@ -69,6 +69,7 @@ struct BaWork {              // per-job HBM scratch, strided by the context limi
     double *db = nullptr;    // [3*max_lm]
     double *poses_b = nullptr; // [7*max_kf]
     double *pts_b = nullptr;   // [3*max_lm]
+    double *pts_i = nullptr;   // [3*max_lm]  landmark positions in the internal numbering
     void *all = nullptr;
 };
 
@@ -78,7 +79,7 @@ static inline hipError_t ba_work_alloc(BaWork &w, int jobs, int max_kf, int max_
     if (max_kf <= 0 || max_lm <= 0 || max_obs <= 0) return hipSuccess;
     size_t J = jobs;
     size_t nd = J * ((size_t)max_obs * (2 + 18) + (size_t)max_kf * 7 +
-                     (size_t)max_lm * (9 + 9 + 3 + 3 + 3));
+                     (size_t)max_lm * (9 + 9 + 3 + 3 + 3 + 3));
     hipError_t e = hipMalloc(&w.all, nd * sizeof(double));
     if (e != hipSuccess) return e;
     double *p = static_cast<double *>(w.all);
@@ -90,17 +91,18 @@ static inline hipError_t ba_work_alloc(BaWork &w, int jobs, int max_kf, int max_
     w.bl = p; p += J * 3 * max_lm;
     w.db = p; p += J * 3 * max_lm;
     w.pts_b = p; p += J * 3 * max_lm;
+    w.pts_i = p; p += J * 3 * max_lm;
     return hipSuccess;
 }
 static inline void ba_work_free(BaWork &w) { if (w.all) (void)hipFree(w.all); w.all = nullptr; }
 
 // ---------------------------------------------------------------- host-side structure
 // aux layout per job (ints), offsets from ba_aux_layout():
-//   lm_estart[nlm+1] lm_edges[nobs] kf_estart[nkf+1]
+//   lm_estart[nlm+1] lm_edges[nobs] kf_estart[nkf+1] lm_orig[nlm]
 //   lm_bstart[nlm+1] blk_kf[nblk] blk_lm[nblk] kf_pidx[nkf] act_kf[nkf]
 //   pc_start[npairs+1] pc_y[ncontrib] pc_w[ncontrib] pc_lm[ncontrib] pb_start[na+1] pb_blk[nblk]
 struct BaAuxLayout {
-    size_t lm_estart, lm_edges, kf_estart, lm_bstart, blk_kf, blk_lm, kf_pidx, act_kf;
+    size_t lm_estart, lm_edges, kf_estart, lm_orig, lm_bstart, blk_kf, blk_lm, kf_pidx, act_kf;
     size_t pc_start, pc_y, pc_w, pc_lm, pb_start, pb_blk, total;
 };
 __host__ __device__ inline BaAuxLayout ba_aux_layout(int nkf, int nlm, int nobs, int nblk, int na, int ncontrib)
@@ -110,6 +112,7 @@ __host__ __device__ inline BaAuxLayout ba_aux_layout(int nkf, int nlm, int nobs,
     L.lm_estart = o; o += (size_t)nlm + 1;
     L.lm_edges = o; o += nobs;
     L.kf_estart = o; o += (size_t)nkf + 1;
+    L.lm_orig = o; o += nlm;
     L.lm_bstart = o; o += (size_t)nlm + 1;
     L.blk_kf = o; o += nblk;
     L.blk_lm = o; o += nblk;
@@ -128,7 +131,7 @@ __host__ __device__ inline BaAuxLayout ba_aux_layout(int nkf, int nlm, int nobs,
 __host__ __device__ inline int ba_pair_index(int a, int b, int na) { return a * na - a * (a - 1) / 2 + (b - a); }
 
 struct BaHostStruct {        // scratch reused across jobs
-    std::vector<int> lm_estart, lm_edges, kf_estart, lm_bstart, blk_kf, blk_lm, kf_pidx,
+    std::vector<int> lm_estart, lm_edges, kf_estart, lm_orig, lm_new, srt, ostart, lm_bstart, blk_kf, blk_lm, kf_pidx,
         act_kf, pc_start, pc_y, pc_w, pc_lm, pb_start, pb_blk, fill, fill2;
     std::vector<BaRec> recs;     // [0,nobs) landmark-major (= lm_edges order), [nobs,2nobs) pose-major
     int nblk = 0, na = 0, ncontrib = 0;
@@ -148,35 +151,63 @@ struct BaHostStruct {        // scratch reused across jobs
             if (k < 0 || k >= nkf || l < 0 || l >= nlm) return false;
             if (e && !((olm[e - 1] < l) || (olm[e - 1] == l && okf[e - 1] <= k))) sorted = false;
         }
-        lm_edges.resize(nobs);
-        for (int e = 0; e < nobs; ++e) lm_edges[e] = e;
+        srt.resize(nobs);
+        for (int e = 0; e < nobs; ++e) srt[e] = e;
         if (!sorted)
-            std::stable_sort(lm_edges.begin(), lm_edges.end(), [&](int a, int b) {
+            std::stable_sort(srt.begin(), srt.end(), [&](int a, int b) {
                 if (olm[a] != olm[b]) return olm[a] < olm[b];
                 return okf[a] < okf[b];
             });
-        // pass 1 (landmark-major): edge ranges, blocks, landmark-major records (keyframe still raw)
+        // Landmarks are renumbered by descending block count (stable), so the lanes of a wave in
+        // the thread-per-landmark passes walk equally many blocks: most landmarks of a local
+        // window are seen from one keyframe only, a few from all of them.
+        ostart.assign((size_t)nlm + 1, 0);          // edge ranges in caller numbering (srt order)
+        lm_new.assign(nlm, 0);                       // first: blocks per landmark
+        {
+            int prev_lm = -1, prev_kf = -1;
+            for (int i = 0; i < nobs; ++i) {
+                const int e = srt[i], k = okf[e], l = olm[e];
+                ostart[l + 1]++;
+                if (l != prev_lm || k != prev_kf) { lm_new[l]++; prev_lm = l; prev_kf = k; }
+            }
+        }
+        for (int i = 0; i < nlm; ++i) ostart[i + 1] += ostart[i];
+        {
+            int maxc = 0;
+            for (int l = 0; l < nlm; ++l) maxc = std::max(maxc, lm_new[l]);
+            fill.assign((size_t)maxc + 2, 0);        // counting sort, descending count
+            for (int l = 0; l < nlm; ++l) fill[(size_t)(maxc - lm_new[l]) + 1]++;
+            for (int c = 0; c <= maxc; ++c) fill[(size_t)c + 1] += fill[c];
+            lm_orig.resize(nlm);
+            for (int l = 0; l < nlm; ++l) { const int nid = fill[(size_t)(maxc - lm_new[l])]++; lm_orig[nid] = l; }
+        }
+        // pass 1 (landmark-major, new numbering): edge ranges, blocks, records (keyframe still raw)
+        lm_edges.resize(nobs);
         lm_estart.assign((size_t)nlm + 1, 0);
         lm_bstart.assign((size_t)nlm + 1, 0);
         kf_estart.assign((size_t)nkf + 1, 0);
         blk_kf.clear(); blk_lm.clear();
         recs.resize(2 * (size_t)nobs);
-        int prev_lm = -1, prev_kf = -1;
-        for (int i = 0; i < nobs; ++i) {
-            const int e = lm_edges[i], k = okf[e], l = olm[e];
-            lm_estart[l + 1]++; kf_estart[k + 1]++;
-            if (l != prev_lm || k != prev_kf) {
-                blk_kf.push_back(k); blk_lm.push_back(l);
-                lm_bstart[l + 1]++;
-                prev_lm = l; prev_kf = k;
+        {
+            int i = 0;
+            for (int jn = 0; jn < nlm; ++jn) {
+                const int l = lm_orig[jn];
+                int prev_kf = -1;
+                for (int q = ostart[l]; q < ostart[l + 1]; ++q, ++i) {
+                    const int e = srt[q], k = okf[e];
+                    lm_edges[i] = e;
+                    kf_estart[k + 1]++;
+                    if (k != prev_kf) { blk_kf.push_back(k); blk_lm.push_back(jn); prev_kf = k; }
+                    BaRec &r = recs[(size_t)i];
+                    r.u = ouv[2 * e]; r.v = ouv[2 * e + 1];
+                    r.lmkc = (k << 1) | (ori[e] ? 1 : 0);      // completed in pass 2
+                    r.blk = (int)blk_kf.size() - 1;
+                }
+                lm_estart[jn + 1] = i;
+                lm_bstart[jn + 1] = (int)blk_kf.size();
             }
-            BaRec &r = recs[(size_t)i];
-            r.u = ouv[2 * e]; r.v = ouv[2 * e + 1];
-            r.lmkc = (k << 1) | (ori[e] ? 1 : 0);      // completed in pass 2
-            r.blk = (int)blk_kf.size() - 1;
         }
         nblk = (int)blk_kf.size();
-        for (int i = 0; i < nlm; ++i) { lm_estart[i + 1] += lm_estart[i]; lm_bstart[i + 1] += lm_bstart[i]; }
         for (int i = 0; i < nkf; ++i) kf_estart[i + 1] += kf_estart[i];
         kf_pidx.assign(nkf, -1); act_kf.assign(nkf, -1);
         na = 0;
@@ -187,7 +218,7 @@ struct BaHostStruct {        // scratch reused across jobs
         for (int i = 0; i < nobs; ++i) {
             BaRec &r = recs[(size_t)i];
             const int k = r.lmkc >> 1, cam = r.lmkc & 1;
-            r.lmkc = olm[lm_edges[i]] | (((kf_pidx[k] << 1) | cam) << 24);
+            r.lmkc = blk_lm[r.blk] | (((kf_pidx[k] << 1) | cam) << 24);
             recs[(size_t)nobs + fill[k]++] = r;
         }
         // (Y,W) block pairs per pose pair, counting sort by pair; landmark-ascending inside a pair
@@ -231,7 +262,7 @@ struct BaHostStruct {        // scratch reused across jobs
         BaAuxLayout L = ba_aux_layout(j.nkf, j.nlm, j.nobs, nblk, na, ncontrib);
         auto cp = [&](size_t off, const std::vector<int> &v, size_t n) { if (n) std::memcpy(aux + off, v.data(), n * sizeof(int)); };
         cp(L.lm_estart, lm_estart, (size_t)j.nlm + 1); cp(L.lm_edges, lm_edges, j.nobs);
-        cp(L.kf_estart, kf_estart, (size_t)j.nkf + 1);
+        cp(L.kf_estart, kf_estart, (size_t)j.nkf + 1); cp(L.lm_orig, lm_orig, j.nlm);
         cp(L.lm_bstart, lm_bstart, (size_t)j.nlm + 1);
         cp(L.blk_kf, blk_kf, nblk); cp(L.blk_lm, blk_lm, nblk);
         cp(L.kf_pidx, kf_pidx, j.nkf); cp(L.act_kf, act_kf, j.nkf);
@@ -361,7 +392,7 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
 
     const BaCams &cams = *camsp;
     double *poses = poses_all + (size_t)jd.kf_ofs * 7;
-    double *pts = pts_all + (size_t)jd.lm_ofs * 3;
+    double *pts_io = pts_all + (size_t)jd.lm_ofs * 3;     // caller numbering
     double *edge_chi2 = edge_chi2_all + jd.obs_ofs;
     const BaRec *recL = recs_all + jd.rec_ofs;       // landmark-major
     const BaRec *recP = recL + nobs;                   // pose-major
@@ -384,6 +415,12 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
     double *db = wk.db + J * 3 * wk.max_lm;
     double *poses_b = wk.poses_b + J * 7 * wk.max_kf;
     double *pts_b = wk.pts_b + J * 3 * wk.max_lm;
+    double *pts = wk.pts_i + J * 3 * wk.max_lm;            // internal numbering (see BaHostStruct::build)
+    const int *lm_orig = aux + AL.lm_orig;
+    for (int j = tid; j < nlm; j += BA_THREADS) {
+        const double *s3 = pts_io + 3 * (size_t)lm_orig[j];
+        pts[3 * (size_t)j] = s3[0]; pts[3 * (size_t)j + 1] = s3[1]; pts[3 * (size_t)j + 2] = s3[2];
+    }
 
     // camera table (constant) and pose table (rebuilt whenever the poses change)
     if (tid < 2) {
@@ -648,17 +685,17 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
             }
             __syncthreads();
             BA_PROF(3);
-            // ---- blocked (6x6 = one pose) right-looking Cholesky S = L L^T in LDS, one wave, one
-            // matrix row per lane; the right-hand side rides along as row np, so L y = bs
-            // comes out of the same sweep; then L^T x = y.  Per block column: every lane
-            // factors the 6x6 diagonal block redundantly in registers (broadcast LDS reads),
-            // solves its own row of the panel, and updates its own row of the trailing matrix.
-            if (wv == 0) {
-                int ok = 1;
+            // ---- blocked (6x6 = one pose) right-looking Cholesky S = L L^T in LDS on the whole
+            // workgroup; the right-hand side rides along as row np, so L y = bs comes out of the
+            // same sweep; then L^T x = y on one wave.  Per block column: every thread factors the
+            // 6x6 diagonal block redundantly in registers (broadcast LDS reads), one thread per
+            // row solves the panel, one thread per (row, block) updates the trailing matrix.
+            int ok = 1;
+            {
                 double *rhs = S + (size_t)np * ld;        // extra row: bs on entry, y on exit
                 double *invd = xp;                         // 1 / L_kk (xp is free until the back-substitution)
-                for (int i = lane; i < np; i += 64) rhs[i] = bs[i];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                for (int i = tid; i < np; i += BA_THREADS) rhs[i] = bs[i];
+                __syncthreads();
                 for (int kb = 0; kb < na; ++kb) {
                     const int c0 = 6 * kb;
                     // 1. + 2. diagonal block -> Ld (lower), inverse pivots
@@ -687,15 +724,16 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
                             Ld[r][c] = v * y;
                         }
                     }
-                    if (!ok) break;
-                    if (lane < 6) {
+                    __syncthreads();                       // everybody has read the diagonal block
+                    if (!ok) break;                        // uniform: all threads factor the same block
+                    if (tid < 6) {
                         double v = inv[0];
 #pragma unroll
-                        for (int c = 1; c < 6; ++c) v = (lane == c) ? inv[c] : v;
-                        invd[c0 + lane] = v;
+                        for (int c = 1; c < 6; ++c) v = (tid == c) ? inv[c] : v;
+                        invd[c0 + tid] = v;
                     }
-                    // 3. panel: own rows i >= c0 (rows inside the diagonal block reproduce Ld)
-                    for (int i = c0 + lane; i <= np; i += 64) {
+                    // 3. panel: one thread per row i >= c0 (rows inside the diagonal block reproduce Ld)
+                    for (int i = c0 + tid; i <= np; i += BA_THREADS) {
                         double *ri = S + (size_t)i * ld + c0;
                         double x[6];
 #pragma unroll
@@ -711,31 +749,32 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
 #pragma unroll
                         for (int c = 0; c < 6; ++c) ri[c] = (r < 6 && c > r) ? 0.0 : x[c];
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    // 4. trailing update: S[i][6jb + c'] -= sum_c L[i][c0 + c] * L[6jb + c'][c0 + c]
-                    for (int i = c0 + 6 + lane; i <= np; i += 64) {
+                    __syncthreads();
+                    // 4. trailing update, one thread per (row i, block column jb):
+                    //    S[i][6jb + c'] -= sum_c L[i][c0 + c] * L[6jb + c'][c0 + c]   (lower triangle only)
+                    const int nbm = na - kb - 1, nrows = np + 1 - (c0 + 6);
+                    for (int t = tid; t < nrows * nbm; t += BA_THREADS) {
+                        const int i = c0 + 6 + t / nbm, jb = kb + 1 + t % nbm;
+                        const int jb_last = (i < np) ? i / 6 : na - 1;
+                        if (jb > jb_last) continue;
                         const double *pi = S + (size_t)i * ld + c0;
                         double x[6];
 #pragma unroll
                         for (int c = 0; c < 6; ++c) x[c] = pi[c];
-                        const int jb_last = (i < np) ? i / 6 : na - 1;     // only the lower triangle is used
-                        for (int jb = kb + 1; jb <= jb_last; ++jb) {
-                            double *u = S + (size_t)i * ld + 6 * jb;
-                            const double *P = S + (size_t)(6 * jb) * ld + c0;
-                            double uu[6];
+                        double *u = S + (size_t)i * ld + 6 * jb;
+                        const double *P = S + (size_t)(6 * jb) * ld + c0;
 #pragma unroll
-                            for (int cp = 0; cp < 6; ++cp) uu[cp] = u[cp];
-#pragma unroll
-                            for (int cp = 0; cp < 6; ++cp) {
-                                const double *pr = P + (size_t)cp * ld;
-                                uu[cp] -= x[0] * pr[0] + x[1] * pr[1] + x[2] * pr[2] + x[3] * pr[3] + x[4] * pr[4] + x[5] * pr[5];
-                            }
-#pragma unroll
-                            for (int cp = 0; cp < 6; ++cp) u[cp] = uu[cp];
+                        for (int cp = 0; cp < 6; ++cp) {
+                            const double *pr = P + (size_t)cp * ld;
+                            u[cp] -= x[0] * pr[0] + x[1] * pr[1] + x[2] * pr[2] + x[3] * pr[3] + x[4] * pr[4] + x[5] * pr[5];
                         }
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __syncthreads();
                 }
+            }
+            if (wv == 0) {
+                double *rhs = S + (size_t)np * ld;
+                double *invd = xp;
                 if (prof && tid == 0) { long long t_ = wall_clock64(); prof[7] += t_ - tprev; }
                 if (ok) {
                     // rhs holds y; back-substitution L^T x = y with the stored inverse pivots
@@ -824,6 +863,10 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
     }
     __syncthreads();
     for (int i = tid; i < nobs; i += BA_THREADS) edge_chi2[lm_edges[i]] = err[2 * i] * err[2 * i] + err[2 * i + 1] * err[2 * i + 1];
+    for (int j = tid; j < nlm; j += BA_THREADS) {
+        double *d3 = pts_io + 3 * (size_t)lm_orig[j];
+        d3[0] = pts[3 * (size_t)j]; d3[1] = pts[3 * (size_t)j + 1]; d3[2] = pts[3 * (size_t)j + 2];
+    }
     if (tid == 0) jd.iters_done = it_done;
 }
 
