@@ -81,11 +81,11 @@ def effective_cpus():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("SVS_BENCH_STREAMS", "2048")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("SVS_BENCH_STREAMS", "4096")),
                     help="independent stereo streams per GPU, advanced in lockstep")
-    ap.add_argument("--groups", type=int, default=int(os.environ.get("SVS_BENCH_GROUPS", "4")),
+    ap.add_argument("--groups", type=int, default=int(os.environ.get("SVS_BENCH_GROUPS", "0")),
                     help="host threads per GPU, each driving streams/groups streams through its own "
                          "svslam context (own HIP stream): one group's BA overlaps the others' tracking")
     ap.add_argument("--host-threads", type=int, default=int(os.environ.get("SVS_BENCH_HOST_THREADS", "0")),
@@ -109,12 +109,19 @@ def main():
     svs.load()                                      # fails loudly if the HIP library is missing
 
     S, Wm, K = args.streams, args.warmup, args.steps
-    G = max(1, min(args.groups, S))
+    # the synthetic frames of the whole run are rendered into HBM up front: keep them under ~190 GB
+    S = max(1, min(S, int(190e9 // (2 * W * H * (Wm + K)))))
+    # host layout from the cores this rank may actually use (cgroup quota / ranks on the node):
+    # about two threads per core (half of them are waiting on the GPU at any time), at most 8
+    # groups (>= 512 streams each at the default size) x at most 4 bookkeeping threads
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    cores = max(1, effective_cpus() // max(1, local_world))
+    G = args.groups if args.groups > 0 else min(8, cores)
+    G = max(1, min(G, S))
     while S % G:
         G -= 1
-    if args.host_threads <= 0:        # auto: share the box's cores between the ranks of this node
-        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-        args.host_threads = max(2, min(12, effective_cpus() // max(1, local_world * G)))
+    if args.host_threads <= 0:
+        args.host_threads = max(1, min(4, (2 * cores + G - 1) // G))
     Sg = S // G
     F = Wm + K
     cfg = pl.default_config(W, H, host_threads=max(1, args.host_threads), backend_on=args.backend_mode)

@@ -19,6 +19,7 @@
 #include "../../include/svslam.h"
 #include "../host/thread_pool.h"
 #include <memory>
+#include <mutex>
 #include "dev_common.h"
 #include "k_pyramid.h"
 #include "k_lk.h"
@@ -74,6 +75,7 @@ struct svslam_ctx {
     // host-side wall time (ns): 0 h2d enqueue, 1 d2h enqueue, 2 stream wait, 3 launches, 4 staging memcpy/prep
     long long host_ns[8] = { 0 };
     bool wait_poll = true;
+    hipEvent_t done = nullptr;   // recorded after the last enqueue of a call; the stream may be shared
     // a submitted, not yet collected local-BA batch owns the staging arena
     struct { bool active = false; int njobs = 0, total_kf = 0, total_lm = 0, total_obs = 0;
              size_t ojobs = 0, oposes = 0, opts = 0, ochi = 0; } ba_pending;
@@ -163,12 +165,12 @@ inline long long now_ns()
 // spin followed by sleep-polling (SVSLAM_WAIT=spin restores hipStreamSynchronize).
 hipError_t wait_stream(svslam_ctx *c)
 {
-    if (!c->wait_poll) return hipStreamSynchronize(c->stream);
+    if (!c->wait_poll) return hipEventSynchronize(c->done);
     static thread_local bool slack_set = false;
     if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0); slack_set = true; }
     const long long t0 = now_ns();
     for (;;) {
-        const hipError_t e = hipStreamQuery(c->stream);
+        const hipError_t e = hipEventQuery(c->done);
         if (e != hipErrorNotReady) return e;
         const long long dt = now_ns() - t0;
         if (dt < 10000) continue;
@@ -179,6 +181,30 @@ hipError_t wait_stream(svslam_ctx *c)
         struct timespec ts = { 0, (long)nap };
         nanosleep(&ts, nullptr);
     }
+}
+// HIP streams are handed out from a small per-device pool: beyond ~16 hardware queues the
+// GPU time-slices them and every stream stalls, while a host that runs many single-threaded
+// pipelines wants one context each.  Contexts that share a stream stay independent: each
+// waits on its own event (done), never on the stream.  Pool streams live until process exit.
+hipError_t pool_stream(int device, hipStream_t *out)
+{
+    static std::mutex m;
+    static std::vector<hipStream_t> pool[64];
+    static size_t next[64] = { 0 };
+    std::lock_guard<std::mutex> lk(m);
+    const char *e = std::getenv("SVSLAM_MAX_STREAMS");
+    const size_t cap = (size_t)std::max(1, e ? atoi(e) : 16);
+    std::vector<hipStream_t> &p = pool[device & 63];
+    if (p.size() < cap) {
+        hipStream_t s = nullptr;
+        hipError_t rc = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+        if (rc != hipSuccess) return rc;
+        p.push_back(s);
+        *out = s;
+        return hipSuccess;
+    }
+    *out = p[next[device & 63]++ % p.size()];
+    return hipSuccess;
 }
 int h2d(svslam_ctx *c, size_t from, size_t to)
 {
@@ -191,6 +217,7 @@ int d2h_enqueue(svslam_ctx *c, size_t from, size_t to)
 {
     const long long t0 = now_ns();
     if (to > from) HIPCHK(c, hipMemcpyAsync(c->ar.h + from, c->ar.d + from, to - from, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(c->done, c->stream));
     c->host_ns[1] += now_ns() - t0;
     return 0;
 }
@@ -331,7 +358,8 @@ int svslam_create(const svslam_limits *lim, svslam_ctx **out)
         const char *wm = std::getenv("SVSLAM_WAIT");        // spin | poll (default)
         c->wait_poll = !(wm && std::strcmp(wm, "spin") == 0);
     }
-    HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(c, pool_stream(c->device, &c->stream));
+    HIPCHK(c, hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
     for (int i = 0; i < 16; ++i) HIPCHK(c, hipEventCreate(&c->ev[i]));
     make_geom(c->geom, lim->width, lim->height);
     HIPCHK(c, hipMalloc(&c->d_pyr, c->geom.slot_bytes * (size_t)lim->max_slots));
@@ -385,7 +413,7 @@ void svslam_destroy(svslam_ctx *c)
     ba_work_free(c->bw);
     if (c->d_ba_prof) (void)hipFree(c->d_ba_prof);
     for (int i = 0; i < 16; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->done) (void)hipEventDestroy(c->done);   // the stream belongs to the pool
     delete c;
 }
 
