@@ -78,6 +78,23 @@ def effective_cpus():
     return n
 
 
+def thread_cpu_seconds():
+    """CPU seconds per thread name of this process (Linux /proc), for the host-cost breakdown"""
+    out = {}
+    tick = os.sysconf("SC_CLK_TCK")
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                comm = open("/proc/self/task/%s/comm" % tid).read().strip()
+                f = open("/proc/self/task/%s/stat" % tid).read().rsplit(")", 1)[1].split()
+                out[comm] = out.get(comm, 0.0) + (int(f[11]) + int(f[12])) / tick
+            except (OSError, IndexError, ValueError):
+                pass
+    except OSError:
+        pass
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -158,6 +175,8 @@ def main():
 
         def work(g):
             try:
+                import ctypes
+                ctypes.CDLL(None).prctl(15, b"svs-group", 0, 0, 0)      # PR_SET_NAME, for the CPU breakdown
                 base = g * Sg * F * img
                 outs[g] = pipes[g].run_device(d_left + base, d_right + base, F * img, img, first, nframes,
                                               want_results=want)
@@ -188,12 +207,16 @@ def main():
     barrier()
     import resource
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
+    tc0 = thread_cpu_seconds()
     t0 = time.perf_counter()
     res_g = run_all(Wm, K, True)
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     t1 = time.perf_counter()
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    tc1 = thread_cpu_seconds()
+    cpu_by_thread = {k: round((tc1[k] - tc0.get(k, 0.0)) / max(t1 - t0, 1e-9), 2) for k in tc1
+                     if tc1[k] - tc0.get(k, 0.0) > 0.005 * (t1 - t0)}
     cpu_busy = ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / max(t1 - t0, 1e-9)
     barrier()
     elapsed = rk.max_over_ranks(t1 - t0)
@@ -253,7 +276,8 @@ def main():
                                  "in_abi_calls": round(cnt["ns_kernel_calls"] / 1e6 / K / G, 3),
                                  "h2d_enqueue": round(hostns[0] / 1e6 / K / G, 3), "d2h_enqueue": round(hostns[1] / 1e6 / K / G, 3),
                                  "stream_wait": round(hostns[2] / 1e6 / K / G, 3), "event_collect": round(hostns[5] / 1e6 / K / G, 3), "ba_host_prep": round(hostns[4] / 1e6 / K / G, 3),
-                                 "cpus_busy": round(cpu_busy, 2), "cpus_allowed": effective_cpus()},
+                                 "cpus_busy": round(cpu_busy, 2), "cpus_allowed": effective_cpus(),
+                                 "cpus_busy_by_thread_name": cpu_by_thread},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(svs, pl, ctx, cfg, d_left, F, img, S, min(args.cpu_frames, S * F),

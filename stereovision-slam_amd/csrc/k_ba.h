@@ -132,7 +132,7 @@ __host__ __device__ inline int ba_pair_index(int a, int b, int na) { return a * 
 
 struct BaHostStruct {        // scratch reused across jobs
     std::vector<int> lm_estart, lm_edges, kf_estart, lm_orig, lm_new, srt, ostart, lm_bstart, blk_kf, blk_lm, kf_pidx,
-        act_kf, pc_start, pc_y, pc_w, pc_lm, pb_start, pb_blk, fill, fill2;
+        act_kf, pc_start, pc_y, pc_w, pc_lm, pb_start, pb_blk, fill, fill2, bpa;
     std::vector<BaRec> recs;     // [0,nobs) landmark-major (= lm_edges order), [nobs,2nobs) pose-major
     int nblk = 0, na = 0, ncontrib = 0;
 
@@ -186,28 +186,35 @@ struct BaHostStruct {        // scratch reused across jobs
         lm_estart.assign((size_t)nlm + 1, 0);
         lm_bstart.assign((size_t)nlm + 1, 0);
         kf_estart.assign((size_t)nkf + 1, 0);
-        blk_kf.clear(); blk_lm.clear();
+        blk_kf.resize(nobs); blk_lm.resize(nobs);     // upper bound, trimmed below
         recs.resize(2 * (size_t)nobs);
         {
-            int i = 0;
+            int i = 0, nb = 0;
+            BaRec *__restrict rl = recs.data();
+            int *__restrict le = lm_edges.data(), *__restrict ke = kf_estart.data();
+            int *__restrict bk = blk_kf.data(), *__restrict bm = blk_lm.data();
+            int *__restrict les = lm_estart.data(), *__restrict lbs = lm_bstart.data();
+            const int *__restrict lo = lm_orig.data(), *__restrict os = ostart.data(), *__restrict sr = srt.data();
             for (int jn = 0; jn < nlm; ++jn) {
-                const int l = lm_orig[jn];
+                const int l = lo[jn];
                 int prev_kf = -1;
-                for (int q = ostart[l]; q < ostart[l + 1]; ++q, ++i) {
-                    const int e = srt[q], k = okf[e];
-                    lm_edges[i] = e;
-                    kf_estart[k + 1]++;
-                    if (k != prev_kf) { blk_kf.push_back(k); blk_lm.push_back(jn); prev_kf = k; }
-                    BaRec &r = recs[(size_t)i];
+                for (int q = os[l]; q < os[l + 1]; ++q, ++i) {
+                    const int e = sr[q], k = okf[e];
+                    le[i] = e;
+                    ke[k + 1]++;
+                    if (k != prev_kf) { bk[nb] = k; bm[nb] = jn; ++nb; prev_kf = k; }
+                    BaRec r;
                     r.u = ouv[2 * e]; r.v = ouv[2 * e + 1];
                     r.lmkc = (k << 1) | (ori[e] ? 1 : 0);      // completed in pass 2
-                    r.blk = (int)blk_kf.size() - 1;
+                    r.blk = nb - 1;
+                    rl[i] = r;
                 }
-                lm_estart[jn + 1] = i;
-                lm_bstart[jn + 1] = (int)blk_kf.size();
+                les[jn + 1] = i;
+                lbs[jn + 1] = nb;
             }
+            nblk = nb;
         }
-        nblk = (int)blk_kf.size();
+        blk_kf.resize(nblk); blk_lm.resize(nblk);
         for (int i = 0; i < nkf; ++i) kf_estart[i + 1] += kf_estart[i];
         kf_pidx.assign(nkf, -1); act_kf.assign(nkf, -1);
         na = 0;
@@ -215,23 +222,38 @@ struct BaHostStruct {        // scratch reused across jobs
             if (kf_estart[k + 1] > kf_estart[k]) { kf_pidx[k] = na; act_kf[na] = k; ++na; }
         // pass 2: finish the records, scatter the pose-major copy (landmark-ascending inside a pose)
         fill.assign(kf_estart.begin(), kf_estart.begin() + nkf);
-        for (int i = 0; i < nobs; ++i) {
-            BaRec &r = recs[(size_t)i];
-            const int k = r.lmkc >> 1, cam = r.lmkc & 1;
-            r.lmkc = blk_lm[r.blk] | (((kf_pidx[k] << 1) | cam) << 24);
-            recs[(size_t)nobs + fill[k]++] = r;
+        {
+            BaRec *__restrict rl = recs.data();
+            BaRec *__restrict rp = recs.data() + nobs;
+            int *__restrict fl = fill.data();
+            const int *__restrict bl_ = blk_lm.data();
+            const int *__restrict pidx = kf_pidx.data();
+            for (int i = 0; i < nobs; ++i) {
+                BaRec r = rl[i];
+                const int k = r.lmkc >> 1, cam = r.lmkc & 1;
+                r.lmkc = bl_[r.blk] | (((pidx[k] << 1) | cam) << 24);
+                rl[i] = r;
+                rp[fl[k]++] = r;
+            }
         }
         // (Y,W) block pairs per pose pair, counting sort by pair; landmark-ascending inside a pair
         const int npairs = na * (na + 1) / 2;
         pc_start.assign((size_t)npairs + 1, 0);
         pb_start.assign((size_t)na + 1, 0);
-        for (int l = 0; l < nlm; ++l) {
-            const int b0 = lm_bstart[l], b1 = lm_bstart[l + 1];
-            for (int u = b0; u < b1; ++u) {
-                const int pu = kf_pidx[blk_kf[u]];
-                pb_start[pu + 1]++;
-                const int base = pu * na - pu * (pu - 1) / 2 - pu;
-                for (int v = u; v < b1; ++v) pc_start[base + kf_pidx[blk_kf[v]] + 1]++;
+        {
+            // active-pose index of every block, once
+            bpa.resize(nblk);
+            for (int b = 0; b < nblk; ++b) bpa[b] = kf_pidx[blk_kf[b]];
+            const int *__restrict lbs = lm_bstart.data(), *__restrict pa = bpa.data();
+            int *__restrict pcs = pc_start.data(), *__restrict pbs = pb_start.data();
+            for (int l = 0; l < nlm; ++l) {
+                const int b0 = lbs[l], b1 = lbs[l + 1];
+                for (int u = b0; u < b1; ++u) {
+                    const int pu = pa[u];
+                    pbs[pu + 1]++;
+                    const int base = pu * na - pu * (pu - 1) / 2 - pu;
+                    for (int v = u; v < b1; ++v) pcs[base + pa[v] + 1]++;
+                }
             }
         }
         for (int p = 0; p < npairs; ++p) pc_start[p + 1] += pc_start[p];
@@ -241,15 +263,20 @@ struct BaHostStruct {        // scratch reused across jobs
         pb_blk.resize(nblk);
         fill.assign(pc_start.begin(), pc_start.begin() + npairs);
         fill2.assign(pb_start.begin(), pb_start.begin() + na);
-        for (int l = 0; l < nlm; ++l) {
-            const int b0 = lm_bstart[l], b1 = lm_bstart[l + 1];
-            for (int u = b0; u < b1; ++u) {
-                const int pu = kf_pidx[blk_kf[u]];
-                pb_blk[fill2[pu]++] = u;
-                const int base = pu * na - pu * (pu - 1) / 2 - pu;
-                for (int v = u; v < b1; ++v) {
-                    const int q = fill[base + kf_pidx[blk_kf[v]]]++;
-                    pc_y[q] = u; pc_w[q] = v; pc_lm[q] = l;
+        {
+            const int *__restrict lbs = lm_bstart.data(), *__restrict pa = bpa.data();
+            int *__restrict f1 = fill.data(), *__restrict f2 = fill2.data(), *__restrict pbb = pb_blk.data();
+            int *__restrict py = pc_y.data(), *__restrict pw = pc_w.data(), *__restrict pl = pc_lm.data();
+            for (int l = 0; l < nlm; ++l) {
+                const int b0 = lbs[l], b1 = lbs[l + 1];
+                for (int u = b0; u < b1; ++u) {
+                    const int pu = pa[u];
+                    pbb[f2[pu]++] = u;
+                    const int base = pu * na - pu * (pu - 1) / 2 - pu;
+                    for (int v = u; v < b1; ++v) {
+                        const int q = f1[base + pa[v]]++;
+                        py[q] = u; pw[q] = v; pl[q] = l;
+                    }
                 }
             }
         }

@@ -79,12 +79,46 @@ struct ObsRef {
     bool operator==(const ObsRef &o) const { return frame == o.frame && idx == o.idx && is_left == o.is_left; }
 };
 
+// Observation list of a landmark: most landmarks of a local window are seen from one or two
+// keyframes (2-4 observations), so the first 6 live inside the MapPoint (one cache line
+// pair, no second pointer chase in the BA gather); the rest spill to the heap.
+class ObsList {
+public:
+    size_t size() const { return n_; }
+    const ObsRef &operator[](size_t i) const { return i < kInline ? in_[i] : more_[i - kInline]; }
+    void push_back(const ObsRef &o)
+    {
+        if (n_ < kInline) in_[n_] = o; else more_.push_back(o);
+        ++n_;
+    }
+    void erase_at(size_t i)                 // order-preserving, like std::list::remove
+    {
+        for (size_t k = i; k + 1 < n_; ++k) at(k) = at(k + 1);
+        --n_;
+        if (n_ >= kInline) more_.pop_back();
+    }
+    struct It {
+        const ObsList *l; size_t i;
+        bool operator!=(const It &o) const { return i != o.i; }
+        void operator++() { ++i; }
+        const ObsRef &operator*() const { return (*l)[i]; }
+    };
+    It begin() const { return It{ this, 0 }; }
+    It end() const { return It{ this, n_ }; }
+private:
+    static constexpr size_t kInline = 6;
+    ObsRef &at(size_t i) { return i < kInline ? in_[i] : more_[i - kInline]; }
+    ObsRef in_[kInline];
+    std::vector<ObsRef> more_;
+    size_t n_ = 0;
+};
+
 struct MapPoint {
     long id = 0;
     double pos[3] = { 0, 0, 0 };
     bool is_outlier = false;
     int observed_times = 0;
-    std::vector<ObsRef> observations;
+    ObsList observations;
 };
 
 inline Feature &feat_of(const ObsRef &r) { return r.is_left ? r.frame->left[r.idx] : r.frame->right[r.idx]; }
@@ -128,7 +162,7 @@ public:
     {
         for (size_t i = 0; i < mp->observations.size(); ++i) {
             if (mp->observations[i] == f) {
-                mp->observations.erase(mp->observations.begin() + (long)i);
+                mp->observations.erase_at(i);
                 Feature &ft = feat_of(f);
                 if (ft.outlier) ft.mp = -1;
                 mp->observed_times--;
@@ -430,7 +464,10 @@ private:
             svslam_track_job &j = jobs_track_[i];
             std::memcpy(j.pose, cur->pose.v, sizeof(j.pose));
             size_t g = (size_t)j.pt_ofs;
-            for (const Feature &f : last->left) {                   // :331-347
+            const std::vector<Feature> &LF = last->left;
+            for (size_t fi = 0; fi < LF.size(); ++fi) {             // :331-347
+                const Feature &f = LF[fi];
+                if (fi + 8 < LF.size() && LF[fi + 8].mp >= 0) __builtin_prefetch(st.map.point(LF[fi + 8].mp), 0, 1);
                 prev_xy_[2 * g] = f.x; prev_xy_[2 * g + 1] = f.y;
                 MapPoint *mp = st.map.point(f.mp);
                 if (mp) {
@@ -708,24 +745,51 @@ private:
                 g.kfs.push_back(kf);
                 for (int t = 0; t < 7; ++t) g.poses.push_back(kf->pose.v[t]);
             }
-            for (MapPoint *mp : st.map.active_landmarks_) {          // :83-160
+            const std::vector<MapPoint *> &AL = st.map.active_landmarks_;
+            // pass 0: upper bound of the edge count (also pulls the landmarks into cache)
+            size_t max_obs = 0;
+            for (size_t li = 0; li < AL.size(); ++li) {
+                if (li + 8 < AL.size()) {                            // the landmarks are scattered over the pool
+                    __builtin_prefetch(AL[li + 8], 0, 1);
+                    __builtin_prefetch(reinterpret_cast<const char *>(AL[li + 8]) + 64, 0, 1);
+                }
+                max_obs += AL[li]->observations.size();
+            }
+            g.lms.resize(AL.size()); g.pts.resize(3 * AL.size());
+            g.okf.resize(max_obs); g.olm.resize(max_obs); g.right.resize(max_obs); g.uv.resize(2 * max_obs);
+            g.edge_feat.resize(max_obs);
+            MapPoint **__restrict o_lms = g.lms.data();
+            double *__restrict o_pts = g.pts.data();
+            int *__restrict o_kf = g.okf.data(), *__restrict o_lm = g.olm.data();
+            uint8_t *__restrict o_right = g.right.data();
+            float *__restrict o_uv = g.uv.data();
+            ObsRef *__restrict o_ef = g.edge_feat.data();
+            int nl = 0; size_t ne = 0;
+            for (size_t li = 0; li < AL.size(); ++li) {              // :83-160
+                MapPoint *mp = AL[li];
                 if (mp->is_outlier) continue;
                 int lm_local = -1;
-                for (const ObsRef &ob : mp->observations) {
-                    Feature &ft = feat_of(ob);
+                const size_t nob = mp->observations.size();
+                for (size_t oi = 0; oi < nob; ++oi) {
+                    const ObsRef &ob = mp->observations[oi];
+                    const Feature &ft = feat_of(ob);
                     if (ft.outlier) continue;
                     if (lm_local < 0) {                              // vertex even if no edge follows (:118-130)
-                        lm_local = (int)g.lms.size();
-                        g.lms.push_back(mp);
-                        g.pts.push_back(mp->pos[0]); g.pts.push_back(mp->pos[1]); g.pts.push_back(mp->pos[2]);
+                        lm_local = nl++;
+                        o_lms[lm_local] = mp;
+                        o_pts[3 * lm_local] = mp->pos[0]; o_pts[3 * lm_local + 1] = mp->pos[1]; o_pts[3 * lm_local + 2] = mp->pos[2];
                     }
-                    if (ob.frame->ba_local < 0) continue;            // frame not in the active window (:133)
-                    g.okf.push_back(ob.frame->ba_local); g.olm.push_back(lm_local);
-                    g.right.push_back(ob.is_left ? 0 : 1);
-                    g.uv.push_back(ft.x); g.uv.push_back(ft.y);
-                    g.edge_feat.push_back(ob);
+                    const int kl = ob.frame->ba_local;
+                    if (kl < 0) continue;                            // frame not in the active window (:133)
+                    o_kf[ne] = kl; o_lm[ne] = lm_local;
+                    o_right[ne] = ob.is_left ? 0 : 1;
+                    o_uv[2 * ne] = ft.x; o_uv[2 * ne + 1] = ft.y;
+                    o_ef[ne] = ob;
+                    ++ne;
                 }
             }
+            g.lms.resize((size_t)nl); g.pts.resize(3 * (size_t)nl);
+            g.okf.resize(ne); g.olm.resize(ne); g.right.resize(ne); g.uv.resize(2 * ne); g.edge_feat.resize(ne);
             for (Frame *kf : g.kfs) kf->ba_local = -1;
         });
         int ko = 0, lo = 0, oo = 0;

@@ -7,6 +7,7 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <pthread.h>
 #include <thread>
 #include <vector>
 
@@ -63,6 +64,7 @@ private:
     }
     void worker()
     {
+        (void)pthread_setname_np(pthread_self(), "svs-pool");
         unsigned long seen = 0;
         for (;;) {
             {

@@ -3,7 +3,7 @@ export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out/pmc_ba; rm -rf $O; mkdir -p $O
 cat > /tmp/ba256.py <<'PY'
 import sys; sys.argv=["kbench","none"]
 sys.path.insert(0,"tools"); import kbench
-kbench.ba(256, 10, 700, reps=2)
+kbench.ba(256, 0, 0, reps=2)
 PY
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_WAVES" \
