@@ -18,6 +18,7 @@
 
 #include "../../include/svslam.h"
 #include "../host/thread_pool.h"
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include "dev_common.h"
@@ -717,71 +718,65 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
     if (c->ba_pending.active) return fail(c, "a submitted local-BA batch owns this context: call svslam_local_ba_collect first");
     c->ar.reset();
     static_assert(sizeof(BaJob) == sizeof(svslam_ba_job), "job layout");
-    // host-side structure of every problem (edge / block / pose-pair lists)
-    std::vector<BaHostStruct> &hs = c->ba_hs;
-    if ((int)hs.size() < njobs) hs.resize(njobs);
-    size_t aux_total = 0;
-    {
-        std::vector<int> bad((size_t)njobs, 0);
-        auto build_one = [&](int i) {
-            BaJob bj;
-            memcpy(&bj, &jobs[i], sizeof(bj));
-            if (!hs[i].build(bj, obs_kf, obs_lm, obs_is_right, obs_uv)) bad[(size_t)i] = 1;   // index out of range
-        };
-        if (c->pool && njobs > 1) c->pool->parallel_for(njobs, build_one);
-        else for (int i = 0; i < njobs; ++i) build_one(i);
-        for (int i = 0; i < njobs; ++i)
-            if (bad[(size_t)i]) return fail(c, "local_ba: job %d has an edge index out of range", i);
-        for (int i = 0; i < njobs; ++i) {
-            BaJob bj;
-            memcpy(&bj, &jobs[i], sizeof(bj));
-            aux_total += hs[i].aux_ints(bj);
-        }
-    }
+    // arena: cams | records | jobs | poses | points | chi2 (out) | aux (bump-allocated below, last)
     size_t ocams = c->ar.take(sizeof(BaCams));
     size_t orecs = c->ar.take(sizeof(BaRec) * 2 * std::max(total_obs, 1));   // landmark-major + pose-major edge records
-    size_t oaux = c->ar.take(sizeof(int) * std::max(aux_total, (size_t)1));
     size_t ojobs = c->ar.take(sizeof(BaDev) * njobs);
     size_t oposes = c->ar.take(sizeof(double) * 7 * std::max(total_kf, 1));
     size_t opts = c->ar.take(sizeof(double) * 3 * std::max(total_lm, 1));
     size_t in_end = c->ar.off;
     size_t ochi = c->ar.take(sizeof(double) * std::max(total_obs, 1));
-    if (c->ar.off > c->ar.cap) return fail(c, "local_ba: staging arena too small (%zu > %zu bytes)", c->ar.off, c->ar.cap);
+    size_t out_end = c->ar.off;
+    size_t oaux = c->ar.take(0);
+    if (oaux > c->ar.cap) return fail(c, "local_ba: staging arena too small (%zu > %zu bytes)", oaux, c->ar.cap);
     BaCams *cams = hp<BaCams>(c, ocams);
     memcpy(cams->cam[0], cam_l, 32); memcpy(cams->cam[1], cam_r, 32);
     memcpy(cams->ext[0], ext_l, 56); memcpy(cams->ext[1], ext_r, 56);
     BaDev *dj = hp<BaDev>(c, ojobs);
+    // Host-side structure of every problem (edge records, blocks, pose-pair lists), built by the
+    // pool with one scratch structure per thread (stays cache-hot) and written straight into the
+    // arena; the aux space of a problem comes from a bump allocator, so its position depends on
+    // thread timing but nothing else does (every problem carries its own offsets).
+    size_t aux_total = 0;
     {
-        size_t aofs = 0;
+        std::vector<int> bad((size_t)njobs, 0);
+        std::atomic<size_t> bump{ 0 };
+        const size_t aux_cap_ints = (c->ar.cap - oaux) / sizeof(int);
         int *aux = hp<int>(c, oaux);
-        std::vector<size_t> aoff((size_t)njobs);
-        for (int i = 0; i < njobs; ++i) {
+        BaRec *recs = hp<BaRec>(c, orecs);
+        auto build_one = [&](int i) {
+            static thread_local BaHostStruct hs;
             BaJob bj;
             memcpy(&bj, &jobs[i], sizeof(bj));
-            aoff[(size_t)i] = aofs;
-            aofs += hs[i].aux_ints(bj);
-        }
-        auto write_one = [&](int i) {
-            BaJob bj;
-            memcpy(&bj, &jobs[i], sizeof(bj));
-            hs[i].write(bj, aux + aoff[(size_t)i], hp<BaRec>(c, orecs) + 2 * (size_t)bj.obs_ofs, dj[i]);
-            dj[i].aux_ofs = (int)aoff[(size_t)i];
+            if (!hs.build(bj, obs_kf, obs_lm, obs_is_right, obs_uv)) { bad[(size_t)i] = 1; return; }   // index out of range
+            const size_t need = hs.aux_ints(bj);
+            const size_t at = bump.fetch_add(need);
+            if (at + need > aux_cap_ints) { bad[(size_t)i] = 2; return; }
+            hs.write(bj, aux + at, recs + 2 * (size_t)bj.obs_ofs, dj[i]);
+            dj[i].aux_ofs = (int)at;
             dj[i].rec_ofs = 2 * bj.obs_ofs;
         };
-        if (c->pool && njobs > 1) c->pool->parallel_for(njobs, write_one);
-        else for (int i = 0; i < njobs; ++i) write_one(i);
+        if (c->pool && njobs > 1) c->pool->parallel_for(njobs, build_one);
+        else for (int i = 0; i < njobs; ++i) build_one(i);
+        for (int i = 0; i < njobs; ++i) {
+            if (bad[(size_t)i] == 1) return fail(c, "local_ba: job %d has an edge index out of range", i);
+            if (bad[(size_t)i] == 2) return fail(c, "local_ba: staging arena too small for the problem structure");
+        }
+        aux_total = bump.load();
+        (void)c->ar.take(sizeof(int) * aux_total);
     }
     if (total_kf > 0) memcpy(hp<void>(c, oposes), poses, sizeof(double) * 7 * total_kf);
     if (total_lm > 0) memcpy(hp<void>(c, opts), pts, sizeof(double) * 3 * total_lm);
     c->host_ns[4] += now_ns() - t_prep0;
     if (h2d(c, 0, in_end)) return -1;
+    if (h2d(c, oaux, c->ar.off)) return -1;
     tm_begin(c, FAM_BA, njobs);
     hipLaunchKernelGGL(k_local_ba, dim3(njobs), dim3(BA_THREADS), ba_lds_bytes(c->lim.max_kf), c->stream,
                        dp<BaDev>(c, ojobs), dp<BaCams>(c, ocams), dp<double>(c, oposes), dp<double>(c, opts),
                        dp<BaRec>(c, orecs), dp<int>(c, oaux), c->bw, huber_delta, iters, dp<double>(c, ochi), c->d_ba_prof);
     tm_end(c);
     HIPCHK(c, hipGetLastError());
-    if (d2h_enqueue(c, ojobs, c->ar.off)) return -1;
+    if (d2h_enqueue(c, ojobs, out_end)) return -1;
     c->ba_pending.active = true; c->ba_pending.njobs = njobs;
     c->ba_pending.total_kf = total_kf; c->ba_pending.total_lm = total_lm; c->ba_pending.total_obs = total_obs;
     c->ba_pending.ojobs = ojobs; c->ba_pending.oposes = oposes; c->ba_pending.opts = opts; c->ba_pending.ochi = ochi;
