@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("SVS_BENCH_STREAMS", "4096")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("SVS_BENCH_STREAMS", "6144")),
                     help="independent stereo streams per GPU, advanced in lockstep")
     ap.add_argument("--groups", type=int, default=int(os.environ.get("SVS_BENCH_GROUPS", "0")),
                     help="host threads per GPU, each driving streams/groups streams through its own "
@@ -127,7 +127,9 @@ def main():
 
     S, Wm, K = args.streams, args.warmup, args.steps
     # the synthetic frames of the whole run are rendered into HBM up front: keep them under ~190 GB
-    S = max(1, min(S, int(190e9 // (2 * W * H * (Wm + K)))))
+    cap = int(190e9 // (2 * W * H * (Wm + K)))
+    if S > cap:
+        S = max(512, cap // 512 * 512) if cap >= 512 else max(1, cap)
     # host layout from the cores this rank may actually use (cgroup quota / ranks on the node):
     # about two threads per core (half of them are waiting on the GPU at any time), at most 8
     # groups (>= 512 streams each at the default size) x at most 4 bookkeeping threads
