@@ -70,7 +70,6 @@ struct svslam_ctx {
     GfttWork gw;
     // BA scratch
     BaWork bw;
-    std::vector<BaHostStruct> ba_hs;
     std::unique_ptr<svs::ThreadPool> pool;   // host-side per-problem preparation
     long long *d_ba_prof = nullptr;
     // host-side wall time (ns): 0 h2d enqueue, 1 d2h enqueue, 2 stream wait, 3 launches, 4 staging memcpy/prep
@@ -204,7 +203,7 @@ hipError_t pool_stream(int device, hipStream_t *out)
         *out = s;
         return hipSuccess;
     }
-    *out = p[next[device & 63]++ % p.size()];
+    *out = p[next[device & 63]++ % std::min(p.size(), cap)];
     return hipSuccess;
 }
 int h2d(svslam_ctx *c, size_t from, size_t to)

@@ -122,3 +122,36 @@ def test_full_resolution_decimating_path_matches_host_decimation(svs, orc):
     assert np.array_equal(c.pyramid_read(0, 2), orc.pyramid(dec)[2])
     c.dev_free(d)
     c.close()
+
+
+def test_contexts_sharing_one_stream_stay_independent(svs, monkeypatch):
+    """With the stream pool capped at 1 every context lands on the same HIP stream; two threads
+    driving their own contexts concurrently must still get their own (correct) results, because
+    a context waits on its completion event and never on the stream."""
+    import threading
+    import oracle_lib as orc
+    monkeypatch.setenv("SVSLAM_MAX_STREAMS", "1")
+    frames = [svs.synth_pair(11, f) for f in range(2)]
+    l0, r0 = frames[0]
+    pts = orc.gftt(l0)
+    want_t = orc.lk(l0, frames[1][0], pts, pts)
+    want_s = orc.lk(l0, r0, pts, pts)
+    out = {}
+
+    def work(name, second, want):
+        c = svs.Context(cm.W, cm.H, max_slots=2, max_jobs=2, max_kf=0, max_lm=0, max_obs=0)
+        ok = True
+        for _ in range(20):
+            c.pyramid([0, 1], [l0, second])
+            q, st, _ = c.lk([(0, 1, pts, pts)])[0]
+            ok = ok and np.array_equal(q.view(np.uint32), want[0].view(np.uint32)) and np.array_equal(st, want[1])
+        c.close()
+        out[name] = ok
+
+    th = [threading.Thread(target=work, args=("t", frames[1][0], want_t)),
+          threading.Thread(target=work, args=("s", r0, want_s))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert out == {"t": True, "s": True}
