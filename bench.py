@@ -113,6 +113,10 @@ def main():
                          "frame like the reference's backend thread and lands exactly one frame late "
                          "(measured: no throughput gain, the GPU is already saturated by the other streams)")
     ap.add_argument("--cpu-frames", type=int, default=1500, help="bound of the CPU baseline sample")
+    ap.add_argument("--full-res", action="store_true",
+                    help="keep the frames in HBM at the camera's 1241x376 and fuse the reference's 1/2 "
+                         "decimation (Dataset::NextFrame) into the pyramid's level 0 (SURVEY 8 row f3); 4x the "
+                         "frame bytes, so fewer streams fit")
     args = ap.parse_args()
 
     import torch
@@ -127,7 +131,8 @@ def main():
 
     S, Wm, K = args.streams, args.warmup, args.steps
     # the synthetic frames of the whole run are rendered into HBM up front: keep them under ~190 GB
-    cap = int(190e9 // (2 * W * H * (Wm + K)))
+    SW, SH = (1241, 376) if args.full_res else (W, H)     # stored frame size
+    cap = int(190e9 // (2 * SW * SH * (Wm + K)))
     if S > cap:
         S = max(512, cap // 512 * 512) if cap >= 512 else max(1, cap)
     # host layout from the cores this rank may actually use (cgroup quota / ranks on the node):
@@ -143,7 +148,8 @@ def main():
         args.host_threads = max(1, min(4, (2 * cores + G - 1) // G))
     Sg = S // G
     F = Wm + K
-    cfg = pl.default_config(W, H, host_threads=max(1, args.host_threads), backend_on=args.backend_mode)
+    cfg = pl.default_config(W, H, host_threads=max(1, args.host_threads), backend_on=args.backend_mode,
+                            src_width=SW if args.full_res else 0, src_height=SH if args.full_res else 0)
     pipes = [pl.Pipeline(cfg, nstreams=Sg, device=local_rank) for _ in range(G)]
     ctxs = [svs.Context.borrow(p.kernel_ctx(), W, H) for p in pipes]   # alloc / timing through the pipelines' contexts
     ctx = ctxs[0]
@@ -151,16 +157,17 @@ def main():
         ctxs = ctxs + [svs.Context.borrow(p.backend_ctx(), W, H) for p in pipes]
 
     # ---- render the synthetic streams straight into HBM: layout [stream][frame][H*W]
-    img = W * H
+    img = SW * SH
+    cam_r = tuple(2 * v for v in svs.KITTI00_HALF_CAM) if args.full_res else svs.KITTI00_HALF_CAM
     d_left = ctx.dev_alloc(S * F * img)
     d_right = ctx.dev_alloc(S * F * img)
     seeds = rk.stream_seeds(S)
     CH = 256
     for s in range(S):
         for f0 in range(0, F, CH):
-            vl, vr = zip(*[svs.synth_views(seeds[s], f) for f in range(f0, min(F, f0 + CH))])
-            svs.synth_render_device(list(vl), W, H, d_left + (s * F + f0) * img, device=local_rank)
-            svs.synth_render_device(list(vr), W, H, d_right + (s * F + f0) * img, device=local_rank)
+            vl, vr = zip(*[svs.synth_views(seeds[s], f, cam_r) for f in range(f0, min(F, f0 + CH))])
+            svs.synth_render_device(list(vl), SW, SH, d_left + (s * F + f0) * img, device=local_rank)
+            svs.synth_render_device(list(vr), SW, SH, d_right + (s * F + f0) * img, device=local_rank)
 
     def barrier():
         rk.barrier()
@@ -259,7 +266,7 @@ def main():
                                    "keyframes)" % ("completes before the next frame" if args.backend_mode == 1 else
                                                    "runs beside the next frame like the reference's backend thread, "
                                                    "lands one frame late, all of it inside the timed region"),
-                       "streams_per_gpu": S, "host_threads_per_gpu": G, "bookkeeping_threads_per_group": args.host_threads, "frame": "%dx%d u8 stereo pair" % (W, H),
+                       "streams_per_gpu": S, "host_threads_per_gpu": G, "bookkeeping_threads_per_group": args.host_threads, "frame": "%dx%d u8 stereo pair" % (W, H) + (" decimated on the fly from %dx%d frames in HBM" % (SW, SH) if args.full_res else ""),
                        "keyframes_in_timed_region": cnt["keyframes"],
                        "ba_problem_mean": {"keyframes": round(cnt["ba_kf"] / max(cnt["ba_calls"], 1), 1),
                                            "landmarks": round(cnt["ba_lm"] / max(cnt["ba_calls"], 1), 1),
@@ -291,14 +298,15 @@ def main():
 
 
 def cpu_baseline(svs, pl, ctx, cfg, d_left, F, img, S, budget_frames, d_right):
-    cfg = pl.default_config(W, H, backend_on=cfg.backend_on)          # single-threaded twin, same backend mode
+    sw, sh = (cfg.src_width, cfg.src_height) if cfg.src_width > 0 else (W, H)
+    cfg = pl.default_config(W, H, backend_on=cfg.backend_on, src_width=cfg.src_width, src_height=cfg.src_height)   # single-threaded twin, same modes
     """The CPU twin (reference-shaped host logic over the oracle kernels, single thread) on a
     bounded sample of the same workload: the first streams' frames, downloaded from HBM."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import pipe_cpu
     nstreams = max(1, min(S, budget_frames // F))
     twin = pipe_cpu.make(cfg, nstreams=1)
-    left = np.zeros((F, H, W), np.uint8); right = np.zeros((F, H, W), np.uint8)
+    left = np.zeros((F, sh, sw), np.uint8); right = np.zeros((F, sh, sw), np.uint8)
     total_t, total_f = 0.0, 0
     for s in range(nstreams):
         ctx.dev_download(d_left + s * F * img, left)

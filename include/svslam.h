@@ -71,6 +71,11 @@ int svslam_pyramid_batch(svslam_ctx *ctx, int n, const int *slots,
 int svslam_pyramid_decimate_batch(svslam_ctx *ctx, int n, const int *slots,
                                   const void *const *imgs, const int *strides,
                                   int src_w, int src_h, int src_is_device);
+/* Declares that every image handed to svslam_pyramid_batch / svslam_track_batch from now on
+ * is a full-resolution src_w x src_h frame to be decimated the same way (0,0 switches it
+ * off): a caller that keeps the camera frames in HBM never stores the half-size copies the
+ * reference makes in Dataset::NextFrame.                                          */
+int svslam_set_source_size(svslam_ctx *ctx, int src_w, int src_h);
 /* test hook: read one level back (tight rows of *w bytes) */
 int svslam_pyramid_read(svslam_ctx *ctx, int slot, int level, uint8_t *out,
                         int *w, int *h);

@@ -30,13 +30,15 @@ public:
     void set_host_threads(int) {}
     const char *last_error() { return err_.c_str(); }
 
+    int set_source_size(int src_w, int src_h) { src_w_ = src_w; src_h_ = src_h; return 0; }
     int pyramid(int n, const int *slots, const void *const *imgs, const int *strides, int)
     {
         for (int i = 0; i < n; ++i) {
             std::vector<uint8_t> &d = slots_[(size_t)slots[i]];
             d.resize((size_t)w_ * h_);
             const uint8_t *s = static_cast<const uint8_t *>(imgs[i]);
-            for (int y = 0; y < h_; ++y) std::memcpy(&d[(size_t)y * w_], s + (size_t)y * strides[i], (size_t)w_);
+            if (src_w_ > 0) orc_decimate(s, src_w_, src_h_, strides[i], d.data(), w_, h_, w_);
+            else for (int y = 0; y < h_; ++y) std::memcpy(&d[(size_t)y * w_], s + (size_t)y * strides[i], (size_t)w_);
         }
         return 0;
     }
@@ -150,6 +152,7 @@ private:
     std::vector<svslam_ba_job> ba_jobs_;
     std::vector<double> ba_poses_, ba_pts_, ba_chi2_;
     int w_, h_;
+    int src_w_ = 0, src_h_ = 0;
     std::vector<std::vector<uint8_t>> slots_;
     int jac_mode_ = 1;
     std::string err_;

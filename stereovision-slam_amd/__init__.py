@@ -18,7 +18,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 
 ABI_SYMBOLS = [
     "svslam_create", "svslam_destroy", "svslam_last_error", "svslam_build_info",
-    "svslam_pyramid_batch", "svslam_pyramid_decimate_batch", "svslam_pyramid_read",
+    "svslam_pyramid_batch", "svslam_pyramid_decimate_batch", "svslam_set_source_size", "svslam_pyramid_read",
     "svslam_lk_batch", "svslam_gftt_batch", "svslam_gftt_eigmap", "svslam_triangulate_batch",
     "svslam_pose_only_batch", "svslam_local_ba_batch", "svslam_local_ba_submit", "svslam_local_ba_collect",
     "svslam_track_batch",

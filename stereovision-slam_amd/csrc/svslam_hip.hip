@@ -75,6 +75,7 @@ struct svslam_ctx {
     // host-side wall time (ns): 0 h2d enqueue, 1 d2h enqueue, 2 stream wait, 3 launches, 4 staging memcpy/prep
     long long host_ns[8] = { 0 };
     bool wait_poll = true;
+    int src_w = 0, src_h = 0;     // > 0: level 0 is the 2:1 decimation of src_w x src_h inputs
     hipEvent_t done = nullptr;   // recorded after the last enqueue of a call; the stream may be shared
     // a submitted, not yet collected local-BA batch owns the staging arena
     struct { bool active = false; int njobs = 0, total_kf = 0, total_lm = 0, total_obs = 0;
@@ -452,7 +453,19 @@ int svslam_timing_get(svslam_ctx *c, int family, double *total_ms, long long *la
 int svslam_pyramid_batch(svslam_ctx *c, int n, const int *slots, const void *const *imgs,
                          const int *strides, int src_is_device)
 {
-    return pyramid_common(c, n, slots, imgs, strides, src_is_device, false, c->geom.w[0], c->geom.h[0], true);
+    const bool dec = c->src_w > 0;
+    return pyramid_common(c, n, slots, imgs, strides, src_is_device, dec, dec ? c->src_w : c->geom.w[0],
+                          dec ? c->src_h : c->geom.h[0], true);
+}
+
+int svslam_set_source_size(svslam_ctx *c, int src_w, int src_h)
+{
+    if (src_w <= 0 || src_h <= 0) { c->src_w = c->src_h = 0; return 0; }
+    const int dw = (int)std::nearbyint(src_w * 0.5), dh = (int)std::nearbyint(src_h * 0.5);   // cvRound
+    if (dw != c->geom.w[0] || dh != c->geom.h[0])
+        return fail(c, "source %dx%d halves to %dx%d, context is %dx%d", src_w, src_h, dw, dh, c->geom.w[0], c->geom.h[0]);
+    c->src_w = src_w; c->src_h = src_h;
+    return 0;
 }
 
 int svslam_pyramid_decimate_batch(svslam_ctx *c, int n, const int *slots, const void *const *imgs,
@@ -883,8 +896,11 @@ int svslam_track_batch(svslam_ctx *c, int njobs, svslam_track_job *jobs, const v
         slots[i] = jobs[i].next_slot;
     }
     // 1. pyramids of the new left images (enqueue only)
-    if (pyramid_common(c, njobs, slots.data(), next_imgs, strides, src_is_device, false, c->geom.w[0],
-                       c->geom.h[0], false)) return -1;
+    {
+        const bool dec = c->src_w > 0;
+        if (pyramid_common(c, njobs, slots.data(), next_imgs, strides, src_is_device, dec, dec ? c->src_w : c->geom.w[0],
+                           dec ? c->src_h : c->geom.h[0], false)) return -1;
+    }
     // 2. LK + pose-only back to back, single readback.  The arena region used by the
     //    pyramid job array stays live until the stream drains, so continue after it.
     int maxn = 0;

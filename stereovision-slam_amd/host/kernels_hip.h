@@ -47,6 +47,7 @@ public:
         return svslam_last_error(ctx_);
     }
     svslam_ctx *backend_ctx() { return ba_ctx_ ? ba_ctx_ : ctx_; }
+    int set_source_size(int src_w, int src_h) { return svslam_set_source_size(ctx_, src_w, src_h); }
 
     int pyramid(int n, const int *slots, const void *const *imgs, const int *strides, int is_device)
     { return svslam_pyramid_batch(ctx_, n, slots, imgs, strides, is_device); }

@@ -18,6 +18,9 @@ typedef struct svs_pipe_config {
     double cam_l[4], ext_l[7], cam_r[4], ext_r[7];
     int max_lm, max_obs;      /* BA limits per problem */
     int host_threads;         /* threads for the per-stream host bookkeeping (>=1) */
+    int src_width, src_height; /* > 0: the frames handed in are full-resolution src_width x src_height and
+                                  are decimated 2:1 to width x height on the way into the pyramid (the
+                                  resize of Dataset::NextFrame, src/dataset.cpp:126-129, fused)        */
 } svs_pipe_config;
 
 typedef struct svs_frame_result {

@@ -30,6 +30,7 @@ svs::Config to_config(const svs_pipe_config &c)
     g.cam_l.fx = c.cam_l[0]; g.cam_l.fy = c.cam_l[1]; g.cam_l.cx = c.cam_l[2]; g.cam_l.cy = c.cam_l[3];
     g.cam_r.fx = c.cam_r[0]; g.cam_r.fy = c.cam_r[1]; g.cam_r.cx = c.cam_r[2]; g.cam_r.cy = c.cam_r[3];
     g.cam_l.pose = svs::SE3(c.ext_l); g.cam_r.pose = svs::SE3(c.ext_r);
+    g.src_width = c.src_width; g.src_height = c.src_height;
     return g;
 }
 } // namespace
@@ -57,6 +58,8 @@ void *svs_pipe_create(const svs_pipe_config *cfg, int nstreams, int device)
             h->kernels->enable_backend_context(lim_ba);
         }
         h->kernels->set_host_threads(cfg->host_threads > 0 ? cfg->host_threads : 1);
+        if (cfg->src_width > 0 && h->kernels->set_source_size(cfg->src_width, cfg->src_height) != 0)
+            throw std::runtime_error(std::string("source size: ") + h->kernels->last_error());
         h->pipe.reset(new svs::Pipeline<SVS_PIPE_KERNELS>(to_config(*cfg), *h->kernels, nstreams,
                                                              cfg->host_threads > 0 ? cfg->host_threads : 1));
         h->lp.resize(nstreams); h->rp.resize(nstreams); h->res.resize(nstreams);

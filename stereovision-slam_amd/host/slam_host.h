@@ -47,6 +47,7 @@ struct Config {                       // config/stereo_slam_configs/config-00.ya
     double max_triangulation_depth = 300.0;
     int num_active_keyframes = 10;
     int backend_on = 1;
+    int src_width = 0, src_height = 0;   // > 0: input frames are full resolution, decimated into the pyramid
     double chi2_th = 5.991;
     int width = 620, height = 188;
     Camera cam_l, cam_r;
@@ -452,7 +453,7 @@ private:
             j.n_tracked = 0; j.n_inlier = 0;
             ofs += j.npts;
             imgs_[i] = left[TS[i]];
-            strides_[i] = strides ? strides[TS[i]] : cfg_.width;
+            strides_[i] = strides ? strides[TS[i]] : (cfg_.src_width > 0 ? cfg_.src_width : cfg_.width);
         }
         const size_t tot = (size_t)std::max(ofs, 1);
         prev_xy_.resize(2 * tot); next_xy_.resize(2 * tot); has_mp_.resize(tot); xyz_.resize(3 * tot);
@@ -549,11 +550,11 @@ private:
         std::vector<int> slots; imgs_.clear(); strides_.clear();
         for (int s : IS) {
             slots.push_back(streams_[s]->slot_cur); imgs_.push_back(left[s]);
-            strides_.push_back(strides ? strides[s] : cfg_.width);
+            strides_.push_back(strides ? strides[s] : (cfg_.src_width > 0 ? cfg_.src_width : cfg_.width));
         }
         for (int s : DS) {
             slots.push_back(streams_[s]->slot_right); imgs_.push_back(right[s]);
-            strides_.push_back(strides ? strides[s] : cfg_.width);
+            strides_.push_back(strides ? strides[s] : (cfg_.src_width > 0 ? cfg_.src_width : cfg_.width));
         }
         { KTimer kt_(cnt_); check(k_.pyramid((int)slots.size(), slots.data(), imgs_.data(), strides_.data(), is_device), "pyramid"); }
         cnt_.pyr_left += (long long)IS.size(); cnt_.pyr_right += (long long)DS.size();

@@ -120,6 +120,24 @@ def test_backend_beside_frontend_lands_one_frame_late(svs):
     assert abs(c2["keyframes"] - c1["keyframes"]) <= 1
 
 
+def test_full_resolution_input_equals_predecimated(svs):
+    """f3: frames handed in at 1241x376 and decimated on the way into the pyramid give exactly the
+    run on frames decimated beforehand (cv::resize INTER_NEAREST 0.5: dst(x,y) = src(2x,2y))."""
+    import pipe_cpu
+    pl = importlib.import_module("stereovision-slam_amd.pipeline")
+    SW, SH = 1241, 376
+    cam2 = tuple(2 * v for v in svs.KITTI00_HALF_CAM)
+    full = [svs.synth_pair(4, f, SW, SH, cam2) for f in range(8)]
+    half = [(l[::2, ::2][:188, :620].copy(), r[::2, ::2][:188, :620].copy()) for l, r in full]
+    a = pipe_cpu.make(pl.default_config(src_width=SW, src_height=SH), nstreams=1)
+    b = pipe_cpu.make(nstreams=1)
+    for (fl, fr), (hl, hr) in zip(full, half):
+        ra = a.step([fl], [fr]); rb = b.step([hl], [hr])
+        assert np.array_equal(ra["pose"], rb["pose"]) and ra["n_features"][0] == rb["n_features"][0]
+    assert a.counters()["keyframes"] >= 1
+    a.close(); b.close()
+
+
 def test_host_pipeline_config_and_failed_init(svs):
     pl = importlib.import_module("stereovision-slam_amd.pipeline")
     ref_cfg = "/root/reference/config/stereo_slam_configs/config-00.yaml"

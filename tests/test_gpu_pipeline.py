@@ -104,3 +104,19 @@ def test_pipeline_backend_beside_frontend_matches_cpu_twin(svs, monkeypatch):
         gt = np.array([svs.synth_gt(sd, f) for f in range(N)])
         assert pl.ate_rmse(eg[:, k], gt) < 0.1
     gpu.close(); cpu.close()
+
+
+def test_pipeline_full_resolution_input(svs):
+    """f3 on the product path: 1241x376 frames resident in host memory, decimation fused into
+    level 0 (svslam_set_source_size) == the same pipeline fed with pre-decimated frames."""
+    pl = importlib.import_module("stereovision-slam_amd.pipeline")
+    SW, SH = 1241, 376
+    cam2 = tuple(2 * v for v in svs.KITTI00_HALF_CAM)
+    full = [svs.synth_pair(4, f, SW, SH, cam2) for f in range(8)]
+    half = [(l[::2, ::2][:188, :620].copy(), r[::2, ::2][:188, :620].copy()) for l, r in full]
+    a = pl.Pipeline(pl.default_config(src_width=SW, src_height=SH), nstreams=1)
+    b = pl.Pipeline(nstreams=1)
+    for (fl, fr), (hl, hr) in zip(full, half):
+        ra = a.step([fl], [fr]); rb = b.step([hl], [hr])
+        assert np.array_equal(ra["pose"], rb["pose"]) and ra["n_features"][0] == rb["n_features"][0]
+    a.close(); b.close()
