@@ -99,8 +99,13 @@ struct Camera {
     // world2pixel (src/camera.cpp:74-80): camera2pixel(pose_ * T_c_w * p_w)
     void world2pixel(const double *pw, const SE3 &T_cw, double *uv) const
     {
+        project(pose * T_cw, pw, uv); // pose_ * T_c_w * p_w associates left to right
+    }
+    // the same with the product pose_ * T_c_w formed once by the caller (loops over points)
+    void project(const SE3 &T_cam_w, const double *pw, double *uv) const
+    {
         double p[3];
-        (pose * T_cw).act(pw, p); // pose_ * T_c_w * p_w associates left to right
+        T_cam_w.act(pw, p);
         uv[0] = fx * p[0] / p[2] + cx;
         uv[1] = fy * p[1] / p[2] + cy;
     }

@@ -465,6 +465,7 @@ private:
             svslam_track_job &j = jobs_track_[i];
             std::memcpy(j.pose, cur->pose.v, sizeof(j.pose));
             size_t g = (size_t)j.pt_ofs;
+            const SE3 T_caml_w = cfg_.cam_l.pose * cur->pose;        // pose_ * T_c_w, once per frame
             const std::vector<Feature> &LF = last->left;
             for (size_t fi = 0; fi < LF.size(); ++fi) {             // :331-347
                 const Feature &f = LF[fi];
@@ -473,7 +474,7 @@ private:
                 MapPoint *mp = st.map.point(f.mp);
                 if (mp) {
                     double uv[2];
-                    cfg_.cam_l.world2pixel(mp->pos, cur->pose, uv);
+                    cfg_.cam_l.project(T_caml_w, mp->pos, uv);
                     next_xy_[2 * g] = (float)uv[0]; next_xy_[2 * g + 1] = (float)uv[1];
                     has_mp_[g] = 1;
                     xyz_[3 * g] = mp->pos[0]; xyz_[3 * g + 1] = mp->pos[1]; xyz_[3 * g + 2] = mp->pos[2];
@@ -620,12 +621,13 @@ private:
             Stream &st = *streams_[DS[i]];
             Frame *cur = st.current;
             size_t g = (size_t)jobs_lk_[i].pt_ofs;
+            const SE3 T_camr_w = cfg_.cam_r.pose * cur->pose;
             for (const Feature &f : cur->left) {
                 prev_xy_[2 * g] = f.x; prev_xy_[2 * g + 1] = f.y;
                 MapPoint *mp = st.map.point(f.mp);
                 if (mp) {
                     double uv[2];
-                    cfg_.cam_r.world2pixel(mp->pos, cur->pose, uv);
+                    cfg_.cam_r.project(T_camr_w, mp->pos, uv);
                     next_xy_[2 * g] = (float)uv[0]; next_xy_[2 * g + 1] = (float)uv[1];
                 } else { next_xy_[2 * g] = f.x; next_xy_[2 * g + 1] = f.y; }
                 ++g;
