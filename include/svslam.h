@@ -45,6 +45,8 @@ typedef struct svslam_limits {
     int max_kf;        /* BA: max keyframes per problem                        */
     int max_lm;        /* BA: max landmarks per problem                        */
     int max_obs;       /* BA: max observations (edges) per problem             */
+    int max_streams;   /* streams whose last-frame features stay resident in HBM
+                          (svslam_rtrack_*); 0 = none                          */
 } svslam_limits;
 
 /* ---- lifetime -------------------------------------------------------- */
@@ -227,6 +229,41 @@ int svslam_track_batch(svslam_ctx *ctx, int njobs, svslam_track_job *jobs,
                        const uint8_t *has_mp, const double *xyz,
                        uint8_t *status, uint8_t *outlier,
                        const svslam_lk_params *p, double chi2_th);
+
+/* ---- the same with the features of the last frame resident in HBM ------------
+ * svslam_track_batch makes the caller gather (position, map point, start guess) of
+ * every feature of the last frame and scatter the survivors into the new frame
+ * (src/frontend.cpp:331-347, :361-381, :546-553) — per-feature host work on every
+ * frame.  Here the feature list of every stream's last frame lives in HBM: the call
+ * reads it, tracks, optimises the pose and leaves the survivors (outlier edges
+ * stripped of their map point) as the new list.  The caller only supplies the
+ * predicted pose and gets counts back; the compacted survivors (xy, map point id) are
+ * also returned for the frames the caller turns into keyframes.  After a keyframe has
+ * added features / map points or the backend has moved them, the caller replaces the
+ * stream's list with svslam_rtrack_upload.                                        */
+typedef struct svslam_rtrack_job {
+    int    stream;       /* resident slot, 0 .. max_streams-1                     */
+    int    prev_slot, next_slot;
+    int    pt_ofs, npts; /* npts = features of the last frame (the caller's count); pt_ofs:
+                            where this job's survivors start in out_xy / out_mp   */
+    double pose[7];      /* in: predicted T_cw; out: refined                      */
+    double T_cam_w[7];   /* in: cam_left.pose * predicted T_cw (src/camera.cpp:74) */
+    int    n_tracked;    /* out: survivors = features of the new frame            */
+    int    n_edges;      /* out: survivors that carry a map point                 */
+    int    n_outlier;    /* out: of those, classified outlier by the pose solve   */
+    int    reserved;
+} svslam_rtrack_job;
+
+int svslam_rtrack_batch(svslam_ctx *ctx, int njobs, svslam_rtrack_job *jobs,
+                        const void *const *next_imgs, const int *strides,
+                        int src_is_device, int total_pts, const double cam[4],
+                        float *out_xy, int *out_mp,
+                        const svslam_lk_params *p, double chi2_th);
+/* replaces the resident feature lists of n streams: stream i has counts[i] features at
+ * xy/mp/xyz + ofs[i] (xyz is read only where mp >= 0)                               */
+int svslam_rtrack_upload(svslam_ctx *ctx, int n, const int *streams, const int *ofs,
+                         const int *counts, const float *xy, const int *mp,
+                         const double *xyz);
 
 /* host threads the library may use to prepare a batched call (per-problem BA structure
  * building); default 1.                                                        */

@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "svslam_pyramid_batch", "svslam_pyramid_decimate_batch", "svslam_set_source_size", "svslam_pyramid_read",
     "svslam_lk_batch", "svslam_gftt_batch", "svslam_gftt_eigmap", "svslam_triangulate_batch",
     "svslam_pose_only_batch", "svslam_local_ba_batch", "svslam_local_ba_submit", "svslam_local_ba_collect",
-    "svslam_track_batch",
+    "svslam_track_batch", "svslam_rtrack_batch", "svslam_rtrack_upload",
     "svslam_dev_alloc", "svslam_dev_free", "svslam_dev_upload", "svslam_dev_download", "svslam_sync",
     "svslam_timing_enable", "svslam_timing_reset", "svslam_timing_get", "svslam_ba_profile",
     "svslam_set_host_threads", "svslam_debug_host_ns", "svslam_debug_clock_mhz",
@@ -33,7 +33,13 @@ FAMILIES = {"pyramid": 0, "lk": 1, "gftt": 2, "triangulate": 3, "pose_only": 4, 
 class Limits(C.Structure):
     _fields_ = [("device", C.c_int), ("width", C.c_int), ("height", C.c_int), ("max_slots", C.c_int),
                 ("max_jobs", C.c_int), ("max_pts", C.c_int), ("max_corners", C.c_int), ("max_kf", C.c_int),
-                ("max_lm", C.c_int), ("max_obs", C.c_int)]
+                ("max_lm", C.c_int), ("max_obs", C.c_int), ("max_streams", C.c_int)]
+
+
+class RtrackJob(C.Structure):
+    _fields_ = [("stream", C.c_int), ("prev_slot", C.c_int), ("next_slot", C.c_int), ("pt_ofs", C.c_int),
+                ("npts", C.c_int), ("pose", C.c_double * 7), ("T_cam_w", C.c_double * 7), ("n_tracked", C.c_int),
+                ("n_edges", C.c_int), ("n_outlier", C.c_int), ("reserved", C.c_int)]
 
 
 class LkJob(C.Structure):
@@ -121,10 +127,10 @@ class Context:
     """One svslam_ctx: own HIP stream, resident pyramid slots, staging arena."""
 
     def __init__(self, width, height, max_slots=4, max_jobs=1, max_pts=512, max_corners=150, max_kf=10,
-                 max_lm=2048, max_obs=8192, device=0):
+                 max_lm=2048, max_obs=8192, device=0, max_streams=0):
         self.L = load()
         self.lim = Limits(device, width, height, max_slots, max_jobs, max_pts, max_corners, max_kf, max_lm,
-                          max_obs)
+                          max_obs, max_streams)
         self.h = C.c_void_p()
         rc = self.L.svslam_create(C.byref(self.lim), C.byref(self.h))
         if rc != 0:
@@ -344,6 +350,41 @@ class Context:
         for j in arr:
             out.append((P[j.kf_ofs:j.kf_ofs + j.nkf].copy(), X[j.lm_ofs:j.lm_ofs + j.nlm].copy(),
                         chi2[j.obs_ofs:j.obs_ofs + j.nobs].copy(), j.iters_done))
+        return out
+
+    # ---- resident tracking -----------------------------------------------------
+    def rtrack_upload(self, lists):
+        """lists: [(stream, xy[n,2], mp[n], xyz[n,3])] -> replaces the resident feature lists"""
+        n = len(lists)
+        streams = (C.c_int * n)(*[l[0] for l in lists])
+        cnt = [len(l[2]) for l in lists]
+        ofs = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int32) if n else np.zeros(0, np.int32)
+        xy = np.ascontiguousarray(np.concatenate([_f32(l[1], 2) for l in lists]))
+        mp = np.ascontiguousarray(np.concatenate([np.asarray(l[2], np.int32) for l in lists]))
+        xyz = np.ascontiguousarray(np.concatenate([np.asarray(l[3], np.float64).reshape(-1, 3) for l in lists]))
+        self._chk(self.L.svslam_rtrack_upload(self.h, n, streams, _p(ofs), (C.c_int * n)(*cnt), _p(xy), _p(mp), _p(xyz)),
+                  "rtrack_upload")
+
+    def rtrack(self, jobs, cam, params=None, chi2_th=5.991):
+        """jobs: [(stream, prev_slot, next_slot, next_img, pose[7], T_cam_w[7], npts)].
+        returns list of dict(xy, mp, pose, n_tracked, n_edges, n_outlier)."""
+        n = len(jobs)
+        arr = (RtrackJob * n)()
+        ofs, keep = 0, []
+        for i, (sid, ps, ns, img, T, Tc, npts) in enumerate(jobs):
+            arr[i] = RtrackJob(sid, ps, ns, ofs, npts, (C.c_double * 7)(*_d(T)), (C.c_double * 7)(*_d(Tc)), 0, 0, 0, 0)
+            ofs += npts
+            keep.append(np.ascontiguousarray(img, np.uint8))
+        ptrs = (C.c_void_p * n)(*[im.ctypes.data for im in keep]); st = (C.c_int * n)(*[im.shape[1] for im in keep])
+        xy = np.zeros((max(ofs, 1), 2), np.float32); mp = np.zeros(max(ofs, 1), np.int32)
+        prm = params or LkParams(3, 30, 0.01, 1e-4, 1)
+        self._chk(self.L.svslam_rtrack_batch(self.h, n, arr, ptrs, st, 0, ofs, _p(_d(cam)), _p(xy), _p(mp), C.byref(prm),
+                                             C.c_double(chi2_th)), "rtrack")
+        out = []
+        for j in arr:
+            s = slice(j.pt_ofs, j.pt_ofs + j.n_tracked)
+            out.append(dict(xy=xy[s].copy(), mp=mp[s].copy(), pose=np.array(list(j.pose)), n_tracked=j.n_tracked,
+                            n_edges=j.n_edges, n_outlier=j.n_outlier))
         return out
 
     # ---- fused tracking --------------------------------------------------------

@@ -136,6 +136,24 @@ __device__ __forceinline__ double wave_max_f64(double v)
     return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 
+// Bit-for-bit twin of host/se3.h SE3::act and Camera::project (no contraction here): the
+// LK start guess of a tracked map point must equal the host's float, because LK is integer
+// arithmetic downstream of it.
+__device__ __forceinline__ void d_project_exact(const double *T, const double *K, const double *x, double *uv)
+{
+    const double *q = T;
+    double ux = q[1] * x[2] - q[2] * x[1];
+    double uy = q[2] * x[0] - q[0] * x[2];
+    double uz = q[0] * x[1] - q[1] * x[0];
+    ux += ux; uy += uy; uz += uz;
+    double p0 = x[0] + q[3] * ux + (q[1] * uz - q[2] * uy);
+    double p1 = x[1] + q[3] * uy + (q[2] * ux - q[0] * uz);
+    double p2 = x[2] + q[3] * uz + (q[0] * uy - q[1] * ux);
+    p0 += T[4]; p1 += T[5]; p2 += T[6];
+    uv[0] = K[0] * p0 / p2 + K[2];
+    uv[1] = K[1] * p1 / p2 + K[3];
+}
+
 // The f64 geometry below is compared to the oracle at a stated tolerance, not bit for bit,
 // so FMA contraction is allowed for it (halves the f64 op count); the integer / f32 code
 // above and in k_pyramid/k_lk/k_gftt stays strictly un-contracted.

@@ -33,6 +33,9 @@
 #include <algorithm>
 #include <cstring>
 
+// f64 LM algebra, compared with the oracle at stated tolerances: FMA contraction allowed
+#pragma clang fp contract(fast)
+
 #ifndef BA_THREADS
 #define BA_THREADS 512
 #ifndef BA_MIN_WAVES_PER_SIMD
@@ -903,3 +906,4 @@ static inline size_t ba_lds_bytes(int max_kf)
     return ((np + 1) * (np + 1) + 3 * np + 36 * (size_t)max_kf + BA_WAVES + BA_PT * (size_t)max_kf + 2 * BA_CT +
             27 * BA_ROWS) * sizeof(double) + 64;
 }
+#pragma clang fp contract(off)

@@ -76,6 +76,9 @@ struct svslam_ctx {
     long long host_ns[8] = { 0 };
     bool wait_poll = true;
     int src_w = 0, src_h = 0;     // > 0: level 0 is the 2:1 decimation of src_w x src_h inputs
+    // resident feature lists (svslam_rtrack_*): two alternating buffers per stream
+    RtStore rt = {};
+    std::vector<int> rt_which, rt_count;
     hipEvent_t done = nullptr;   // recorded after the last enqueue of a call; the stream may be shared
     // a submitted, not yet collected local-BA batch owns the staging arena
     struct { bool active = false; int njobs = 0, total_kf = 0, total_lm = 0, total_obs = 0;
@@ -396,6 +399,17 @@ int svslam_create(const svslam_limits *lim, svslam_ctx **out)
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_local_ba),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ba_lds_bytes(lim->max_kf)));
     }
+    if (lim->max_streams > 0) {
+        const size_t n = (size_t)lim->max_streams * lim->max_pts;
+        for (int b = 0; b < 2; ++b) {
+            HIPCHK(c, hipMalloc(&c->rt.xy[b], n * sizeof(float2)));
+            HIPCHK(c, hipMalloc(&c->rt.mp[b], n * sizeof(int)));
+            HIPCHK(c, hipMalloc(&c->rt.xyz[b], n * 3 * sizeof(double)));
+        }
+        c->rt.max_pts = lim->max_pts;
+        c->rt_which.assign((size_t)lim->max_streams, 0);
+        c->rt_count.assign((size_t)lim->max_streams, 0);
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -405,6 +419,7 @@ void svslam_destroy(svslam_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int b = 0; b < 2; ++b) { (void)hipFree(c->rt.xy[b]); (void)hipFree(c->rt.mp[b]); (void)hipFree(c->rt.xyz[b]); }
     (void)hipFree(c->d_pyr);
     (void)hipFree(c->ar.d);
     if (c->ar.h) (void)hipHostFree(c->ar.h);
@@ -968,6 +983,141 @@ int svslam_track_batch(svslam_ctx *c, int njobs, svslam_track_job *jobs, const v
         memcpy(outlier, hp<void>(c, oout), total_pts);
     }
     return 0;
+}
+
+int svslam_rtrack_batch(svslam_ctx *c, int njobs, svslam_rtrack_job *jobs, const void *const *next_imgs,
+                        const int *strides, int src_is_device, int total_pts, const double cam[4],
+                        float *out_xy, int *out_mp, const svslam_lk_params *p, double chi2_th)
+{
+    if (njobs <= 0) return 0;
+    if (c->rt.max_pts <= 0) return fail(c, "rtrack: context created with max_streams = 0");
+    if (njobs > c->lim.max_jobs) return fail(c, "rtrack: %d jobs > max_jobs", njobs);
+    if (total_pts > c->lim.max_jobs * c->lim.max_pts) return fail(c, "rtrack: too many points");
+    std::vector<int> slots(njobs);
+    for (int i = 0; i < njobs; ++i) {
+        const svslam_rtrack_job &j = jobs[i];
+        if (check_slot(c, j.prev_slot) || check_slot(c, j.next_slot)) return -1;
+        if (j.stream < 0 || j.stream >= c->lim.max_streams) return fail(c, "rtrack: job %d stream %d out of range", i, j.stream);
+        if (j.npts != c->rt_count[(size_t)j.stream])
+            return fail(c, "rtrack: job %d says %d features, stream %d holds %d", i, j.npts, j.stream, c->rt_count[(size_t)j.stream]);
+        if (j.pt_ofs < 0 || j.pt_ofs + j.npts > total_pts) return fail(c, "rtrack: job %d point range out of bounds", i);
+        slots[i] = j.next_slot;
+    }
+    {
+        const bool dec = c->src_w > 0;
+        if (pyramid_common(c, njobs, slots.data(), next_imgs, strides, src_is_device, dec, dec ? c->src_w : c->geom.w[0],
+                           dec ? c->src_h : c->geom.h[0], false)) return -1;
+    }
+    int maxn = 0;
+    for (int i = 0; i < njobs; ++i) maxn = std::max(maxn, jobs[i].npts);
+    const size_t T = (size_t)std::max(total_pts, 1);
+    size_t base = c->ar.off;
+    size_t olk = c->ar.take(sizeof(LkJob) * njobs);
+    size_t ocam = c->ar.take(32);
+    size_t opj = c->ar.take(sizeof(PoseJob) * njobs);
+    size_t ort = c->ar.take(sizeof(RtJob) * njobs);
+    size_t in_end = c->ar.off;
+    size_t oxy = c->ar.take(sizeof(float) * 2 * T);        // compacted survivors for the host
+    size_t ompo = c->ar.take(sizeof(int) * T);
+    size_t out_end = c->ar.off;
+    // device-only scratch of this call
+    size_t oprev = c->ar.take(sizeof(float) * 2 * T);
+    size_t onext = c->ar.take(sizeof(float) * 2 * T);
+    size_t omp = c->ar.take(T);
+    size_t oxyz = c->ar.take(sizeof(double) * 3 * T);
+    size_t ostat = c->ar.take(T);
+    size_t oerr = c->ar.take(sizeof(float) * T);
+    size_t oval = c->ar.take(T);
+    size_t oout = c->ar.take(T);
+    size_t ontr = c->ar.take(sizeof(int) * njobs);
+    if (c->ar.off > c->ar.cap) return fail(c, "rtrack: staging arena too small (%zu > %zu bytes)", c->ar.off, c->ar.cap);
+    LkJob *lj = hp<LkJob>(c, olk);
+    PoseJob *pj = hp<PoseJob>(c, opj);
+    RtJob *rj = hp<RtJob>(c, ort);
+    for (int i = 0; i < njobs; ++i) {
+        const svslam_rtrack_job &j = jobs[i];
+        lj[i].prev_slot = j.prev_slot; lj[i].next_slot = j.next_slot; lj[i].pt_ofs = j.pt_ofs; lj[i].npts = j.npts;
+        pj[i].pt_ofs = j.pt_ofs; pj[i].npts = j.npts;
+        memcpy(pj[i].pose, j.pose, 56);
+        pj[i].n_inlier = 0; pj[i].pad = 0;
+        rj[i].stream = j.stream; rj[i].pt_ofs = j.pt_ofs; rj[i].npts = j.npts; rj[i].src_buf = c->rt_which[(size_t)j.stream];
+        memcpy(rj[i].T_cam_w, j.T_cam_w, 56);
+        rj[i].n_tracked = rj[i].n_edges = rj[i].n_outlier = 0; rj[i].pad = 0;
+    }
+    memcpy(hp<void>(c, ocam), cam, 32);
+    if (h2d(c, base, in_end)) return -1;
+    if (maxn > 0) {
+        hipLaunchKernelGGL(k_rt_gather, dim3(cdiv(maxn, 256), njobs), dim3(256), 0, c->stream, dp<RtJob>(c, ort), c->rt,
+                           dp<double>(c, ocam), dp<float2>(c, oprev), dp<float2>(c, onext), dp<uint8_t>(c, omp), dp<double>(c, oxyz));
+        tm_begin(c, FAM_LK, total_pts);
+        hipLaunchKernelGGL(k_lk, dim3(cdiv(maxn, LK_WAVES_PER_BLOCK), njobs), dim3(64 * LK_WAVES_PER_BLOCK), 0,
+                           c->stream, dp<LkJob>(c, olk), c->d_pyr, c->geom, dp<float2>(c, oprev),
+                           dp<float2>(c, onext), dp<uint8_t>(c, ostat), dp<float>(c, oerr), make_lk_params(p));
+        tm_end(c);
+        hipLaunchKernelGGL(k_track_filter, dim3(njobs), dim3(256), 0, c->stream,
+                           reinterpret_cast<const LkJobView *>(dp<LkJob>(c, olk)), dp<float2>(c, onext),
+                           dp<uint8_t>(c, ostat), dp<uint8_t>(c, omp), dp<uint8_t>(c, oval), dp<int>(c, ontr),
+                           c->geom.w[0], c->geom.h[0]);
+    }
+    tm_begin(c, FAM_POSE, njobs);
+    hipLaunchKernelGGL(k_pose_only, dim3(njobs), dim3(64), 0, c->stream, dp<PoseJob>(c, opj), dp<double>(c, ocam),
+                       dp<double>(c, oxyz), dp<float2>(c, onext), dp<uint8_t>(c, oval), dp<uint8_t>(c, oout),
+                       chi2_th, 4, 10);
+    tm_end(c);
+    hipLaunchKernelGGL(k_rt_finish, dim3(njobs), dim3(64), 0, c->stream, dp<RtJob>(c, ort), c->rt, dp<float2>(c, onext),
+                       dp<uint8_t>(c, ostat), dp<uint8_t>(c, oout), dp<double>(c, oxyz), dp<float2>(c, oxy), dp<int>(c, ompo));
+    HIPCHK(c, hipGetLastError());
+    if (d2h_sync(c, opj, out_end)) return -1;      // pose jobs, rt jobs, compacted survivors
+    for (int i = 0; i < njobs; ++i) {
+        svslam_rtrack_job &j = jobs[i];
+        memcpy(j.pose, pj[i].pose, 56);
+        j.n_tracked = rj[i].n_tracked; j.n_edges = rj[i].n_edges; j.n_outlier = rj[i].n_outlier;
+        c->rt_which[(size_t)j.stream] ^= 1;
+        c->rt_count[(size_t)j.stream] = j.n_tracked;
+    }
+    if (total_pts > 0) {
+        if (out_xy) memcpy(out_xy, hp<void>(c, oxy), sizeof(float) * 2 * total_pts);
+        if (out_mp) memcpy(out_mp, hp<void>(c, ompo), sizeof(int) * total_pts);
+    }
+    return 0;
+}
+
+int svslam_rtrack_upload(svslam_ctx *c, int n, const int *streams, const int *ofs, const int *counts,
+                         const float *xy, const int *mp, const double *xyz)
+{
+    if (n <= 0) return 0;
+    if (c->rt.max_pts <= 0) return fail(c, "rtrack_upload: context created with max_streams = 0");
+    if (n > c->lim.max_jobs) return fail(c, "rtrack_upload: %d streams > max_jobs", n);
+    int total = 0, maxc = 0;
+    for (int i = 0; i < n; ++i) {
+        if (streams[i] < 0 || streams[i] >= c->lim.max_streams) return fail(c, "rtrack_upload: stream %d out of range", streams[i]);
+        if (counts[i] < 0 || counts[i] > c->lim.max_pts) return fail(c, "rtrack_upload: %d features > max_pts %d", counts[i], c->lim.max_pts);
+        total = std::max(total, ofs[i] + counts[i]); maxc = std::max(maxc, counts[i]);
+    }
+    if (c->ba_pending.active) return fail(c, "a submitted local-BA batch owns this context: call svslam_local_ba_collect first");
+    c->ar.reset();
+    const size_t T = (size_t)std::max(total, 1);
+    size_t oj = c->ar.take(sizeof(RtUpJob) * n);
+    size_t oxy = c->ar.take(sizeof(float) * 2 * T);
+    size_t omp = c->ar.take(sizeof(int) * T);
+    size_t oxyz = c->ar.take(sizeof(double) * 3 * T);
+    if (c->ar.off > c->ar.cap) return fail(c, "rtrack_upload: staging arena too small");
+    RtUpJob *uj = hp<RtUpJob>(c, oj);
+    for (int i = 0; i < n; ++i) {
+        uj[i].stream = streams[i]; uj[i].ofs = ofs[i]; uj[i].count = counts[i]; uj[i].dst_buf = c->rt_which[(size_t)streams[i]];
+        c->rt_count[(size_t)streams[i]] = counts[i];
+    }
+    if (total > 0) {
+        memcpy(hp<void>(c, oxy), xy, sizeof(float) * 2 * total);
+        memcpy(hp<void>(c, omp), mp, sizeof(int) * total);
+        memcpy(hp<void>(c, oxyz), xyz, sizeof(double) * 3 * total);
+    }
+    if (h2d(c, 0, c->ar.off)) return -1;
+    if (maxc > 0)
+        hipLaunchKernelGGL(k_rt_store, dim3(cdiv(maxc, 256), n), dim3(256), 0, c->stream, dp<RtUpJob>(c, oj), c->rt,
+                           dp<float2>(c, oxy), dp<int>(c, omp), dp<double>(c, oxyz));
+    HIPCHK(c, hipGetLastError());
+    return d2h_sync(c, 0, 0);       // the staging memory is reused by the next call
 }
 
 } // extern "C"

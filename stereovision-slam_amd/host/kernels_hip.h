@@ -55,6 +55,12 @@ public:
               int total, const double *cam, const float *prev_xy, float *next_xy, const uint8_t *has_mp,
               const double *xyz, uint8_t *status, uint8_t *outlier, const svslam_lk_params *p, double chi2_th)
     { return svslam_track_batch(ctx_, n, jobs, imgs, strides, is_device, total, cam, prev_xy, next_xy, has_mp, xyz, status, outlier, p, chi2_th); }
+    int rtrack(int n, svslam_rtrack_job *jobs, const void *const *imgs, const int *strides, int is_device, int total,
+               const double *cam, float *out_xy, int *out_mp, const svslam_lk_params *p, double chi2_th)
+    { return svslam_rtrack_batch(ctx_, n, jobs, imgs, strides, is_device, total, cam, out_xy, out_mp, p, chi2_th); }
+    int rtrack_upload(int n, const int *streams, const int *ofs, const int *counts, const float *xy, const int *mp,
+                      const double *xyz)
+    { return svslam_rtrack_upload(ctx_, n, streams, ofs, counts, xy, mp, xyz); }
     int lk(int n, const svslam_lk_job *jobs, int total, const float *prev_xy, float *next_xy, uint8_t *status,
            float *err, const svslam_lk_params *p)
     { return svslam_lk_batch(ctx_, n, jobs, total, prev_xy, next_xy, status, err, p); }

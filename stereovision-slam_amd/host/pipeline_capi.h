@@ -21,6 +21,8 @@ typedef struct svs_pipe_config {
     int src_width, src_height; /* > 0: the frames handed in are full-resolution src_width x src_height and
                                   are decimated 2:1 to width x height on the way into the pyramid (the
                                   resize of Dataset::NextFrame, src/dataset.cpp:126-129, fused)        */
+    int resident_track;       /* 1: the features of every stream's last frame stay in device memory
+                                  (svslam_rtrack_*); used when backend_on <= 1                      */
 } svs_pipe_config;
 
 typedef struct svs_frame_result {

@@ -31,6 +31,7 @@ svs::Config to_config(const svs_pipe_config &c)
     g.cam_r.fx = c.cam_r[0]; g.cam_r.fy = c.cam_r[1]; g.cam_r.cx = c.cam_r[2]; g.cam_r.cy = c.cam_r[3];
     g.cam_l.pose = svs::SE3(c.ext_l); g.cam_r.pose = svs::SE3(c.ext_r);
     g.src_width = c.src_width; g.src_height = c.src_height;
+    g.resident_track = c.resident_track;
     return g;
 }
 } // namespace
@@ -49,6 +50,7 @@ void *svs_pipe_create(const svs_pipe_config *cfg, int nstreams, int device)
         lim.max_slots = 3 * nstreams; lim.max_jobs = 2 * nstreams; // one call may build left+right pyramids
         lim.max_pts = 512; lim.max_corners = cfg->num_features;
         lim.max_kf = cfg->num_active_keyframes + 1; lim.max_lm = cfg->max_lm; lim.max_obs = cfg->max_obs;
+        lim.max_streams = (cfg->resident_track && cfg->backend_on <= 1) ? nstreams : 0;
         svslam_limits lim_front = lim;
         if (cfg->backend_on >= 2) { lim_front.max_kf = 0; lim_front.max_lm = 0; lim_front.max_obs = 0; }   // BA lives in its own context
         h->kernels.reset(SVS_PIPE_MAKE_KERNELS(lim_front));

@@ -48,6 +48,7 @@ struct Config {                       // config/stereo_slam_configs/config-00.ya
     int num_active_keyframes = 10;
     int backend_on = 1;
     int src_width = 0, src_height = 0;   // > 0: input frames are full resolution, decimated into the pyramid
+    int resident_track = 1;              // last-frame features stay in device memory (needs backend_on <= 1)
     double chi2_th = 5.991;
     int width = 620, height = 188;
     Camera cam_l, cam_r;
@@ -263,6 +264,7 @@ struct Stream {
     long frame_factory_id = 0, kf_factory_id = 0;
     int slot_prev = 0, slot_cur = 1, slot_right = 2;
     bool is_new_kf = false, init_ok = false;
+    int dev_feat = 0;                    // features of the last frame held by the kernel provider (resident mode)
     // scratch between stages (per stream: the stages run one thread per stream)
     std::vector<int> tri_idx;
     BaGather ba;
@@ -324,8 +326,13 @@ public:
         cnt_.frames += S;
         st_[0] += now_ns() - t_b;
         if (!TS.empty()) {
-            TrackPrepareAndRun(TS, left, strides, is_device);
-            { STimer t_(st_[2]); pool_.parallel_for((int)TS.size(), [&](int i) { TrackFinish(TS[i], i); }); }
+            if (resident()) {
+                TrackResidentRun(TS, left, strides, is_device);
+                { STimer t_(st_[2]); pool_.parallel_for((int)TS.size(), [&](int i) { TrackFinishResident(TS[i], i); }); }
+            } else {
+                TrackPrepareAndRun(TS, left, strides, is_device);
+                { STimer t_(st_[2]); pool_.parallel_for((int)TS.size(), [&](int i) { TrackFinish(TS[i], i); }); }
+            }
             for (int s : TS) if (streams_[s]->is_new_kf) KS.push_back(s);
         }
         std::vector<int> DS = IS;                 // streams that detect this frame
@@ -355,6 +362,9 @@ public:
             BackendCollect();
             if (!MS.empty()) BackendSubmit(MS);
         }
+        // frames whose feature list or map points changed on the host (init, keyframes, BA) replace
+        // the resident copy; every other frame's list never left the device
+        if (resident() && !DS.empty()) UploadFeatures(DS);
         long long t_e = now_ns();
         for (int s : TS) {
             Stream &st = *streams_[s];
@@ -366,7 +376,7 @@ public:
             std::memcpy(r.pose, st.current->pose.v, sizeof(r.pose));
             r.status = (int)st.status;
             r.is_keyframe = st.current->is_keyframe ? 1 : 0;
-            r.n_features = (int)st.current->left.size();
+            r.n_features = resident() ? st.dev_feat : (int)st.current->left.size();
             r.n_inliers = st.tracking_inliers;
             r.frame_id = st.current->id;
             r.keyframe_id = st.current->is_keyframe ? st.current->keyframe_id : -1;
@@ -492,6 +502,100 @@ private:
                        prev_xy_.data(), next_xy_.data(), has_mp_.data(), xyz_.data(), status_.data(),
                        outlier_.data(), &prm, 5.991), "track"); }
         cnt_.track_pts += ofs; cnt_.pyr_left += n;
+    }
+
+    bool resident() const { return cfg_.resident_track && cfg_.backend_on <= 1; }
+
+    // ---- Track() with the last frame's features resident in the kernel provider's memory: the
+    // gather of :331-347 and the scatter of :361-381 / :546-553 run on the device, the host
+    // supplies the predicted pose and reads counts (and, for keyframes, the survivor list).
+    void TrackResidentRun(const std::vector<int> &TS, const void *const *left, const int *strides, int is_device)
+    {
+        const int n = (int)TS.size();
+        long long t_p = now_ns();
+        jobs_rt_.resize(n);
+        imgs_.resize(n); strides_.resize(n);
+        int ofs = 0;
+        for (int i = 0; i < n; ++i) {
+            Stream &st = *streams_[TS[i]];
+            svslam_rtrack_job &j = jobs_rt_[i];
+            Frame *cur = st.current, *last = st.last;
+            cur->pose = st.relative_motion * last->pose;            // :655
+            const SE3 T_caml_w = cfg_.cam_l.pose * cur->pose;
+            j.stream = TS[i]; j.prev_slot = st.slot_prev; j.next_slot = st.slot_cur;
+            j.pt_ofs = ofs; j.npts = st.dev_feat;
+            std::memcpy(j.pose, cur->pose.v, sizeof(j.pose));
+            std::memcpy(j.T_cam_w, T_caml_w.v, sizeof(j.T_cam_w));
+            j.n_tracked = j.n_edges = j.n_outlier = 0; j.reserved = 0;
+            ofs += j.npts;
+            imgs_[i] = left[TS[i]];
+            strides_[i] = strides ? strides[TS[i]] : (cfg_.src_width > 0 ? cfg_.src_width : cfg_.width);
+        }
+        const size_t tot = (size_t)std::max(ofs, 1);
+        next_xy_.resize(2 * tot); rt_mp_.resize(tot);
+        st_[1] += now_ns() - t_p;
+        svslam_lk_params prm = { 3, 30, 0.01, 1e-4, 1 };            // :353-357
+        { KTimer kt_(cnt_); check(k_.rtrack(n, jobs_rt_.data(), imgs_.data(), strides_.data(), is_device, ofs, cam_l_,
+                       next_xy_.data(), rt_mp_.data(), &prm, 5.991), "rtrack"); }
+        cnt_.track_pts += ofs; cnt_.pyr_left += n;
+    }
+
+    void TrackFinishResident(int s, int i)
+    {
+        Stream &st = *streams_[s];
+        const svslam_rtrack_job &j = jobs_rt_[i];
+        Frame *cur = st.current;
+        st.dev_feat = j.n_tracked;
+        st.c_pose_edges += j.n_edges;
+        cur->pose = SE3(j.pose);                                   // :542
+        st.tracking_inliers = j.n_edges - j.n_outlier;             // :556
+        if (st.tracking_inliers > cfg_.num_features_tracking) st.status = FrontendStatus::TRACKING_GOOD;
+        else if (st.tracking_inliers > cfg_.num_features_tracking_bad) st.status = FrontendStatus::TRACKING_BAD;
+        else st.status = FrontendStatus::LOST;                     // :665-679
+        if (st.tracking_inliers >= cfg_.num_features_needed_for_keyframe) return;
+        // InsertKeyframe :576-616 — only now does the host need the frame's features
+        cur->left.reserve((size_t)j.n_tracked + (size_t)cfg_.num_features);
+        for (int r = 0; r < j.n_tracked; ++r) {
+            Feature f;
+            f.x = next_xy_[2 * ((size_t)j.pt_ofs + r)]; f.y = next_xy_[2 * ((size_t)j.pt_ofs + r) + 1];
+            f.mp = rt_mp_[(size_t)j.pt_ofs + r];
+            cur->left.push_back(f);
+        }
+        MakeKeyFrame(st);
+        st.frontend_prev_kf = st.frontend_current_kf;
+        st.frontend_current_kf = cur;
+        cur->prev_keyframe = st.frontend_prev_kf;
+        cur->relative_pose_pkf = cur->pose * st.frontend_prev_kf->pose.inverse();
+        for (size_t k = 0; k < cur->left.size(); ++k)               // SetObservationsForKeyFrame :560-574
+            if (cur->left[k].mp >= 0) st.map.AddObservation(st.map.point(cur->left[k].mp), ObsRef{ cur, (int)k, true });
+        st.is_new_kf = true;
+    }
+
+    void UploadFeatures(const std::vector<int> &DS)
+    {
+        const int n = (int)DS.size();
+        up_stream_.resize(n); up_ofs_.resize(n); up_cnt_.resize(n);
+        int ofs = 0;
+        for (int i = 0; i < n; ++i) {
+            up_stream_[i] = DS[i]; up_ofs_[i] = ofs; up_cnt_[i] = (int)streams_[DS[i]]->current->left.size();
+            ofs += up_cnt_[i];
+        }
+        const size_t tot = (size_t)std::max(ofs, 1);
+        up_xy_.resize(2 * tot); up_mp_.resize(tot); up_xyz_.resize(3 * tot);
+        pool_.parallel_for(n, [&](int i) {
+            Stream &st = *streams_[DS[i]];
+            size_t g = (size_t)up_ofs_[i];
+            for (const Feature &f : st.current->left) {
+                up_xy_[2 * g] = f.x; up_xy_[2 * g + 1] = f.y; up_mp_[g] = (int)f.mp;
+                const MapPoint *mp = st.map.point(f.mp);
+                if (mp) { up_xyz_[3 * g] = mp->pos[0]; up_xyz_[3 * g + 1] = mp->pos[1]; up_xyz_[3 * g + 2] = mp->pos[2]; }
+                else { up_xyz_[3 * g] = 0; up_xyz_[3 * g + 1] = 0; up_xyz_[3 * g + 2] = 1; }
+                ++g;
+            }
+            st.dev_feat = up_cnt_[i];
+        });
+        { KTimer kt_(cnt_); check(k_.rtrack_upload(n, up_stream_.data(), up_ofs_.data(), up_cnt_.data(), up_xy_.data(),
+                                                   up_mp_.data(), up_xyz_.data()), "rtrack_upload"); }
     }
 
     // sets st.is_new_kf if the frame became a keyframe
@@ -916,6 +1020,10 @@ private:
     double cam_l_[4], cam_r_[4];
     // staging vectors (reused across frames: no per-frame allocation in steady state)
     std::vector<svslam_track_job> jobs_track_;
+    std::vector<svslam_rtrack_job> jobs_rt_;
+    std::vector<int> rt_mp_, up_stream_, up_ofs_, up_cnt_, up_mp_;
+    std::vector<float> up_xy_;
+    std::vector<double> up_xyz_;
     std::vector<svslam_lk_job> jobs_lk_;
     std::vector<svslam_gftt_job> jobs_gftt_;
     std::vector<svslam_tri_job> jobs_tri_;

@@ -257,6 +257,47 @@ def svs_mod():
     return importlib.import_module("stereovision-slam_amd")
 
 
+def test_resident_track_matches_track(svs, orc, frames):
+    """svslam_rtrack_* (features resident in HBM, gather/scatter on the device) == svslam_track_batch
+    fed by the host gather of src/frontend.cpp:331-347, over two consecutive frames."""
+    l0, r0 = frames[0]
+    pts = orc.gftt(l0)
+    q, st, _ = orc.lk(l0, r0, pts, pts)
+    xyz, ok = orc.triangulate(cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R, pts, q)
+    mp = np.where((st > 0) & (ok > 0), np.arange(len(pts)), -1).astype(np.int32)
+    c = svs.Context(cm.W, cm.H, max_slots=3, max_jobs=1, max_kf=0, max_lm=0, max_obs=0, max_streams=2)
+    c.pyramid([0], [l0])
+    c.rtrack_upload([(1, pts, mp, xyz)])
+    pose = cm.EXT_L.copy()
+    cur_xy, cur_mp, cur_xyz = pts, mp, xyz
+    slots = (0, 1)
+    for f in (1, 2):
+        img = frames[f][0]
+        Tc = orc.se3_mul(cm.EXT_L, pose)
+        (r,) = c.rtrack([(1, slots[0], slots[1], img, pose, Tc, len(cur_xy))], cm.CAM)
+        # host-side gather exactly as the pipeline's non-resident path does it
+        guess = cur_xy.copy()
+        has = cur_mp >= 0
+        for i in np.nonzero(has)[0]:
+            p = orc.se3_act(Tc, cur_xyz[i])
+            guess[i] = (np.float32(cm.CAM[0] * p[0] / p[2] + cm.CAM[2]), np.float32(cm.CAM[1] * p[1] / p[2] + cm.CAM[3]))
+        c2 = svs.Context(cm.W, cm.H, max_slots=2, max_jobs=1, max_kf=0, max_lm=0, max_obs=0)
+        c2.pyramid([0], [frames[f - 1][0]])
+        (t,) = c2.track([(0, 1, img, pose, cur_xy, guess, has.astype(np.uint8), np.where(has[:, None], cur_xyz, [0, 0, 1.0]))], cm.CAM)
+        c2.close()
+        keep = t["status"] > 0
+        want_mp = np.where(has & (t["outlier"] == 0), cur_mp, -1)[keep]
+        assert r["n_tracked"] == keep.sum() == t["n_tracked"]
+        assert np.array_equal(r["xy"].view(np.uint32), t["next_xy"][keep].view(np.uint32))
+        assert np.array_equal(r["mp"], want_mp)
+        assert r["n_edges"] == (has & keep).sum() and r["n_outlier"] == (has & keep & (t["outlier"] > 0)).sum()
+        assert np.array_equal(r["pose"], t["pose"])
+        pose = r["pose"]
+        cur_xyz = cur_xyz[keep]; cur_xy = r["xy"]; cur_mp = r["mp"]
+        slots = (slots[1], slots[0])
+    c.close()
+
+
 def test_track_fused_matches_separate_calls(ctx, orc, frames):
     l0, r0 = frames[0]
     l1, _ = frames[1]
