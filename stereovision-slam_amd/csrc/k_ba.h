@@ -45,6 +45,7 @@
 #define BA_WAVES (BA_THREADS / 64)
 #define BA_ROWS (BA_THREADS / 16)
 #define BA_MAX_NP 192
+#define BA_DIAG_PARTS 3
 
 struct BaJob { int kf_ofs, nkf, lm_ofs, nlm, obs_ofs, nobs, iters_done, reserved; };
 struct BaCams { double cam[2][4]; double ext[2][7]; };
@@ -69,7 +70,6 @@ struct BaWork {              // per-job HBM scratch, strided by the context limi
     double *Hll = nullptr;   // [9*max_lm]
     double *Dinv = nullptr;  // [9*max_lm]
     double *bl = nullptr;    // [3*max_lm]
-    double *db = nullptr;    // [3*max_lm]
     double *poses_b = nullptr; // [7*max_kf]
     double *pts_b = nullptr;   // [3*max_lm]
     double *pts_i = nullptr;   // [3*max_lm]  landmark positions in the internal numbering
@@ -82,7 +82,7 @@ static inline hipError_t ba_work_alloc(BaWork &w, int jobs, int max_kf, int max_
     if (max_kf <= 0 || max_lm <= 0 || max_obs <= 0) return hipSuccess;
     size_t J = jobs;
     size_t nd = J * ((size_t)max_obs * (2 + 18) + (size_t)max_kf * 7 +
-                     (size_t)max_lm * (9 + 9 + 3 + 3 + 3 + 3));
+                     (size_t)max_lm * (9 + 9 + 3 + 3 + 3));
     hipError_t e = hipMalloc(&w.all, nd * sizeof(double));
     if (e != hipSuccess) return e;
     double *p = static_cast<double *>(w.all);
@@ -92,7 +92,6 @@ static inline hipError_t ba_work_alloc(BaWork &w, int jobs, int max_kf, int max_
     w.Hll = p; p += J * 9 * max_lm;
     w.Dinv = p; p += J * 9 * max_lm;
     w.bl = p; p += J * 3 * max_lm;
-    w.db = p; p += J * 3 * max_lm;
     w.pts_b = p; p += J * 3 * max_lm;
     w.pts_i = p; p += J * 3 * max_lm;
     return hipSuccess;
@@ -103,10 +102,10 @@ static inline void ba_work_free(BaWork &w) { if (w.all) (void)hipFree(w.all); w.
 // aux layout per job (ints), offsets from ba_aux_layout():
 //   lm_estart[nlm+1] lm_edges[nobs] kf_estart[nkf+1] lm_orig[nlm]
 //   lm_bstart[nlm+1] blk_kf[nblk] blk_lm[nblk] kf_pidx[nkf] act_kf[nkf]
-//   pc_start[npairs+1] pc_y[ncontrib] pc_w[ncontrib] pc_lm[ncontrib] pb_start[na+1] pb_blk[nblk]
+//   pc_start[npairs+1] pc_y[ncontrib] pc_w[ncontrib] pc_lm[ncontrib]
 struct BaAuxLayout {
     size_t lm_estart, lm_edges, kf_estart, lm_orig, lm_bstart, blk_kf, blk_lm, kf_pidx, act_kf;
-    size_t pc_start, pc_y, pc_w, pc_lm, pb_start, pb_blk, total;
+    size_t pc_start, pc_y, pc_w, pc_lm, total;
 };
 __host__ __device__ inline BaAuxLayout ba_aux_layout(int nkf, int nlm, int nobs, int nblk, int na, int ncontrib)
 {
@@ -125,8 +124,6 @@ __host__ __device__ inline BaAuxLayout ba_aux_layout(int nkf, int nlm, int nobs,
     L.pc_y = o; o += ncontrib;
     L.pc_w = o; o += ncontrib;
     L.pc_lm = o; o += ncontrib;
-    L.pb_start = o; o += (size_t)na + 1;
-    L.pb_blk = o; o += nblk;
     L.total = o;
     return L;
 }
@@ -135,7 +132,7 @@ __host__ __device__ inline int ba_pair_index(int a, int b, int na) { return a * 
 
 struct BaHostStruct {        // scratch reused across jobs
     std::vector<int> lm_estart, lm_edges, kf_estart, lm_orig, lm_new, srt, ostart, lm_bstart, blk_kf, blk_lm, kf_pidx,
-        act_kf, pc_start, pc_y, pc_w, pc_lm, pb_start, pb_blk, fill, fill2, bpa;
+        act_kf, pc_start, pc_y, pc_w, pc_lm, fill, bpa;
     std::vector<BaRec> recs;     // [0,nobs) landmark-major (= lm_edges order), [nobs,2nobs) pose-major
     int nblk = 0, na = 0, ncontrib = 0;
 
@@ -242,39 +239,33 @@ struct BaHostStruct {        // scratch reused across jobs
         // (Y,W) block pairs per pose pair, counting sort by pair; landmark-ascending inside a pair
         const int npairs = na * (na + 1) / 2;
         pc_start.assign((size_t)npairs + 1, 0);
-        pb_start.assign((size_t)na + 1, 0);
         {
             // active-pose index of every block, once
             bpa.resize(nblk);
             for (int b = 0; b < nblk; ++b) bpa[b] = kf_pidx[blk_kf[b]];
             const int *__restrict lbs = lm_bstart.data(), *__restrict pa = bpa.data();
-            int *__restrict pcs = pc_start.data(), *__restrict pbs = pb_start.data();
+            int *__restrict pcs = pc_start.data();
             for (int l = 0; l < nlm; ++l) {
                 const int b0 = lbs[l], b1 = lbs[l + 1];
                 for (int u = b0; u < b1; ++u) {
                     const int pu = pa[u];
-                    pbs[pu + 1]++;
                     const int base = pu * na - pu * (pu - 1) / 2 - pu;
                     for (int v = u; v < b1; ++v) pcs[base + pa[v] + 1]++;
                 }
             }
         }
         for (int p = 0; p < npairs; ++p) pc_start[p + 1] += pc_start[p];
-        for (int a = 0; a < na; ++a) pb_start[a + 1] += pb_start[a];
         ncontrib = pc_start[npairs];
         pc_y.resize(ncontrib); pc_w.resize(ncontrib); pc_lm.resize(ncontrib);
-        pb_blk.resize(nblk);
         fill.assign(pc_start.begin(), pc_start.begin() + npairs);
-        fill2.assign(pb_start.begin(), pb_start.begin() + na);
         {
             const int *__restrict lbs = lm_bstart.data(), *__restrict pa = bpa.data();
-            int *__restrict f1 = fill.data(), *__restrict f2 = fill2.data(), *__restrict pbb = pb_blk.data();
+            int *__restrict f1 = fill.data();
             int *__restrict py = pc_y.data(), *__restrict pw = pc_w.data(), *__restrict pl = pc_lm.data();
             for (int l = 0; l < nlm; ++l) {
                 const int b0 = lbs[l], b1 = lbs[l + 1];
                 for (int u = b0; u < b1; ++u) {
                     const int pu = pa[u];
-                    pbb[f2[pu]++] = u;
                     const int base = pu * na - pu * (pu - 1) / 2 - pu;
                     for (int v = u; v < b1; ++v) {
                         const int q = f1[base + pa[v]]++;
@@ -298,7 +289,6 @@ struct BaHostStruct {        // scratch reused across jobs
         cp(L.kf_pidx, kf_pidx, j.nkf); cp(L.act_kf, act_kf, j.nkf);
         cp(L.pc_start, pc_start, (size_t)na * (na + 1) / 2 + 1); cp(L.pc_y, pc_y, ncontrib); cp(L.pc_w, pc_w, ncontrib);
         cp(L.pc_lm, pc_lm, ncontrib);
-        cp(L.pb_start, pb_start, (size_t)na + 1); cp(L.pb_blk, pb_blk, nblk);
         d.kf_ofs = j.kf_ofs; d.nkf = j.nkf; d.lm_ofs = j.lm_ofs; d.nlm = j.nlm; d.obs_ofs = j.obs_ofs; d.nobs = j.nobs;
         d.nblk = nblk; d.na = na; d.ncontrib = ncontrib; d.iters_done = 0; d.rec_ofs = 0;
     }
@@ -418,7 +408,8 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
     double *PTab = red + BA_WAVES;
     double *CTab = PTab + BA_PT * na;
     double *part = CTab + 2 * BA_CT;               // [BA_ROWS][27] pose-pass partial sums
-    int *iflag = reinterpret_cast<int *>(part + 27 * BA_ROWS);
+    double *spart = part + 27 * BA_ROWS;           // [na * BA_DIAG_PARTS][42] Schur partial sums of the diagonal pairs
+    int *iflag = reinterpret_cast<int *>(spart + 42 * BA_DIAG_PARTS * na);
 
     const BaCams &cams = *camsp;
     double *poses = poses_all + (size_t)jd.kf_ofs * 7;
@@ -434,7 +425,6 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
     const int *blk_kf = aux + AL.blk_kf, *blk_lm = aux + AL.blk_lm;
     const int *kf_pidx = aux + AL.kf_pidx, *act_kf = aux + AL.act_kf;
     const int *pc_start = aux + AL.pc_start, *pc_y = aux + AL.pc_y, *pc_w = aux + AL.pc_w, *pc_lm = aux + AL.pc_lm;
-    const int *pb_start = aux + AL.pb_start, *pb_blk = aux + AL.pb_blk;
 
     const size_t J = job;
     double *err = wk.err + J * 2 * wk.max_obs;
@@ -442,7 +432,6 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
     double *Hll = wk.Hll + J * 9 * wk.max_lm;
     double *Dinv = wk.Dinv + J * 9 * wk.max_lm;
     double *bl = wk.bl + J * 3 * wk.max_lm;
-    double *db = wk.db + J * 3 * wk.max_lm;
     double *poses_b = wk.poses_b + J * 7 * wk.max_kf;
     double *pts_b = wk.pts_b + J * 3 * wk.max_lm;
     double *pts = wk.pts_i + J * 3 * wk.max_lm;            // internal numbering (see BaHostStruct::build)
@@ -615,7 +604,7 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
         }
         double rho = 0; int qmax = 0;
         do {
-            // backup, Dinv / db / Y, S = blockdiag(Hpp) + lambda I
+            // backup, Dinv, S = blockdiag(Hpp) + lambda I
             for (int i = tid; i < 7 * nkf; i += BA_THREADS) poses_b[i] = poses[i];
             for (int i = tid; i < 3 * nlm; i += BA_THREADS) pts_b[i] = pts[i];
             for (int j = tid; j < nlm; j += BA_THREADS) {
@@ -628,9 +617,6 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
                 double *dj = Dinv + 9 * (size_t)j;
 #pragma unroll
                 for (int t = 0; t < 9; ++t) dj[t] = Di[t];
-                const double b0 = bl[3 * j], b1 = bl[3 * j + 1], b2 = bl[3 * j + 2];
-#pragma unroll
-                for (int a = 0; a < 3; ++a) db[3 * j + a] = Di[a * 3] * b0 + Di[a * 3 + 1] * b1 + Di[a * 3 + 2] * b2;
             }
             for (int i = tid; i < np * np; i += BA_THREADS) {
                 int r = i / np, c = i - r * np;
@@ -641,76 +627,101 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
             }
             __syncthreads();
             BA_PROF(2);
-            // ---- Schur assembly: one 16-lane row per pose pair (then one per pose for bs)
+            // ---- Schur assembly on 16-lane rows.  A diagonal pose pair (a,a) lists every block of
+            // pose a (the heavy tasks: most landmarks are seen from one keyframe), an off-diagonal
+            // pair only the landmarks two poses share; the diagonal pairs are therefore cut into
+            // BA_DIAG_PARTS row tasks whose partial sums are combined in a fixed order afterwards,
+            // and they also produce the reduced right-hand side bs = bp - sum Y bl on the way.
             {
                 const int npairs = na * (na + 1) / 2;
                 const int row = tid >> 4, rl = tid & 15;
-                for (int t = row; t < npairs + na; t += BA_ROWS) {
-                    if (t < npairs) {
-                        int a = 0, rem = t;
-                        while (rem >= na - a) { rem -= na - a; ++a; }
-                        const int b = a + rem;
-                        double acc[36];
-#pragma unroll
-                        for (int z = 0; z < 36; ++z) acc[z] = 0;
-                        for (int c = pc_start[t] + rl; c < pc_start[t + 1]; c += 16) {
-                            double yy[18], ww[18];
-                            const int by = pc_y[c], bw = pc_w[c];
-                            ld_block18(W + 18 * (size_t)by, ww);
-                            {
-                                const double *Di = Dinv + 9 * (size_t)pc_lm[c];      // symmetric
-                                const double d00 = Di[0], d01 = Di[1], d02 = Di[2], d11 = Di[4], d12 = Di[5], d22 = Di[8];
-#pragma unroll
-                                for (int r = 0; r < 6; ++r) {
-                                    const double x0 = ww[r * 3], x1 = ww[r * 3 + 1], x2 = ww[r * 3 + 2];
-                                    yy[r * 3 + 0] = x0 * d00 + x1 * d01 + x2 * d02;
-                                    yy[r * 3 + 1] = x0 * d01 + x1 * d11 + x2 * d12;
-                                    yy[r * 3 + 2] = x0 * d02 + x1 * d12 + x2 * d22;
-                                }
-                            }
-                            if (bw != by) ld_block18(W + 18 * (size_t)bw, ww);
-#pragma unroll
-                            for (int r = 0; r < 6; ++r)
-#pragma unroll
-                                for (int cc = 0; cc < 6; ++cc)
-                                    acc[r * 6 + cc] += yy[r * 3] * ww[cc * 3] + yy[r * 3 + 1] * ww[cc * 3 + 1] + yy[r * 3 + 2] * ww[cc * 3 + 2];
-                        }
-#pragma unroll
-                        for (int z = 0; z < 36; ++z) acc[z] = row_sum_f64(acc[z]);
-                        // every lane of the row holds the 36 sums; lane l retires entries l, l+16, l+32
-#pragma unroll
-                        for (int g = 0; g < 3; ++g) {
-                            double mine = acc[16 * g];
-#pragma unroll
-                            for (int z = 1; z < 16; ++z) if (16 * g + z < 36) mine = (rl == z) ? acc[16 * g + z] : mine;
-                            const int z = 16 * g + rl;
-                            if (z < 36) {
-                                const int r = z / 6, cc = z % 6;
-                                S[(size_t)(6 * a + r) * ld + 6 * b + cc] -= mine;
-                                if (a != b) S[(size_t)(6 * b + cc) * ld + 6 * a + r] -= mine;
-                            }
-                        }
+                const int ntask = na * BA_DIAG_PARTS + npairs;
+                for (int t = row; t < ntask; t += BA_ROWS) {
+                    int a, b2, c0, c1;
+                    const bool diag = t < na * BA_DIAG_PARTS;
+                    if (diag) {
+                        a = b2 = t / BA_DIAG_PARTS;
+                        const int pr = ba_pair_index(a, a, na), s0 = pc_start[pr], e0 = pc_start[pr + 1];
+                        const int L = (e0 - s0 + BA_DIAG_PARTS - 1) / BA_DIAG_PARTS;
+                        c0 = s0 + (t % BA_DIAG_PARTS) * L; c1 = min(e0, c0 + L);
                     } else {
-                        const int a = t - npairs;
-                        double acc[6] = { 0, 0, 0, 0, 0, 0 };
-                        for (int i = pb_start[a] + rl; i < pb_start[a + 1]; i += 16) {
-                            const int b = pb_blk[i];
-                            double w1[18];
-                            ld_block18(W + 18 * (size_t)b, w1);
-                            const double *d3 = db + 3 * (size_t)blk_lm[b];
-                            const double d0 = d3[0], d1 = d3[1], d2 = d3[2];
+                        const int pr = t - na * BA_DIAG_PARTS;
+                        int rem = pr; a = 0;
+                        while (rem >= na - a) { rem -= na - a; ++a; }
+                        b2 = a + rem;
+                        if (a == b2) continue;
+                        c0 = pc_start[pr]; c1 = pc_start[pr + 1];
+                    }
+                    double acc[36], accb[6];
 #pragma unroll
-                            for (int r = 0; r < 6; ++r) acc[r] += w1[r * 3] * d0 + w1[r * 3 + 1] * d1 + w1[r * 3 + 2] * d2;
+                    for (int z = 0; z < 36; ++z) acc[z] = 0;
+#pragma unroll
+                    for (int z = 0; z < 6; ++z) accb[z] = 0;
+                    for (int c = c0 + rl; c < c1; c += 16) {
+                        double yy[18], ww[18];
+                        const int by = pc_y[c], bw = pc_w[c], lmj = pc_lm[c];
+                        ld_block18(W + 18 * (size_t)by, ww);
+                        {
+                            const double *Di = Dinv + 9 * (size_t)lmj;      // symmetric
+                            const double d00 = Di[0], d01 = Di[1], d02 = Di[2], d11 = Di[4], d12 = Di[5], d22 = Di[8];
+#pragma unroll
+                            for (int r = 0; r < 6; ++r) {
+                                const double x0 = ww[r * 3], x1 = ww[r * 3 + 1], x2 = ww[r * 3 + 2];
+                                yy[r * 3 + 0] = x0 * d00 + x1 * d01 + x2 * d02;
+                                yy[r * 3 + 1] = x0 * d01 + x1 * d11 + x2 * d12;
+                                yy[r * 3 + 2] = x0 * d02 + x1 * d12 + x2 * d22;
+                            }
                         }
+                        if (diag) {
+                            const double *b3 = bl + 3 * (size_t)lmj;
+                            const double g0 = b3[0], g1 = b3[1], g2 = b3[2];
 #pragma unroll
-                        for (int r = 0; r < 6; ++r) acc[r] = row_sum_f64(acc[r]);
-                        if (rl < 6) {
-                            double v = acc[0];
+                            for (int r = 0; r < 6; ++r) accb[r] += yy[r * 3] * g0 + yy[r * 3 + 1] * g1 + yy[r * 3 + 2] * g2;
+                        }
+                        if (bw != by) ld_block18(W + 18 * (size_t)bw, ww);
 #pragma unroll
-                            for (int r = 1; r < 6; ++r) v = (rl == r) ? acc[r] : v;
-                            bs[6 * a + rl] = bp[6 * a + rl] - v;
+                        for (int r = 0; r < 6; ++r)
+#pragma unroll
+                            for (int cc = 0; cc < 6; ++cc)
+                                acc[r * 6 + cc] += yy[r * 3] * ww[cc * 3] + yy[r * 3 + 1] * ww[cc * 3 + 1] + yy[r * 3 + 2] * ww[cc * 3 + 2];
+                    }
+#pragma unroll
+                    for (int z = 0; z < 36; ++z) acc[z] = row_sum_f64(acc[z]);
+                    // every lane of the row holds the 36 sums; lane l retires entries l, l+16, l+32
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) {
+                        double mine = acc[16 * g];
+#pragma unroll
+                        for (int z = 1; z < 16; ++z) if (16 * g + z < 36) mine = (rl == z) ? acc[16 * g + z] : mine;
+                        const int z = 16 * g + rl;
+                        if (z < 36) {
+                            if (diag) spart[t * 42 + z] = mine;
+                            else {
+                                const int r = z / 6, cc = z % 6;
+                                S[(size_t)(6 * a + r) * ld + 6 * b2 + cc] -= mine;
+                                S[(size_t)(6 * b2 + cc) * ld + 6 * a + r] -= mine;
+                            }
                         }
                     }
+                    if (diag) {
+#pragma unroll
+                        for (int r = 0; r < 6; ++r) accb[r] = row_sum_f64(accb[r]);
+                        if (rl < 6) {
+                            double v = accb[0];
+#pragma unroll
+                            for (int r = 1; r < 6; ++r) v = (rl == r) ? accb[r] : v;
+                            spart[t * 42 + 36 + rl] = v;
+                        }
+                    }
+                }
+                __syncthreads();
+                for (int z = tid; z < na * 42; z += BA_THREADS) {
+                    const int a = z / 42, k = z - a * 42;
+                    double v = 0;
+#pragma unroll
+                    for (int q = 0; q < BA_DIAG_PARTS; ++q) v += spart[(a * BA_DIAG_PARTS + q) * 42 + k];
+                    if (k < 36) S[(size_t)(6 * a + k / 6) * ld + 6 * a + k % 6] -= v;
+                    else bs[6 * a + (k - 36)] = bp[6 * a + (k - 36)] - v;
                 }
             }
             __syncthreads();
@@ -904,6 +915,6 @@ static inline size_t ba_lds_bytes(int max_kf)
 {
     size_t np = 6 * (size_t)max_kf;
     return ((np + 1) * (np + 1) + 3 * np + 36 * (size_t)max_kf + BA_WAVES + BA_PT * (size_t)max_kf + 2 * BA_CT +
-            27 * BA_ROWS) * sizeof(double) + 64;
+            27 * BA_ROWS + 42 * BA_DIAG_PARTS * (size_t)max_kf) * sizeof(double) + 64;
 }
 #pragma clang fp contract(off)
