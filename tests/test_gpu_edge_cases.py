@@ -155,3 +155,35 @@ def test_contexts_sharing_one_stream_stay_independent(svs, monkeypatch):
     for t in th:
         t.join()
     assert out == {"t": True, "s": True}
+
+
+def test_resident_track_edge_cases(svs):
+    """empty resident list, a frame on which every point is lost, and the count check"""
+    import oracle_lib as orc
+    l0, _ = svs.synth_pair(12, 0)
+    l1, _ = svs.synth_pair(12, 1)
+    pts = orc.gftt(l0)[:40]
+    c = svs.Context(cm.W, cm.H, max_slots=4, max_jobs=2, max_kf=0, max_lm=0, max_obs=0, max_streams=3)
+    c.pyramid([0, 2], [l0, l0])
+    T = cm.EXT_L.copy()
+    # stream 0: nothing resident; stream 2: 40 features without map points
+    c.rtrack_upload([(2, pts, np.full(len(pts), -1, np.int32), np.zeros((len(pts), 3)))])
+    r0, r2 = c.rtrack([(0, 0, 1, l1, T, T, 0), (2, 2, 3, l1, T, T, len(pts))], cm.CAM)
+    assert r0["n_tracked"] == 0 and r0["n_edges"] == 0 and np.array_equal(r0["pose"], T)
+    q, st, _ = orc.lk(l0, l1, pts, pts)
+    inb = (q[:, 0] >= 0) & (q[:, 0] < cm.W) & (q[:, 1] >= 0) & (q[:, 1] < cm.H)
+    keep = (st > 0) & inb
+    assert r2["n_tracked"] == keep.sum() and r2["n_edges"] == 0
+    assert np.array_equal(r2["xy"].view(np.uint32), q[keep].view(np.uint32)) and (r2["mp"] == -1).all()
+    # next frame is blank: every point fails the min-eigenvalue test, the list becomes empty
+    blank = np.full_like(l0, 77)
+    c.pyramid([2], [blank])      # previous pyramid of stream 2 replaced by a textureless one
+    (r,) = c.rtrack([(2, 2, 3, blank, T, T, int(keep.sum()))], cm.CAM)
+    assert r["n_tracked"] == 0
+    (r,) = c.rtrack([(2, 3, 2, l1, T, T, 0)], cm.CAM)
+    assert r["n_tracked"] == 0
+    with pytest.raises(RuntimeError, match="holds 0"):
+        c.rtrack([(2, 2, 3, l1, T, T, 5)], cm.CAM)
+    with pytest.raises(RuntimeError, match="out of range"):
+        c.rtrack([(7, 2, 3, l1, T, T, 0)], cm.CAM)
+    c.close()
