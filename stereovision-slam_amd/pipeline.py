@@ -101,7 +101,7 @@ _product = None
 def product_lib():
     global _product
     if _product is None:
-        p = os.path.join(HERE, "lib", "libsvslam_pipeline.so")
+        p = os.environ.get("SVS_PIPELINE_LIB") or os.path.join(HERE, "lib", "libsvslam_pipeline.so")   # override: A/B experiments
         if not os.path.exists(p):
             raise RuntimeError("libsvslam_pipeline.so is missing: run stereovision-slam_amd/build.py")
         _product = _bind(C.CDLL(p))
