@@ -164,6 +164,105 @@ k_gftt_eig(const GfttJob *jobs, const uint8_t *pyr, PyrGeom g, GfttWork wk)
     }
 }
 
+// ---- min-eigenvalue map without LDS ------------------------------------------------------
+// One wave carries 64 image columns (60 outputs + 2 halo columns each side) and walks down
+// GE_ROWS + 4 rows.  Horizontal neighbours come from DPP wave shifts (gfx9 wave_shr / wave_shl),
+// vertical neighbours from a three-row register window, for the pixels and again for the
+// covariance products, so the 3x3 box sum reads registers where k_gftt_eig read 27 LDS words
+// per pixel (that kernel is LDS-read bound, ~5x off its VALU time).  Same arithmetic, same
+// order of operations, same REFLECT_101 treatment (the covariance of an out-of-image position
+// is evaluated at the reflected pixel: with the stored border that is the mirrored
+// neighbourhood, i.e. left/right or top/bottom swapped).
+#define GE_COLS 60
+#define GE_ROWS 32
+#define SVS_DPP_WAVE_SHR1 0x138
+#define SVS_DPP_WAVE_SHL1 0x130
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+struct GePix { float l, m, r; };
+struct GeCov { float xxl, xxm, xxr, xyl, xym, xyr, yyl, yym, yyr; };
+
+__global__ void __launch_bounds__(64)
+k_gftt_eig2(const GfttJob *jobs, const uint8_t *pyr, PyrGeom g, GfttWork wk)
+{
+    const int job = blockIdx.z;
+    const GfttJob jb = jobs[job];
+    const int w = g.w[0], h = g.h[0], pitch = g.pitch[0];
+    const uint8_t *img = lvl_origin(pyr + (size_t)jb.slot * g.slot_bytes, g, 0);
+    const size_t P = (size_t)w * h;
+    float *eig = wk.eig + (size_t)job * P;
+    const uint8_t *mask = wk.mask + (size_t)job * ((P + 3) & ~(size_t)3);
+    const int lane = threadIdx.x;
+    const int x0 = blockIdx.x * GE_COLS, y0 = blockIdx.y * GE_ROWS;
+    const int gx = x0 - 2 + lane;                               // column of this lane's pixel / covariance
+    const uint8_t *colp = img + min(gx, w + SVS_BORDER - 1);
+    const bool col_out = gx < 0 || gx >= w;
+    const bool col_zero = gx > w;                               // beyond the 1-px covariance halo
+    const bool store_lane = lane >= 2 && lane < 2 + GE_COLS && gx < w;
+    const float s1 = (float)(1.0 / 3060.0);
+    const float s2 = (float)(2.0 * (1.0 / 3060.0));
+    GePix Pw[3];
+    GeCov Cw[3];
+    unsigned int best = 0;
+
+    auto step = [&](int i, GePix &Pnew, const GePix &Ptop, const GePix &Pmid, GeCov &Cnew, const GeCov &Ctop, const GeCov &Cmid) {
+        // pixel row y0 - 2 + i
+        const int ry = min(y0 - 2 + i, h + SVS_BORDER - 1);
+        const float p = (float)colp[(ptrdiff_t)ry * pitch];
+        float l = dpp_f32<SVS_DPP_WAVE_SHR1>(p), r = dpp_f32<SVS_DPP_WAVE_SHL1>(p);
+        if (col_out) { const float t = l; l = r; r = t; }
+        Pnew.l = l; Pnew.m = p; Pnew.r = r;
+        if (i < 2) return;
+        // covariance row cy = y0 - 3 + i from pixel rows (Ptop, Pmid, Pnew)
+        const int cy = y0 - 3 + i;
+        const bool row_out = cy < 0 || cy >= h;
+        const GePix &T = row_out ? Pnew : Ptop, &B = row_out ? Ptop : Pnew;
+        const float d0 = T.r - T.l, d1 = Pmid.r - Pmid.l, d2 = B.r - B.l;
+        float dx = (d0 + d2) * s1 + d1 * s2;
+        const float c0 = (s1 * T.l + s2 * T.m) + s1 * T.r;
+        const float c2 = (s1 * B.l + s2 * B.m) + s1 * B.r;
+        float dy = c2 - c0;
+        if (col_zero || cy > h) { dx = 0.f; dy = 0.f; }
+        const float xx = dx * dx, xy = dx * dy, yy = dy * dy;
+        Cnew.xxm = xx; Cnew.xym = xy; Cnew.yym = yy;
+        Cnew.xxl = dpp_f32<SVS_DPP_WAVE_SHR1>(xx); Cnew.xxr = dpp_f32<SVS_DPP_WAVE_SHL1>(xx);
+        Cnew.xyl = dpp_f32<SVS_DPP_WAVE_SHR1>(xy); Cnew.xyr = dpp_f32<SVS_DPP_WAVE_SHL1>(xy);
+        Cnew.yyl = dpp_f32<SVS_DPP_WAVE_SHR1>(yy); Cnew.yyr = dpp_f32<SVS_DPP_WAVE_SHL1>(yy);
+        if (i < 4) return;
+        // output row oy = y0 - 4 + i from covariance rows (Ctop, Cmid, Cnew), row-major f64 sum from zero
+        const int oy = y0 - 4 + i;
+        double sxx = 0, sxy = 0, syy = 0;
+        sxx += (double)Ctop.xxl; sxy += (double)Ctop.xyl; syy += (double)Ctop.yyl;
+        sxx += (double)Ctop.xxm; sxy += (double)Ctop.xym; syy += (double)Ctop.yym;
+        sxx += (double)Ctop.xxr; sxy += (double)Ctop.xyr; syy += (double)Ctop.yyr;
+        sxx += (double)Cmid.xxl; sxy += (double)Cmid.xyl; syy += (double)Cmid.yyl;
+        sxx += (double)Cmid.xxm; sxy += (double)Cmid.xym; syy += (double)Cmid.yym;
+        sxx += (double)Cmid.xxr; sxy += (double)Cmid.xyr; syy += (double)Cmid.yyr;
+        sxx += (double)Cnew.xxl; sxy += (double)Cnew.xyl; syy += (double)Cnew.yyl;
+        sxx += (double)Cnew.xxm; sxy += (double)Cnew.xym; syy += (double)Cnew.yym;
+        sxx += (double)Cnew.xxr; sxy += (double)Cnew.xyr; syy += (double)Cnew.yyr;
+        const float a = (float)sxx * 0.5f, b = (float)sxy, cc = (float)syy * 0.5f;
+        const float t = a - cc;
+        const float e = (a + cc) - sqrtf(t * t + b * b);
+        if (store_lane && oy < h) {
+            const size_t pi = (size_t)oy * w + gx;
+            eig[pi] = e;
+            if (mask[pi]) best = max(best, f32_ordered(e));
+        }
+    };
+    for (int i0 = 0; i0 < GE_ROWS + 4; i0 += 3) {
+        // window slot of pixel row i: i % 3; covariance row (i - 2): (i - 2) % 3 = (i + 1) % 3
+        step(i0 + 0, Pw[0], Pw[1], Pw[2], Cw[1], Cw[2], Cw[0]);
+        step(i0 + 1, Pw[1], Pw[2], Pw[0], Cw[2], Cw[0], Cw[1]);
+        step(i0 + 2, Pw[2], Pw[0], Pw[1], Cw[0], Cw[1], Cw[2]);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) best = max(best, (unsigned int)__shfl_xor((int)best, o, 64));
+    if (lane == 0 && best) atomicMax(&wk.counters[job * GF_CNT_STRIDE + 0], best);
+}
+
 // thread = 4 consecutive pixels of one row; candidates are compacted with one LDS atomic per
 // thread and ONE global atomic per block (a per-candidate global atomic serialises ~3000
 // same-address operations per image).  The key order is irrelevant: k_gftt_select sorts.

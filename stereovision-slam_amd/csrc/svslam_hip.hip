@@ -575,8 +575,12 @@ static int launch_gftt(svslam_ctx *c, int njobs, const GfttJob *djobs, int max_n
     hipLaunchKernelGGL(k_gftt_init, dim3(32, njobs), dim3(256), 0, c->stream, c->gw, w, h, njobs);
     if (max_nrect > 0)
         hipLaunchKernelGGL(k_gftt_mask, dim3(max_nrect, njobs), dim3(256), 0, c->stream, djobs, c->gw, drects, w, h);
-    hipLaunchKernelGGL(k_gftt_eig, dim3(cdiv(w, GF_TW), cdiv(h, GF_TH), njobs), dim3(256), 0, c->stream, djobs,
-                       c->d_pyr, c->geom, c->gw);
+    if (std::getenv("SVSLAM_GFTT_EIG_LDS"))      // the LDS-tile version, kept for A/B measurements
+        hipLaunchKernelGGL(k_gftt_eig, dim3(cdiv(w, GF_TW), cdiv(h, GF_TH), njobs), dim3(256), 0, c->stream, djobs,
+                           c->d_pyr, c->geom, c->gw);
+    else
+        hipLaunchKernelGGL(k_gftt_eig2, dim3(cdiv(w, GE_COLS), cdiv(h, GE_ROWS), njobs), dim3(64), 0, c->stream, djobs,
+                           c->d_pyr, c->geom, c->gw);
     hipLaunchKernelGGL(k_gftt_cand, dim3(cdiv(w, 256), cdiv(h, 4), njobs), dim3(64, 4), 0, c->stream, c->gw, w, h,
                        quality);
     hipLaunchKernelGGL(k_gftt_select, dim3(njobs), dim3(GF_SEL_THREADS), GF_SEL_LDS_BYTES, c->stream, c->gw, w,
