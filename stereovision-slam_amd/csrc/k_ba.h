@@ -7,25 +7,25 @@
 // flow of oracle/orc_geom.c:orc_local_ba; Jacobians are analytic (the reference
 // lets g2o differentiate numerically; see DESIGN.md for the tolerance).
 //
-// Data flow per LM iteration (every sum has a fixed order -> deterministic):
-//   landmark pass  thread / landmark walks its edge records (sorted landmark-major by the
-//                  host): residual, rho', Jp(2x6), Jl(2x3) on the fly -> Hll_j, bl_j and
-//                  the 6x3 blocks W_kj = sum w Jp^T Jl.  Jacobians are never stored.
-//   pose pass      16-lane rows over the pose-major edge records recompute Jp ->
-//                  Hpp_k, bp_k (kept in LDS)
-//   per LM trial:
-//     Dinv_j, db_j                                                  thread / landmark
-//     S_ab = Hpp + lambda I - sum_j (W_aj Dinv_j) W_bj^T (S in LDS) 16-lane row / pose pair
-//       the block pairs of every pose pair are listed by the host once per call; Y = W Dinv
-//       is formed in registers, never stored
-//     Cholesky + triangular solves of the 6K x 6K system in LDS     one wave
-//     back-substitution, update, new errors (landmark-major records), rho test
+// Data flow (every sum has a fixed order -> deterministic).  Nothing but the edge records, the
+// poses and the landmark positions is read from global memory inside an LM iteration: the 6x3
+// blocks W, Hll, Hll^-1 and bl live in LDS one landmark tile at a time and are recomputed from
+// the records whenever they are needed (a Jacobian is ~70 FMA; a round trip of the 18 doubles
+// of a block costs 9 L1 transactions per lane, and the kernel is bound by those: PMC
+// TCP_TOTAL_CACHE_ACCESSES ~ 27 per VMEM instruction in the version that stored W).
+//   per LM iteration:
+//     pose pass      16-lane rows over the pose-major edge records -> Hpp_k, bp_k (LDS)
+//   per LM trial, for each tile of <= BA_TILE landmarks / blocks (landmarks are renumbered by
+//   descending block count, a tile is a run of them):
+//     tile pass      thread / landmark walks its edge records: residual, rho', Jp, Jl ->
+//                    Hll_j, bl_j, (Hll_j + lambda I)^-1 and the blocks W_kj -> LDS
+//     Schur pass     16-lane row / pose pair over the tile's block pairs (listed by the host,
+//                    tile-local indices): S_ab -= (W_aj Dinv_j) W_bj^T, bs_a -= W_aj Dinv_j bl_j
+//   then Cholesky + triangular solves of the 6K x 6K system in LDS (whole workgroup),
+//   back-substitution (thread / landmark, Jacobians recomputed:
+//   dl = -Dinv sum Jl^T w (r + Jp dp)), update, error pass, rho test.
 // Rotations / translations of the active poses and both cameras live in an LDS table that
 // is rebuilt whenever the state changes, so a projection costs no global gather.
-// Why this shape: the kernel is bound by L1/TA transactions (one per lane for every
-// 16-byte access to an array-of-blocks: PMC TCP_TOTAL_CACHE_ACCESSES ~ 37 per VMEM
-// instruction in the previous version, which stored Jp/Jl/Y), not by f64 arithmetic, so
-// recomputing a Jacobian (~70 FMA) is cheaper than one round trip of its 18 doubles.
 // The reduced camera system is 60x60 f64 at K=10: MFMA does not apply.
 #pragma once
 #include "dev_common.h"
@@ -45,7 +45,7 @@
 #define BA_WAVES (BA_THREADS / 64)
 #define BA_ROWS (BA_THREADS / 16)
 #define BA_MAX_NP 192
-#define BA_DIAG_PARTS 3
+#define BA_TILE 480             // landmarks and (pose, landmark) blocks per LDS tile of the Schur sweep
 
 struct BaJob { int kf_ofs, nkf, lm_ofs, nlm, obs_ofs, nobs, iters_done, reserved; };
 struct BaCams { double cam[2][4]; double ext[2][7]; };
@@ -58,6 +58,7 @@ struct BaDev {               // device-side job descriptor (built on the host)
     int kf_ofs, nkf, lm_ofs, nlm, obs_ofs, nobs;
     int nblk, na;            // unique (kf,lm) blocks, active poses
     int ncontrib;            // (Y,W) block pairs
+    int ntile;               // LDS tiles of the Schur sweep
     int aux_ofs;             // offset into the int aux buffer
     int iters_done;
     int rec_ofs;             // offset (records) of this job's 2*nobs records: landmark-major, then pose-major
@@ -66,10 +67,6 @@ struct BaDev {               // device-side job descriptor (built on the host)
 struct BaWork {              // per-job HBM scratch, strided by the context limits
     int max_kf = 0, max_lm = 0, max_obs = 0;
     double *err = nullptr;   // [2*max_obs]  residuals of the last evaluation, landmark-major edge order
-    double *W = nullptr;     // [18*max_obs]
-    double *Hll = nullptr;   // [9*max_lm]
-    double *Dinv = nullptr;  // [9*max_lm]
-    double *bl = nullptr;    // [3*max_lm]
     double *poses_b = nullptr; // [7*max_kf]
     double *pts_b = nullptr;   // [3*max_lm]
     double *pts_i = nullptr;   // [3*max_lm]  landmark positions in the internal numbering
@@ -81,17 +78,12 @@ static inline hipError_t ba_work_alloc(BaWork &w, int jobs, int max_kf, int max_
     w.max_kf = max_kf; w.max_lm = max_lm; w.max_obs = max_obs;
     if (max_kf <= 0 || max_lm <= 0 || max_obs <= 0) return hipSuccess;
     size_t J = jobs;
-    size_t nd = J * ((size_t)max_obs * (2 + 18) + (size_t)max_kf * 7 +
-                     (size_t)max_lm * (9 + 9 + 3 + 3 + 3));
+    size_t nd = J * ((size_t)max_obs * 2 + (size_t)max_kf * 7 + (size_t)max_lm * 6);
     hipError_t e = hipMalloc(&w.all, nd * sizeof(double));
     if (e != hipSuccess) return e;
     double *p = static_cast<double *>(w.all);
     w.err = p; p += J * 2 * max_obs;
-    w.W = p; p += J * 18 * max_obs;
     w.poses_b = p; p += J * 7 * max_kf;
-    w.Hll = p; p += J * 9 * max_lm;
-    w.Dinv = p; p += J * 9 * max_lm;
-    w.bl = p; p += J * 3 * max_lm;
     w.pts_b = p; p += J * 3 * max_lm;
     w.pts_i = p; p += J * 3 * max_lm;
     return hipSuccess;
@@ -102,12 +94,12 @@ static inline void ba_work_free(BaWork &w) { if (w.all) (void)hipFree(w.all); w.
 // aux layout per job (ints), offsets from ba_aux_layout():
 //   lm_estart[nlm+1] lm_edges[nobs] kf_estart[nkf+1] lm_orig[nlm]
 //   lm_bstart[nlm+1] blk_kf[nblk] blk_lm[nblk] kf_pidx[nkf] act_kf[nkf]
-//   pc_start[npairs+1] pc_y[ncontrib] pc_w[ncontrib] pc_lm[ncontrib]
+//   tile_lm[ntile+1]  pcs[ntile*npairs+1]  pitem[ncontrib] (y | w << 10 | landmark << 20, tile-local)
 struct BaAuxLayout {
     size_t lm_estart, lm_edges, kf_estart, lm_orig, lm_bstart, blk_kf, blk_lm, kf_pidx, act_kf;
-    size_t pc_start, pc_y, pc_w, pc_lm, total;
+    size_t tile_lm, pcs, pitem, total;
 };
-__host__ __device__ inline BaAuxLayout ba_aux_layout(int nkf, int nlm, int nobs, int nblk, int na, int ncontrib)
+__host__ __device__ inline BaAuxLayout ba_aux_layout(int nkf, int nlm, int nobs, int nblk, int na, int ncontrib, int ntile)
 {
     BaAuxLayout L;
     size_t o = 0;
@@ -120,10 +112,9 @@ __host__ __device__ inline BaAuxLayout ba_aux_layout(int nkf, int nlm, int nobs,
     L.blk_lm = o; o += nblk;
     L.kf_pidx = o; o += nkf;
     L.act_kf = o; o += nkf;
-    L.pc_start = o; o += (size_t)na * (na + 1) / 2 + 1;
-    L.pc_y = o; o += ncontrib;
-    L.pc_w = o; o += ncontrib;
-    L.pc_lm = o; o += ncontrib;
+    L.tile_lm = o; o += (size_t)ntile + 1;
+    L.pcs = o; o += (size_t)ntile * ((size_t)na * (na + 1) / 2) + 1;
+    L.pitem = o; o += ncontrib;
     L.total = o;
     return L;
 }
@@ -132,9 +123,9 @@ __host__ __device__ inline int ba_pair_index(int a, int b, int na) { return a * 
 
 struct BaHostStruct {        // scratch reused across jobs
     std::vector<int> lm_estart, lm_edges, kf_estart, lm_orig, lm_new, srt, ostart, lm_bstart, blk_kf, blk_lm, kf_pidx,
-        act_kf, pc_start, pc_y, pc_w, pc_lm, fill, bpa;
+        act_kf, tile_lm, pcs, pitem, fill, bpa;
     std::vector<BaRec> recs;     // [0,nobs) landmark-major (= lm_edges order), [nobs,2nobs) pose-major
-    int nblk = 0, na = 0, ncontrib = 0;
+    int nblk = 0, na = 0, ncontrib = 0, ntile = 0;
 
     // Returns false if an edge index is out of range.  Two passes over the edges when they
     // arrive landmark-major with keyframes ascending inside a landmark (the order the host
@@ -236,61 +227,73 @@ struct BaHostStruct {        // scratch reused across jobs
                 rp[fl[k]++] = r;
             }
         }
-        // (Y,W) block pairs per pose pair, counting sort by pair; landmark-ascending inside a pair
-        const int npairs = na * (na + 1) / 2;
-        pc_start.assign((size_t)npairs + 1, 0);
+        // LDS tiles: consecutive landmarks (internal order) with at most BA_TILE landmarks and
+        // BA_TILE blocks; inside a tile the (Y,W) block pairs are listed per pose pair, landmark
+        // ascending, as tile-local indices packed into one int
+        tile_lm.clear(); tile_lm.push_back(0);
         {
-            // active-pose index of every block, once
-            bpa.resize(nblk);
-            for (int b = 0; b < nblk; ++b) bpa[b] = kf_pidx[blk_kf[b]];
-            const int *__restrict lbs = lm_bstart.data(), *__restrict pa = bpa.data();
-            int *__restrict pcs = pc_start.data();
+            int nl_t = 0, nb_t = 0;
             for (int l = 0; l < nlm; ++l) {
-                const int b0 = lbs[l], b1 = lbs[l + 1];
-                for (int u = b0; u < b1; ++u) {
-                    const int pu = pa[u];
-                    const int base = pu * na - pu * (pu - 1) / 2 - pu;
-                    for (int v = u; v < b1; ++v) pcs[base + pa[v] + 1]++;
-                }
+                const int k = lm_bstart[l + 1] - lm_bstart[l];
+                if (nl_t + 1 > BA_TILE || nb_t + k > BA_TILE) { tile_lm.push_back(l); nl_t = 0; nb_t = 0; }
+                ++nl_t; nb_t += k;
             }
+            tile_lm.push_back(nlm);
         }
-        for (int p = 0; p < npairs; ++p) pc_start[p + 1] += pc_start[p];
-        ncontrib = pc_start[npairs];
-        pc_y.resize(ncontrib); pc_w.resize(ncontrib); pc_lm.resize(ncontrib);
-        fill.assign(pc_start.begin(), pc_start.begin() + npairs);
+        ntile = (int)tile_lm.size() - 1;
+        const int npairs = na * (na + 1) / 2;
+        bpa.resize(nblk);
+        for (int b = 0; b < nblk; ++b) bpa[b] = kf_pidx[blk_kf[b]];
+        pcs.assign((size_t)ntile * npairs + 1, 0);
         {
             const int *__restrict lbs = lm_bstart.data(), *__restrict pa = bpa.data();
-            int *__restrict f1 = fill.data();
-            int *__restrict py = pc_y.data(), *__restrict pw = pc_w.data(), *__restrict pl = pc_lm.data();
-            for (int l = 0; l < nlm; ++l) {
-                const int b0 = lbs[l], b1 = lbs[l + 1];
-                for (int u = b0; u < b1; ++u) {
-                    const int pu = pa[u];
-                    const int base = pu * na - pu * (pu - 1) / 2 - pu;
-                    for (int v = u; v < b1; ++v) {
-                        const int q = f1[base + pa[v]]++;
-                        py[q] = u; pw[q] = v; pl[q] = l;
+            int *__restrict pc = pcs.data();
+            for (int t = 0; t < ntile; ++t)
+                for (int l = tile_lm[t]; l < tile_lm[t + 1]; ++l) {
+                    const int b0 = lbs[l], b1 = lbs[l + 1];
+                    for (int u = b0; u < b1; ++u) {
+                        const int pu = pa[u];
+                        const int base = t * npairs + pu * na - pu * (pu - 1) / 2 - pu;
+                        for (int v = u; v < b1; ++v) pc[base + pa[v] + 1]++;
+                    }
+                }
+        }
+        for (size_t q = 0; q < (size_t)ntile * npairs; ++q) pcs[q + 1] += pcs[q];
+        ncontrib = pcs[(size_t)ntile * npairs];
+        pitem.resize(ncontrib);
+        fill.assign(pcs.begin(), pcs.begin() + (size_t)ntile * npairs);
+        {
+            const int *__restrict lbs = lm_bstart.data(), *__restrict pa = bpa.data();
+            int *__restrict f1 = fill.data(), *__restrict pi = pitem.data();
+            for (int t = 0; t < ntile; ++t) {
+                const int l0 = tile_lm[t], bt0 = lbs[l0];
+                for (int l = l0; l < tile_lm[t + 1]; ++l) {
+                    const int b0 = lbs[l], b1 = lbs[l + 1];
+                    for (int u = b0; u < b1; ++u) {
+                        const int pu = pa[u];
+                        const int base = t * npairs + pu * na - pu * (pu - 1) / 2 - pu;
+                        for (int v = u; v < b1; ++v) pi[f1[base + pa[v]]++] = (u - bt0) | ((v - bt0) << 10) | ((l - l0) << 20);
                     }
                 }
             }
         }
         return true;
     }
-    size_t aux_ints(const BaJob &j) const { return ba_aux_layout(j.nkf, j.nlm, j.nobs, nblk, na, ncontrib).total; }
+    size_t aux_ints(const BaJob &j) const { return ba_aux_layout(j.nkf, j.nlm, j.nobs, nblk, na, ncontrib, ntile).total; }
     void write(const BaJob &j, int *aux, BaRec *rec_out, BaDev &d) const
     {
         if (j.nobs) std::memcpy(rec_out, recs.data(), sizeof(BaRec) * 2 * (size_t)j.nobs);
-        BaAuxLayout L = ba_aux_layout(j.nkf, j.nlm, j.nobs, nblk, na, ncontrib);
+        BaAuxLayout L = ba_aux_layout(j.nkf, j.nlm, j.nobs, nblk, na, ncontrib, ntile);
         auto cp = [&](size_t off, const std::vector<int> &v, size_t n) { if (n) std::memcpy(aux + off, v.data(), n * sizeof(int)); };
         cp(L.lm_estart, lm_estart, (size_t)j.nlm + 1); cp(L.lm_edges, lm_edges, j.nobs);
         cp(L.kf_estart, kf_estart, (size_t)j.nkf + 1); cp(L.lm_orig, lm_orig, j.nlm);
         cp(L.lm_bstart, lm_bstart, (size_t)j.nlm + 1);
         cp(L.blk_kf, blk_kf, nblk); cp(L.blk_lm, blk_lm, nblk);
         cp(L.kf_pidx, kf_pidx, j.nkf); cp(L.act_kf, act_kf, j.nkf);
-        cp(L.pc_start, pc_start, (size_t)na * (na + 1) / 2 + 1); cp(L.pc_y, pc_y, ncontrib); cp(L.pc_w, pc_w, ncontrib);
-        cp(L.pc_lm, pc_lm, ncontrib);
+        cp(L.tile_lm, tile_lm, (size_t)ntile + 1);
+        cp(L.pcs, pcs, (size_t)ntile * ((size_t)na * (na + 1) / 2) + 1); cp(L.pitem, pitem, ncontrib);
         d.kf_ofs = j.kf_ofs; d.nkf = j.nkf; d.lm_ofs = j.lm_ofs; d.nlm = j.nlm; d.obs_ofs = j.obs_ofs; d.nobs = j.nobs;
-        d.nblk = nblk; d.na = na; d.ncontrib = ncontrib; d.iters_done = 0; d.rec_ofs = 0;
+        d.nblk = nblk; d.na = na; d.ncontrib = ncontrib; d.ntile = ntile; d.iters_done = 0; d.rec_ofs = 0;
     }
 };
 
@@ -385,6 +388,24 @@ __device__ __forceinline__ void ba_jac_pose(const double *CT, const BaProj &o, d
     }
 }
 
+// one edge linearised: residual, robust weight, Jp (2x6), Jl = M R (2x3)
+struct BaLin { double ex, ey, w, rho, jp[12], jl[6]; };
+__device__ __forceinline__ void ba_linearize(const double *PT, const double *CT, const double *X, float u, float v,
+                                             double delta, BaLin &L)
+{
+    BaProj o;
+    ba_project(PT, CT, X, u, v, o);
+    L.ex = o.ex; L.ey = o.ey;
+    d_huber(o.ex * o.ex + o.ey * o.ey, delta, L.rho, L.w);
+    double M[6];
+    ba_jac_pose(CT, o, M, L.jp);
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            L.jl[3 * r + c] = M[3 * r] * PT[c] + M[3 * r + 1] * PT[3 + c] + M[3 * r + 2] * PT[6 + c];
+}
+
 __global__ void __launch_bounds__(BA_THREADS, BA_MIN_WAVES_PER_SIMD)
 k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all, const BaRec *recs_all,
            const int *aux_all, BaWork wk, double delta, int iters, double *edge_chi2_all, long long *prof_all)
@@ -408,8 +429,10 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
     double *PTab = red + BA_WAVES;
     double *CTab = PTab + BA_PT * na;
     double *part = CTab + 2 * BA_CT;               // [BA_ROWS][27] pose-pass partial sums
-    double *spart = part + 27 * BA_ROWS;           // [na * BA_DIAG_PARTS][42] Schur partial sums of the diagonal pairs
-    int *iflag = reinterpret_cast<int *>(spart + 42 * BA_DIAG_PARTS * na);
+    double *Wt = part + 27 * BA_ROWS;              // [BA_TILE][18] blocks of the current tile
+    double *Dl = Wt + 18 * BA_TILE;                // [BA_TILE][6]  (Hll + lambda I)^-1, symmetric
+    double *Bl = Dl + 6 * BA_TILE;                 // [BA_TILE][3]  bl
+    int *iflag = reinterpret_cast<int *>(Bl + 3 * BA_TILE);
 
     const BaCams &cams = *camsp;
     double *poses = poses_all + (size_t)jd.kf_ofs * 7;
@@ -418,20 +441,17 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
     const BaRec *recL = recs_all + jd.rec_ofs;       // landmark-major
     const BaRec *recP = recL + nobs;                   // pose-major
     const int *aux = aux_all + jd.aux_ofs;
-    const BaAuxLayout AL = ba_aux_layout(nkf, nlm, nobs, nblk, na, jd.ncontrib);
+    const int ntile = jd.ntile;
+    const BaAuxLayout AL = ba_aux_layout(nkf, nlm, nobs, nblk, na, jd.ncontrib, ntile);
     const int *lm_estart = aux + AL.lm_estart, *lm_edges = aux + AL.lm_edges;
     const int *kf_estart = aux + AL.kf_estart;
     const int *lm_bstart = aux + AL.lm_bstart;
     const int *blk_kf = aux + AL.blk_kf, *blk_lm = aux + AL.blk_lm;
     const int *kf_pidx = aux + AL.kf_pidx, *act_kf = aux + AL.act_kf;
-    const int *pc_start = aux + AL.pc_start, *pc_y = aux + AL.pc_y, *pc_w = aux + AL.pc_w, *pc_lm = aux + AL.pc_lm;
+    const int *tile_lm = aux + AL.tile_lm, *pcs = aux + AL.pcs, *pitem = aux + AL.pitem;
 
     const size_t J = job;
     double *err = wk.err + J * 2 * wk.max_obs;
-    double *W = wk.W + J * 18 * wk.max_obs;
-    double *Hll = wk.Hll + J * 9 * wk.max_lm;
-    double *Dinv = wk.Dinv + J * 9 * wk.max_lm;
-    double *bl = wk.bl + J * 3 * wk.max_lm;
     double *poses_b = wk.poses_b + J * 7 * wk.max_kf;
     double *pts_b = wk.pts_b + J * 3 * wk.max_lm;
     double *pts = wk.pts_i + J * 3 * wk.max_lm;            // internal numbering (see BaHostStruct::build)
@@ -481,63 +501,10 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
 
     double lambda = 0, ni = 2;
     int it_done = 0;
+    const int npairs = na * (na + 1) / 2;
+    double currentChi = 0;
     for (int it = 0; it < iters; ++it) {
         pose_table();
-        // ---- landmark pass: errors, Jacobians on the fly, Hll, bl, W blocks
-        double chi_part = 0;
-        for (int j = tid; j < nlm; j += BA_THREADS) {
-            double h[6] = { 0, 0, 0, 0, 0, 0 }, b3[3] = { 0, 0, 0 };
-            const double X[3] = { pts[3 * (size_t)j], pts[3 * (size_t)j + 1], pts[3 * (size_t)j + 2] };
-            const int eend = lm_estart[j + 1];
-            int i = lm_estart[j];
-            while (i < eend) {
-                BaRec rc = recL[i];
-                const int blk = rc.blk;
-                double wacc[18];
-#pragma unroll
-                for (int t = 0; t < 18; ++t) wacc[t] = 0;
-                for (;;) {
-                    const int kc = (unsigned)rc.lmkc >> 24;
-                    const double *PT = PTab + BA_PT * (kc >> 1), *CT = CTab + BA_CT * (kc & 1);
-                    BaProj o;
-                    ba_project(PT, CT, X, rc.u, rc.v, o);
-                    err[2 * i] = o.ex; err[2 * i + 1] = o.ey;
-                    double r0, w;
-                    d_huber(o.ex * o.ex + o.ey * o.ey, delta, r0, w);
-                    chi_part += r0;
-                    double M[6], jp[12];
-                    ba_jac_pose(CT, o, M, jp);
-                    // Jl = M R
-                    double jl[6];
-#pragma unroll
-                    for (int r = 0; r < 2; ++r)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c)
-                            jl[3 * r + c] = M[3 * r] * PT[c] + M[3 * r + 1] * PT[3 + c] + M[3 * r + 2] * PT[6 + c];
-                    const double wl0 = w * jl[0], wl1 = w * jl[1], wl2 = w * jl[2], wl3 = w * jl[3], wl4 = w * jl[4], wl5 = w * jl[5];
-#pragma unroll
-                    for (int a = 0; a < 6; ++a) {
-                        const double p0 = jp[a], p1 = jp[6 + a];
-                        wacc[a * 3 + 0] += p0 * wl0 + p1 * wl3;
-                        wacc[a * 3 + 1] += p0 * wl1 + p1 * wl4;
-                        wacc[a * 3 + 2] += p0 * wl2 + p1 * wl5;
-                    }
-                    b3[0] -= wl0 * o.ex + wl3 * o.ey; b3[1] -= wl1 * o.ex + wl4 * o.ey; b3[2] -= wl2 * o.ex + wl5 * o.ey;
-                    h[0] += wl0 * jl[0] + wl3 * jl[3]; h[1] += wl0 * jl[1] + wl3 * jl[4]; h[2] += wl0 * jl[2] + wl3 * jl[5];
-                    h[3] += wl1 * jl[1] + wl4 * jl[4]; h[4] += wl1 * jl[2] + wl4 * jl[5]; h[5] += wl2 * jl[2] + wl5 * jl[5];
-                    ++i;
-                    if (i >= eend) break;
-                    rc = recL[i];
-                    if (rc.blk != blk) break;
-                }
-                st_block18(W + 18 * (size_t)blk, wacc);
-            }
-            double *hj = Hll + 9 * (size_t)j;
-            hj[0] = h[0]; hj[1] = h[1]; hj[2] = h[2]; hj[3] = h[1]; hj[4] = h[3]; hj[5] = h[4];
-            hj[6] = h[2]; hj[7] = h[4]; hj[8] = h[5];
-            bl[3 * j] = b3[0]; bl[3 * j + 1] = b3[1]; bl[3 * j + 2] = b3[2];
-        }
-        BA_PROF(0);
         // ---- pose pass: Hpp (block diagonal), bp -> LDS.  16-lane rows; pose a is shared by
         // the rows a, a + na, a + 2 na ... (< BA_ROWS), partial sums combined in row order
         {
@@ -590,34 +557,36 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
                 } else bp[6 * a2 + (t - 21)] = v;
             }
         }
-        double currentChi = block_sum(chi_part, red, tid);
-        double tempChi = currentChi;
         __syncthreads();
         BA_PROF(1);
         if (it == 0) {
+            // lambda_0 = 1e-5 * max diagonal of the Hessian: the landmark diagonals need one cheap sweep
             double md = 0;
             for (int i = tid; i < np; i += BA_THREADS) md = fmax(md, fabs(Hpp[36 * (i / 6) + (i % 6) * 7]));
-            for (int i = tid; i < 3 * nlm; i += BA_THREADS)
-                if (lm_estart[i / 3 + 1] > lm_estart[i / 3]) md = fmax(md, fabs(Hll[9 * (size_t)(i / 3) + (i % 3) * 4]));
+            for (int j = tid; j < nlm; j += BA_THREADS) {
+                const double X[3] = { pts[3 * (size_t)j], pts[3 * (size_t)j + 1], pts[3 * (size_t)j + 2] };
+                double h0 = 0, h3 = 0, h5 = 0;
+                for (int i = lm_estart[j]; i < lm_estart[j + 1]; ++i) {
+                    const BaRec rc = recL[i];
+                    const int kc = (unsigned)rc.lmkc >> 24;
+                    BaLin L;
+                    ba_linearize(PTab + BA_PT * (kc >> 1), CTab + BA_CT * (kc & 1), X, rc.u, rc.v, delta, L);
+                    h0 += L.w * (L.jl[0] * L.jl[0] + L.jl[3] * L.jl[3]);
+                    h3 += L.w * (L.jl[1] * L.jl[1] + L.jl[4] * L.jl[4]);
+                    h5 += L.w * (L.jl[2] * L.jl[2] + L.jl[5] * L.jl[5]);
+                }
+                if (lm_estart[j + 1] > lm_estart[j]) md = fmax(md, fmax(fabs(h0), fmax(fabs(h3), fabs(h5))));
+            }
             md = block_max(md, red, tid);
             lambda = 1e-5 * md; ni = 2;
         }
+        double tempChi = 0;
+        bool have_chi = it > 0;       // after the first iteration currentChi carries over from the accepted trial
         double rho = 0; int qmax = 0;
         do {
-            // backup, Dinv, S = blockdiag(Hpp) + lambda I
+            // backup, S = blockdiag(Hpp) + lambda I, bs = bp
             for (int i = tid; i < 7 * nkf; i += BA_THREADS) poses_b[i] = poses[i];
             for (int i = tid; i < 3 * nlm; i += BA_THREADS) pts_b[i] = pts[i];
-            for (int j = tid; j < nlm; j += BA_THREADS) {
-                double D[9], Di[9];
-                const double *hj = Hll + 9 * (size_t)j;
-#pragma unroll
-                for (int t = 0; t < 9; ++t) D[t] = hj[t];
-                D[0] += lambda; D[4] += lambda; D[8] += lambda;
-                d_inv3(D, Di);
-                double *dj = Dinv + 9 * (size_t)j;
-#pragma unroll
-                for (int t = 0; t < 9; ++t) dj[t] = Di[t];
-            }
             for (int i = tid; i < np * np; i += BA_THREADS) {
                 int r = i / np, c = i - r * np;
                 double v = 0;
@@ -625,106 +594,137 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
                 if (r == c) v += lambda;
                 S[(size_t)r * ld + c] = v;
             }
+            for (int i = tid; i < np; i += BA_THREADS) bs[i] = bp[i];
             __syncthreads();
             BA_PROF(2);
-            // ---- Schur assembly on 16-lane rows.  A diagonal pose pair (a,a) lists every block of
-            // pose a (the heavy tasks: most landmarks are seen from one keyframe), an off-diagonal
-            // pair only the landmarks two poses share; the diagonal pairs are therefore cut into
-            // BA_DIAG_PARTS row tasks whose partial sums are combined in a fixed order afterwards,
-            // and they also produce the reduced right-hand side bs = bp - sum Y bl on the way.
-            {
-                const int npairs = na * (na + 1) / 2;
-                const int row = tid >> 4, rl = tid & 15;
-                const int ntask = na * BA_DIAG_PARTS + npairs;
-                for (int t = row; t < ntask; t += BA_ROWS) {
-                    int a, b2, c0, c1;
-                    const bool diag = t < na * BA_DIAG_PARTS;
-                    if (diag) {
-                        a = b2 = t / BA_DIAG_PARTS;
-                        const int pr = ba_pair_index(a, a, na), s0 = pc_start[pr], e0 = pc_start[pr + 1];
-                        const int L = (e0 - s0 + BA_DIAG_PARTS - 1) / BA_DIAG_PARTS;
-                        c0 = s0 + (t % BA_DIAG_PARTS) * L; c1 = min(e0, c0 + L);
-                    } else {
-                        const int pr = t - na * BA_DIAG_PARTS;
-                        int rem = pr; a = 0;
-                        while (rem >= na - a) { rem -= na - a; ++a; }
-                        b2 = a + rem;
-                        if (a == b2) continue;
-                        c0 = pc_start[pr]; c1 = pc_start[pr + 1];
+            // ---- tile sweep: linearise the tile's landmarks into LDS, then fold the tile into S / bs
+            double chi_part = 0;
+            for (int tl = 0; tl < ntile; ++tl) {
+                const int l0 = tile_lm[tl], l1 = tile_lm[tl + 1], bt0 = lm_bstart[l0];
+                for (int lj = tid; lj < l1 - l0; lj += BA_THREADS) {
+                    const int j = l0 + lj;
+                    double h[6] = { 0, 0, 0, 0, 0, 0 }, b3[3] = { 0, 0, 0 };
+                    const double X[3] = { pts[3 * (size_t)j], pts[3 * (size_t)j + 1], pts[3 * (size_t)j + 2] };
+                    const int eend = lm_estart[j + 1];
+                    int i = lm_estart[j];
+                    while (i < eend) {
+                        BaRec rc = recL[i];
+                        const int blk = rc.blk;
+                        double wacc[18];
+#pragma unroll
+                        for (int t = 0; t < 18; ++t) wacc[t] = 0;
+                        for (;;) {
+                            const int kc = (unsigned)rc.lmkc >> 24;
+                            BaLin L;
+                            ba_linearize(PTab + BA_PT * (kc >> 1), CTab + BA_CT * (kc & 1), X, rc.u, rc.v, delta, L);
+                            if (!have_chi) { err[2 * i] = L.ex; err[2 * i + 1] = L.ey; chi_part += L.rho; }
+                            const double wl0 = L.w * L.jl[0], wl1 = L.w * L.jl[1], wl2 = L.w * L.jl[2],
+                                         wl3 = L.w * L.jl[3], wl4 = L.w * L.jl[4], wl5 = L.w * L.jl[5];
+#pragma unroll
+                            for (int a = 0; a < 6; ++a) {
+                                const double p0 = L.jp[a], p1 = L.jp[6 + a];
+                                wacc[a * 3 + 0] += p0 * wl0 + p1 * wl3;
+                                wacc[a * 3 + 1] += p0 * wl1 + p1 * wl4;
+                                wacc[a * 3 + 2] += p0 * wl2 + p1 * wl5;
+                            }
+                            b3[0] -= wl0 * L.ex + wl3 * L.ey; b3[1] -= wl1 * L.ex + wl4 * L.ey; b3[2] -= wl2 * L.ex + wl5 * L.ey;
+                            h[0] += wl0 * L.jl[0] + wl3 * L.jl[3]; h[1] += wl0 * L.jl[1] + wl3 * L.jl[4]; h[2] += wl0 * L.jl[2] + wl3 * L.jl[5];
+                            h[3] += wl1 * L.jl[1] + wl4 * L.jl[4]; h[4] += wl1 * L.jl[2] + wl4 * L.jl[5]; h[5] += wl2 * L.jl[2] + wl5 * L.jl[5];
+                            ++i;
+                            if (i >= eend) break;
+                            rc = recL[i];
+                            if (rc.blk != blk) break;
+                        }
+                        double *wd = Wt + 18 * (blk - bt0);
+#pragma unroll
+                        for (int t = 0; t < 18; ++t) wd[t] = wacc[t];
                     }
-                    double acc[36], accb[6];
+                    double D[9] = { h[0] + lambda, h[1], h[2], h[1], h[3] + lambda, h[4], h[2], h[4], h[5] + lambda }, Di[9];
+                    d_inv3(D, Di);
+                    double *dd = Dl + 6 * lj;
+                    dd[0] = Di[0]; dd[1] = Di[1]; dd[2] = Di[2]; dd[3] = Di[4]; dd[4] = Di[5]; dd[5] = Di[8];
+                    Bl[3 * lj] = b3[0]; Bl[3 * lj + 1] = b3[1]; Bl[3 * lj + 2] = b3[2];
+                }
+                __syncthreads();
+                {
+                    const int row = tid >> 4, rl = tid & 15;
+                    for (int pr = row; pr < npairs; pr += BA_ROWS) {
+                        const int c0 = pcs[tl * npairs + pr], c1 = pcs[tl * npairs + pr + 1];
+                        if (c0 == c1) continue;
+                        int a = 0, rem = pr;
+                        while (rem >= na - a) { rem -= na - a; ++a; }
+                        const int b2 = a + rem;
+                        const bool diag = a == b2;
+                        double acc[36], accb[6];
 #pragma unroll
-                    for (int z = 0; z < 36; ++z) acc[z] = 0;
+                        for (int z = 0; z < 36; ++z) acc[z] = 0;
 #pragma unroll
-                    for (int z = 0; z < 6; ++z) accb[z] = 0;
-                    for (int c = c0 + rl; c < c1; c += 16) {
-                        double yy[18], ww[18];
-                        const int by = pc_y[c], bw = pc_w[c], lmj = pc_lm[c];
-                        ld_block18(W + 18 * (size_t)by, ww);
-                        {
-                            const double *Di = Dinv + 9 * (size_t)lmj;      // symmetric
-                            const double d00 = Di[0], d01 = Di[1], d02 = Di[2], d11 = Di[4], d12 = Di[5], d22 = Di[8];
+                        for (int z = 0; z < 6; ++z) accb[z] = 0;
+                        for (int c = c0 + rl; c < c1; c += 16) {
+                            const int it3 = pitem[c];
+                            const int by = it3 & 1023, bw = (it3 >> 10) & 1023, lq = it3 >> 20;
+                            double yy[18], ww[18];
+                            const double *wy = Wt + 18 * by;
 #pragma unroll
-                            for (int r = 0; r < 6; ++r) {
-                                const double x0 = ww[r * 3], x1 = ww[r * 3 + 1], x2 = ww[r * 3 + 2];
-                                yy[r * 3 + 0] = x0 * d00 + x1 * d01 + x2 * d02;
-                                yy[r * 3 + 1] = x0 * d01 + x1 * d11 + x2 * d12;
-                                yy[r * 3 + 2] = x0 * d02 + x1 * d12 + x2 * d22;
+                            for (int z = 0; z < 18; ++z) ww[z] = wy[z];
+                            {
+                                const double *Di = Dl + 6 * lq;
+                                const double d00 = Di[0], d01 = Di[1], d02 = Di[2], d11 = Di[3], d12 = Di[4], d22 = Di[5];
+#pragma unroll
+                                for (int r = 0; r < 6; ++r) {
+                                    const double x0 = ww[r * 3], x1 = ww[r * 3 + 1], x2 = ww[r * 3 + 2];
+                                    yy[r * 3 + 0] = x0 * d00 + x1 * d01 + x2 * d02;
+                                    yy[r * 3 + 1] = x0 * d01 + x1 * d11 + x2 * d12;
+                                    yy[r * 3 + 2] = x0 * d02 + x1 * d12 + x2 * d22;
+                                }
+                            }
+                            if (diag) {
+                                const double g0 = Bl[3 * lq], g1 = Bl[3 * lq + 1], g2 = Bl[3 * lq + 2];
+#pragma unroll
+                                for (int r = 0; r < 6; ++r) accb[r] += yy[r * 3] * g0 + yy[r * 3 + 1] * g1 + yy[r * 3 + 2] * g2;
+                            }
+                            if (bw != by) {
+                                const double *w2 = Wt + 18 * bw;
+#pragma unroll
+                                for (int z = 0; z < 18; ++z) ww[z] = w2[z];
+                            }
+#pragma unroll
+                            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                                for (int cc = 0; cc < 6; ++cc)
+                                    acc[r * 6 + cc] += yy[r * 3] * ww[cc * 3] + yy[r * 3 + 1] * ww[cc * 3 + 1] + yy[r * 3 + 2] * ww[cc * 3 + 2];
+                        }
+#pragma unroll
+                        for (int z = 0; z < 36; ++z) acc[z] = row_sum_f64(acc[z]);
+                        // every lane of the row holds the 36 sums; lane l retires entries l, l+16, l+32
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) {
+                            double mine = acc[16 * g];
+#pragma unroll
+                            for (int z = 1; z < 16; ++z) if (16 * g + z < 36) mine = (rl == z) ? acc[16 * g + z] : mine;
+                            const int z = 16 * g + rl;
+                            if (z < 36) {
+                                const int r = z / 6, cc = z % 6;
+                                S[(size_t)(6 * a + r) * ld + 6 * b2 + cc] -= mine;
+                                if (!diag) S[(size_t)(6 * b2 + cc) * ld + 6 * a + r] -= mine;
                             }
                         }
                         if (diag) {
-                            const double *b3 = bl + 3 * (size_t)lmj;
-                            const double g0 = b3[0], g1 = b3[1], g2 = b3[2];
 #pragma unroll
-                            for (int r = 0; r < 6; ++r) accb[r] += yy[r * 3] * g0 + yy[r * 3 + 1] * g1 + yy[r * 3 + 2] * g2;
-                        }
-                        if (bw != by) ld_block18(W + 18 * (size_t)bw, ww);
+                            for (int r = 0; r < 6; ++r) accb[r] = row_sum_f64(accb[r]);
+                            if (rl < 6) {
+                                double v = accb[0];
 #pragma unroll
-                        for (int r = 0; r < 6; ++r)
-#pragma unroll
-                            for (int cc = 0; cc < 6; ++cc)
-                                acc[r * 6 + cc] += yy[r * 3] * ww[cc * 3] + yy[r * 3 + 1] * ww[cc * 3 + 1] + yy[r * 3 + 2] * ww[cc * 3 + 2];
-                    }
-#pragma unroll
-                    for (int z = 0; z < 36; ++z) acc[z] = row_sum_f64(acc[z]);
-                    // every lane of the row holds the 36 sums; lane l retires entries l, l+16, l+32
-#pragma unroll
-                    for (int g = 0; g < 3; ++g) {
-                        double mine = acc[16 * g];
-#pragma unroll
-                        for (int z = 1; z < 16; ++z) if (16 * g + z < 36) mine = (rl == z) ? acc[16 * g + z] : mine;
-                        const int z = 16 * g + rl;
-                        if (z < 36) {
-                            if (diag) spart[t * 42 + z] = mine;
-                            else {
-                                const int r = z / 6, cc = z % 6;
-                                S[(size_t)(6 * a + r) * ld + 6 * b2 + cc] -= mine;
-                                S[(size_t)(6 * b2 + cc) * ld + 6 * a + r] -= mine;
+                                for (int r = 1; r < 6; ++r) v = (rl == r) ? accb[r] : v;
+                                bs[6 * a + rl] -= v;
                             }
-                        }
-                    }
-                    if (diag) {
-#pragma unroll
-                        for (int r = 0; r < 6; ++r) accb[r] = row_sum_f64(accb[r]);
-                        if (rl < 6) {
-                            double v = accb[0];
-#pragma unroll
-                            for (int r = 1; r < 6; ++r) v = (rl == r) ? accb[r] : v;
-                            spart[t * 42 + 36 + rl] = v;
                         }
                     }
                 }
                 __syncthreads();
-                for (int z = tid; z < na * 42; z += BA_THREADS) {
-                    const int a = z / 42, k = z - a * 42;
-                    double v = 0;
-#pragma unroll
-                    for (int q = 0; q < BA_DIAG_PARTS; ++q) v += spart[(a * BA_DIAG_PARTS + q) * 42 + k];
-                    if (k < 36) S[(size_t)(6 * a + k / 6) * ld + 6 * a + k % 6] -= v;
-                    else bs[6 * a + (k - 36)] = bp[6 * a + (k - 36)] - v;
-                }
             }
-            __syncthreads();
+            if (!have_chi) { currentChi = block_sum(chi_part, red, tid); have_chi = true; }
+            tempChi = currentChi;
             BA_PROF(3);
             // ---- blocked (6x6 = one pose) right-looking Cholesky S = L L^T in LDS on the whole
             // workgroup; the right-hand side rides along as row np, so L y = bs comes out of the
@@ -843,26 +843,39 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
             const int ok2 = iflag[0];
             double scale_part = 0;
             if (ok2) {
+                // back-substitution with the Jacobians recomputed (the pose table still holds the
+                // linearisation point): dl = Dinv (bl - sum W^T dp) = -Dinv sum Jl^T w (r + Jp dp)
                 for (int j = tid; j < nlm; j += BA_THREADS) {
                     if (lm_estart[j + 1] == lm_estart[j]) continue;
-                    double c0 = bl[3 * j], c1 = bl[3 * j + 1], c2 = bl[3 * j + 2];
-                    for (int b = lm_bstart[j]; b < lm_bstart[j + 1]; ++b) {
-                        const double *w1 = W + 18 * (size_t)b;
-                        const double *x6 = xp + 6 * kf_pidx[blk_kf[b]];
+                    const double X[3] = { pts[3 * (size_t)j], pts[3 * (size_t)j + 1], pts[3 * (size_t)j + 2] };
+                    double h[6] = { 0, 0, 0, 0, 0, 0 }, g3[3] = { 0, 0, 0 }, b3[3] = { 0, 0, 0 };
+                    for (int i = lm_estart[j]; i < lm_estart[j + 1]; ++i) {
+                        const BaRec rc = recL[i];
+                        const int kc = (unsigned)rc.lmkc >> 24;
+                        BaLin L;
+                        ba_linearize(PTab + BA_PT * (kc >> 1), CTab + BA_CT * (kc & 1), X, rc.u, rc.v, delta, L);
+                        const double *x6 = xp + 6 * (kc >> 1);
+                        double t0 = 0, t1 = 0;
 #pragma unroll
-                        for (int a = 0; a < 6; ++a) {
-                            const double xa = x6[a];
-                            c0 -= w1[a * 3] * xa; c1 -= w1[a * 3 + 1] * xa; c2 -= w1[a * 3 + 2] * xa;
-                        }
+                        for (int a = 0; a < 6; ++a) { t0 += L.jp[a] * x6[a]; t1 += L.jp[6 + a] * x6[a]; }
+                        const double wl0 = L.w * L.jl[0], wl1 = L.w * L.jl[1], wl2 = L.w * L.jl[2],
+                                     wl3 = L.w * L.jl[3], wl4 = L.w * L.jl[4], wl5 = L.w * L.jl[5];
+                        b3[0] -= wl0 * L.ex + wl3 * L.ey; b3[1] -= wl1 * L.ex + wl4 * L.ey; b3[2] -= wl2 * L.ex + wl5 * L.ey;
+                        g3[0] += wl0 * t0 + wl3 * t1; g3[1] += wl1 * t0 + wl4 * t1; g3[2] += wl2 * t0 + wl5 * t1;
+                        h[0] += wl0 * L.jl[0] + wl3 * L.jl[3]; h[1] += wl0 * L.jl[1] + wl3 * L.jl[4]; h[2] += wl0 * L.jl[2] + wl3 * L.jl[5];
+                        h[3] += wl1 * L.jl[1] + wl4 * L.jl[4]; h[4] += wl1 * L.jl[2] + wl4 * L.jl[5]; h[5] += wl2 * L.jl[2] + wl5 * L.jl[5];
                     }
-                    const double *Di = Dinv + 9 * (size_t)j;
+                    double D[9] = { h[0] + lambda, h[1], h[2], h[1], h[3] + lambda, h[4], h[2], h[4], h[5] + lambda }, Di[9];
+                    d_inv3(D, Di);
+                    const double c0 = b3[0] - g3[0], c1 = b3[1] - g3[1], c2 = b3[2] - g3[2];
 #pragma unroll
                     for (int a = 0; a < 3; ++a) {
                         const double x = Di[a * 3] * c0 + Di[a * 3 + 1] * c1 + Di[a * 3 + 2] * c2;
                         pts[3 * j + a] += x;
-                        scale_part += x * (lambda * x + bl[3 * j + a]);
+                        scale_part += x * (lambda * x + b3[a]);
                     }
                 }
+                __syncthreads();     // every landmark used the old poses / table before they move
                 for (int a = tid; a < na; a += BA_THREADS) {
                     const int k = act_kf[a];
                     double dT[7], Tn[7], x6[6];
@@ -915,6 +928,6 @@ static inline size_t ba_lds_bytes(int max_kf)
 {
     size_t np = 6 * (size_t)max_kf;
     return ((np + 1) * (np + 1) + 3 * np + 36 * (size_t)max_kf + BA_WAVES + BA_PT * (size_t)max_kf + 2 * BA_CT +
-            27 * BA_ROWS + 42 * BA_DIAG_PARTS * (size_t)max_kf) * sizeof(double) + 64;
+            27 * BA_ROWS + 27 * (size_t)BA_TILE) * sizeof(double) + 64;
 }
 #pragma clang fp contract(off)
