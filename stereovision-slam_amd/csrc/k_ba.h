@@ -45,7 +45,8 @@
 #define BA_WAVES (BA_THREADS / 64)
 #define BA_ROWS (BA_THREADS / 16)
 #define BA_MAX_NP 192
-#define BA_TILE 480             // landmarks and (pose, landmark) blocks per LDS tile of the Schur sweep
+#define BA_PIT_CAP 2048          // block-pair items of a tile staged in LDS (more are read from global)
+#define BA_TILE_MAX 480             // landmarks and (pose, landmark) blocks per LDS tile of the Schur sweep
 
 struct BaJob { int kf_ofs, nkf, lm_ofs, nlm, obs_ofs, nobs, iters_done, reserved; };
 struct BaCams { double cam[2][4]; double ext[2][7]; };
@@ -130,7 +131,8 @@ struct BaHostStruct {        // scratch reused across jobs
     // Returns false if an edge index is out of range.  Two passes over the edges when they
     // arrive landmark-major with keyframes ascending inside a landmark (the order the host
     // pipeline gathers them in, src/backend.cpp:83-160); otherwise they are sorted first.
-    bool build(const BaJob &j, const int *obs_kf, const int *obs_lm, const uint8_t *obs_right, const float *obs_uv)
+    bool build(const BaJob &j, const int *obs_kf, const int *obs_lm, const uint8_t *obs_right, const float *obs_uv,
+               int tile_cap)
     {
         const int nkf = j.nkf, nlm = j.nlm, nobs = j.nobs;
         const int *okf = obs_kf + j.obs_ofs, *olm = obs_lm + j.obs_ofs;
@@ -227,15 +229,15 @@ struct BaHostStruct {        // scratch reused across jobs
                 rp[fl[k]++] = r;
             }
         }
-        // LDS tiles: consecutive landmarks (internal order) with at most BA_TILE landmarks and
-        // BA_TILE blocks; inside a tile the (Y,W) block pairs are listed per pose pair, landmark
+        // LDS tiles: consecutive landmarks (internal order) with at most tile_cap landmarks and
+        // tile_cap blocks (a landmark seen from every keyframe must fit: tile_cap >= nkf); inside a tile the (Y,W) block pairs are listed per pose pair, landmark
         // ascending, as tile-local indices packed into one int
         tile_lm.clear(); tile_lm.push_back(0);
         {
             int nl_t = 0, nb_t = 0;
             for (int l = 0; l < nlm; ++l) {
                 const int k = lm_bstart[l + 1] - lm_bstart[l];
-                if (nl_t + 1 > BA_TILE || nb_t + k > BA_TILE) { tile_lm.push_back(l); nl_t = 0; nb_t = 0; }
+                if (nl_t + 1 > tile_cap || nb_t + k > tile_cap) { tile_lm.push_back(l); nl_t = 0; nb_t = 0; }
                 ++nl_t; nb_t += k;
             }
             tile_lm.push_back(nlm);
@@ -408,7 +410,8 @@ __device__ __forceinline__ void ba_linearize(const double *PT, const double *CT,
 
 __global__ void __launch_bounds__(BA_THREADS, BA_MIN_WAVES_PER_SIMD)
 k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all, const BaRec *recs_all,
-           const int *aux_all, BaWork wk, double delta, int iters, double *edge_chi2_all, long long *prof_all)
+           const int *aux_all, BaWork wk, double delta, int iters, double *edge_chi2_all, long long *prof_all,
+           int tile_cap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int job = blockIdx.x;
@@ -429,10 +432,12 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
     double *PTab = red + BA_WAVES;
     double *CTab = PTab + BA_PT * na;
     double *part = CTab + 2 * BA_CT;               // [BA_ROWS][27] pose-pass partial sums
-    double *Wt = part + 27 * BA_ROWS;              // [BA_TILE][18] blocks of the current tile
-    double *Dl = Wt + 18 * BA_TILE;                // [BA_TILE][6]  (Hll + lambda I)^-1, symmetric
-    double *Bl = Dl + 6 * BA_TILE;                 // [BA_TILE][3]  bl
-    int *iflag = reinterpret_cast<int *>(Bl + 3 * BA_TILE);
+    double *Wt = part + 27 * BA_ROWS;              // [tile_cap][18] blocks of the current tile
+    double *Dl = Wt + 18 * tile_cap;               // [tile_cap][6]  (Hll + lambda I)^-1, symmetric
+    double *Bl = Dl + 6 * tile_cap;                // [tile_cap][3]  bl
+    int *Pcs = reinterpret_cast<int *>(Bl + 3 * tile_cap);   // [npairs + 1] item ranges of the current tile
+    int *Pit = Pcs + (BA_MAX_NP / 6) * (BA_MAX_NP / 6 + 1) / 2 + 1;   // [BA_PIT_CAP] its items
+    int *iflag = Pit + BA_PIT_CAP;
 
     const BaCams &cams = *camsp;
     double *poses = poses_all + (size_t)jd.kf_ofs * 7;
@@ -601,6 +606,17 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
             double chi_part = 0;
             for (int tl = 0; tl < ntile; ++tl) {
                 const int l0 = tile_lm[tl], l1 = tile_lm[tl + 1], bt0 = lm_bstart[l0];
+                // the tile's pair ranges and items go to LDS too: issued here, stored after the
+                // landmark work, so their latency hides behind it (the Schur pass then never
+                // waits for a dependent global load)
+                const int it0 = pcs[tl * npairs], it1 = pcs[(tl + 1) * npairs];
+                int pre[BA_PIT_CAP / BA_THREADS];
+#pragma unroll
+                for (int q = 0; q < BA_PIT_CAP / BA_THREADS; ++q) {
+                    const int c = it0 + tid + q * BA_THREADS;
+                    pre[q] = c < it1 ? pitem[c] : 0;
+                }
+                const int pcs_mine = tid <= npairs ? pcs[tl * npairs + tid] : 0;   // npairs + 1 <= BA_THREADS
                 for (int lj = tid; lj < l1 - l0; lj += BA_THREADS) {
                     const int j = l0 + lj;
                     double h[6] = { 0, 0, 0, 0, 0, 0 }, b3[3] = { 0, 0, 0 };
@@ -645,34 +661,41 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
                     dd[0] = Di[0]; dd[1] = Di[1]; dd[2] = Di[2]; dd[3] = Di[4]; dd[4] = Di[5]; dd[5] = Di[8];
                     Bl[3 * lj] = b3[0]; Bl[3 * lj + 1] = b3[1]; Bl[3 * lj + 2] = b3[2];
                 }
+#pragma unroll
+                for (int q = 0; q < BA_PIT_CAP / BA_THREADS; ++q) Pit[tid + q * BA_THREADS] = pre[q];
+                if (tid <= npairs) Pcs[tid] = pcs_mine;
+                for (int i2 = BA_THREADS + tid; i2 <= npairs; i2 += BA_THREADS) Pcs[i2] = pcs[tl * npairs + i2];
                 __syncthreads();
+                BA_PROF(8);
                 {
-                    const int row = tid >> 4, rl = tid & 15;
-                    for (int pr = row; pr < npairs; pr += BA_ROWS) {
-                        const int c0 = pcs[tl * npairs + pr], c1 = pcs[tl * npairs + pr + 1];
+                    // task = (pose pair, two of the six output rows): 8-lane groups, 64 per workgroup.
+                    // Splitting a pair by output rows (not by items) keeps every S entry owned by one
+                    // group, so no partial sums have to be combined, and cuts the per-item arithmetic
+                    // and the reduction to a third, which is what balances the heavy diagonal pairs.
+                    const int grp = tid >> 3, gl = tid & 7;
+                    for (int tk = grp; tk < 3 * npairs; tk += BA_THREADS / 8) {
+                        const int pr = tk / 3, rg = tk - 3 * pr;
+                        const int c0 = Pcs[pr], c1 = Pcs[pr + 1];
                         if (c0 == c1) continue;
                         int a = 0, rem = pr;
                         while (rem >= na - a) { rem -= na - a; ++a; }
                         const int b2 = a + rem;
                         const bool diag = a == b2;
-                        double acc[36], accb[6];
+                        double acc[12], accb[2];
 #pragma unroll
-                        for (int z = 0; z < 36; ++z) acc[z] = 0;
-#pragma unroll
-                        for (int z = 0; z < 6; ++z) accb[z] = 0;
-                        for (int c = c0 + rl; c < c1; c += 16) {
-                            const int it3 = pitem[c];
+                        for (int z = 0; z < 12; ++z) acc[z] = 0;
+                        accb[0] = accb[1] = 0;
+                        for (int c = c0 + gl; c < c1; c += 8) {
+                            const int it3 = (c - it0 < BA_PIT_CAP) ? Pit[c - it0] : pitem[c];
                             const int by = it3 & 1023, bw = (it3 >> 10) & 1023, lq = it3 >> 20;
-                            double yy[18], ww[18];
-                            const double *wy = Wt + 18 * by;
-#pragma unroll
-                            for (int z = 0; z < 18; ++z) ww[z] = wy[z];
+                            double yy[6], ww[18];
                             {
+                                const double *wy = Wt + 18 * by + 6 * rg;       // rows 2 rg, 2 rg + 1 of W_y
                                 const double *Di = Dl + 6 * lq;
                                 const double d00 = Di[0], d01 = Di[1], d02 = Di[2], d11 = Di[3], d12 = Di[4], d22 = Di[5];
 #pragma unroll
-                                for (int r = 0; r < 6; ++r) {
-                                    const double x0 = ww[r * 3], x1 = ww[r * 3 + 1], x2 = ww[r * 3 + 2];
+                                for (int r = 0; r < 2; ++r) {
+                                    const double x0 = wy[r * 3], x1 = wy[r * 3 + 1], x2 = wy[r * 3 + 2];
                                     yy[r * 3 + 0] = x0 * d00 + x1 * d01 + x2 * d02;
                                     yy[r * 3 + 1] = x0 * d01 + x1 * d11 + x2 * d12;
                                     yy[r * 3 + 2] = x0 * d02 + x1 * d12 + x2 * d22;
@@ -680,48 +703,46 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
                             }
                             if (diag) {
                                 const double g0 = Bl[3 * lq], g1 = Bl[3 * lq + 1], g2 = Bl[3 * lq + 2];
-#pragma unroll
-                                for (int r = 0; r < 6; ++r) accb[r] += yy[r * 3] * g0 + yy[r * 3 + 1] * g1 + yy[r * 3 + 2] * g2;
+                                accb[0] += yy[0] * g0 + yy[1] * g1 + yy[2] * g2;
+                                accb[1] += yy[3] * g0 + yy[4] * g1 + yy[5] * g2;
                             }
-                            if (bw != by) {
+                            {
                                 const double *w2 = Wt + 18 * bw;
 #pragma unroll
                                 for (int z = 0; z < 18; ++z) ww[z] = w2[z];
                             }
 #pragma unroll
-                            for (int r = 0; r < 6; ++r)
+                            for (int r = 0; r < 2; ++r)
 #pragma unroll
                                 for (int cc = 0; cc < 6; ++cc)
                                     acc[r * 6 + cc] += yy[r * 3] * ww[cc * 3] + yy[r * 3 + 1] * ww[cc * 3 + 1] + yy[r * 3 + 2] * ww[cc * 3 + 2];
                         }
+                        double red14[14];
 #pragma unroll
-                        for (int z = 0; z < 36; ++z) acc[z] = row_sum_f64(acc[z]);
-                        // every lane of the row holds the 36 sums; lane l retires entries l, l+16, l+32
+                        for (int z = 0; z < 14; ++z) {
+                            double v = z < 12 ? acc[z] : accb[z - 12];
+                            v += dpp_f64<SVS_DPP_XOR1>(v);
+                            v += dpp_f64<SVS_DPP_XOR2>(v);
+                            v += dpp_f64<SVS_DPP_HALF_MIRROR>(v);
+                            red14[z] = v;
+                        }
+                        // every lane of the group holds the 14 sums; lane l retires entries l and l + 8
 #pragma unroll
-                        for (int g = 0; g < 3; ++g) {
-                            double mine = acc[16 * g];
+                        for (int g = 0; g < 2; ++g) {
+                            double mine = red14[8 * g];
 #pragma unroll
-                            for (int z = 1; z < 16; ++z) if (16 * g + z < 36) mine = (rl == z) ? acc[16 * g + z] : mine;
-                            const int z = 16 * g + rl;
-                            if (z < 36) {
-                                const int r = z / 6, cc = z % 6;
+                            for (int z = 1; z < 8; ++z) if (8 * g + z < 14) mine = (gl == z) ? red14[8 * g + z] : mine;
+                            const int e = 8 * g + gl;
+                            if (e < 12) {
+                                const int r = 2 * rg + e / 6, cc = e % 6;
                                 S[(size_t)(6 * a + r) * ld + 6 * b2 + cc] -= mine;
                                 if (!diag) S[(size_t)(6 * b2 + cc) * ld + 6 * a + r] -= mine;
-                            }
-                        }
-                        if (diag) {
-#pragma unroll
-                            for (int r = 0; r < 6; ++r) accb[r] = row_sum_f64(accb[r]);
-                            if (rl < 6) {
-                                double v = accb[0];
-#pragma unroll
-                                for (int r = 1; r < 6; ++r) v = (rl == r) ? accb[r] : v;
-                                bs[6 * a + rl] -= v;
-                            }
+                            } else if (e < 14 && diag) bs[6 * a + 2 * rg + (e - 12)] -= mine;
                         }
                     }
                 }
                 __syncthreads();
+                BA_PROF(9);
             }
             if (!have_chi) { currentChi = block_sum(chi_part, red, tid); have_chi = true; }
             tempChi = currentChi;
@@ -924,10 +945,21 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
     if (tid == 0) jd.iters_done = it_done;
 }
 
-static inline size_t ba_lds_bytes(int max_kf)
+static inline size_t ba_lds_fixed_bytes(int max_kf)
 {
     size_t np = 6 * (size_t)max_kf;
     return ((np + 1) * (np + 1) + 3 * np + 36 * (size_t)max_kf + BA_WAVES + BA_PT * (size_t)max_kf + 2 * BA_CT +
-            27 * BA_ROWS + 27 * (size_t)BA_TILE) * sizeof(double) + 64;
+            27 * BA_ROWS) * sizeof(double) +
+           ((BA_MAX_NP / 6) * (BA_MAX_NP / 6 + 1) / 2 + 1 + BA_PIT_CAP) * sizeof(int) + 64;
 }
+// landmarks / blocks per LDS tile: what the 160 KB leave after the reduced system, at most BA_TILE_MAX
+static inline int ba_tile_cap(int max_kf)
+{
+    const size_t lim = 160 * 1024, fixed = ba_lds_fixed_bytes(max_kf);
+    if (fixed + 27 * sizeof(double) * 64 > lim) return 0;
+    size_t t = (lim - fixed) / (27 * sizeof(double));
+    t = t / 16 * 16;
+    return (int)(t > BA_TILE_MAX ? BA_TILE_MAX : t);
+}
+static inline size_t ba_lds_bytes(int max_kf) { return ba_lds_fixed_bytes(max_kf) + 27 * sizeof(double) * (size_t)ba_tile_cap(max_kf); }
 #pragma clang fp contract(off)

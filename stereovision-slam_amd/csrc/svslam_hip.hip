@@ -393,7 +393,7 @@ int svslam_create(const svslam_limits *lim, svslam_ctx **out)
     // BA scratch
     if (lim->max_kf > 0) {
         if (6 * lim->max_kf > BA_MAX_NP) return fail(c, "max_kf %d too large (<= %d)", lim->max_kf, BA_MAX_NP / 6);
-        if (ba_lds_bytes(lim->max_kf) > 160 * 1024) return fail(c, "max_kf %d: reduced system does not fit LDS", lim->max_kf);
+        if (ba_tile_cap(lim->max_kf) < std::max(lim->max_kf, 64) || ba_lds_bytes(lim->max_kf) > 160 * 1024) return fail(c, "max_kf %d: reduced system does not fit LDS", lim->max_kf);
         if (ba_work_alloc(c->bw, lim->max_jobs, lim->max_kf, lim->max_lm, lim->max_obs) != hipSuccess)
             return fail(c, "BA workspace allocation failed");
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_local_ba),
@@ -779,7 +779,7 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
             static thread_local BaHostStruct hs;
             BaJob bj;
             memcpy(&bj, &jobs[i], sizeof(bj));
-            if (!hs.build(bj, obs_kf, obs_lm, obs_is_right, obs_uv)) { bad[(size_t)i] = 1; return; }   // index out of range
+            if (!hs.build(bj, obs_kf, obs_lm, obs_is_right, obs_uv, ba_tile_cap(c->lim.max_kf))) { bad[(size_t)i] = 1; return; }   // index out of range
             const size_t need = hs.aux_ints(bj);
             const size_t at = bump.fetch_add(need);
             if (at + need > aux_cap_ints) { bad[(size_t)i] = 2; return; }
@@ -804,7 +804,8 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
     tm_begin(c, FAM_BA, njobs);
     hipLaunchKernelGGL(k_local_ba, dim3(njobs), dim3(BA_THREADS), ba_lds_bytes(c->lim.max_kf), c->stream,
                        dp<BaDev>(c, ojobs), dp<BaCams>(c, ocams), dp<double>(c, oposes), dp<double>(c, opts),
-                       dp<BaRec>(c, orecs), dp<int>(c, oaux), c->bw, huber_delta, iters, dp<double>(c, ochi), c->d_ba_prof);
+                       dp<BaRec>(c, orecs), dp<int>(c, oaux), c->bw, huber_delta, iters, dp<double>(c, ochi), c->d_ba_prof,
+                       ba_tile_cap(c->lim.max_kf));
     tm_end(c);
     HIPCHK(c, hipGetLastError());
     if (d2h_enqueue(c, ojobs, out_end)) return -1;
