@@ -38,9 +38,12 @@
 
 #ifndef BA_THREADS
 #define BA_THREADS 512
+#endif
 #ifndef BA_MIN_WAVES_PER_SIMD
 #define BA_MIN_WAVES_PER_SIMD 2
 #endif
+#ifndef BA_LDS_LIMIT
+#define BA_LDS_LIMIT (160 * 1024)   // A/B knob: leave LDS to co-resident kernels (no gain measured)
 #endif
 #define BA_WAVES (BA_THREADS / 64)
 #define BA_ROWS (BA_THREADS / 16)
@@ -955,7 +958,7 @@ static inline size_t ba_lds_fixed_bytes(int max_kf)
 // landmarks / blocks per LDS tile: what the 160 KB leave after the reduced system, at most BA_TILE_MAX
 static inline int ba_tile_cap(int max_kf)
 {
-    const size_t lim = 160 * 1024, fixed = ba_lds_fixed_bytes(max_kf);
+    const size_t lim = BA_LDS_LIMIT, fixed = ba_lds_fixed_bytes(max_kf);
     if (fixed + 27 * sizeof(double) * 64 > lim) return 0;
     size_t t = (lim - fixed) / (27 * sizeof(double));
     t = t / 16 * 16;
