@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--host-threads", type=int, default=int(os.environ.get("SVS_BENCH_HOST_THREADS", "0")),
                     help="threads per group for the per-stream host bookkeeping (Frontend/Map/Backend glue)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pin", action="store_true", help="do not restrict the host threads to the GPU's NUMA node")
     ap.add_argument("--backend-mode", type=int, default=1, choices=(1, 2),
                     help="1 (default): local BA completes before the next frame; 2: it runs beside the next "
                          "frame like the reference's backend thread and lands exactly one frame late "
@@ -140,6 +141,7 @@ def main():
     # groups (>= 512 streams each at the default size) x at most 4 bookkeeping threads
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     cores = max(1, effective_cpus() // max(1, local_world))
+    pinned = set() if args.no_pin else sdist.pin_to_device_numa(local_rank, min_cpus=cores)
     G = args.groups if args.groups > 0 else min(8, cores)
     G = max(1, min(G, S))
     while S % G:
@@ -301,6 +303,7 @@ def main():
                                  "h2d_enqueue": round(hostns[0] / 1e6 / K / G, 3), "d2h_enqueue": round(hostns[1] / 1e6 / K / G, 3),
                                  "stream_wait": round(hostns[2] / 1e6 / K / G, 3), "event_collect": round(hostns[5] / 1e6 / K / G, 3), "ba_host_prep": round(hostns[4] / 1e6 / K / G, 3),
                                  "cpus_busy": round(cpu_busy, 2), "cpus_allowed": effective_cpus(),
+                                 "pinned_to_gpu_numa_cpus": len(pinned),
                                  "cpus_busy_by_thread_name": cpu_by_thread},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -64,3 +64,55 @@ def init(backend="nccl"):
         device = "cuda"
     dist.init_process_group(backend, rank=rank, world_size=world)
     return Rank(rank, local_rank, world, dist, device)
+
+
+def _parse_cpulist(txt):
+    out = set()
+    for part in txt.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.update(range(int(a), int(b or a) + 1))
+    return out
+
+
+def device_numa_cpus(device_index, physical_only=True):
+    """CPUs of the NUMA node the GPU hangs off (sysfs, via the device's PCI address); with
+    physical_only the first hardware thread of each core.  Empty set when it cannot be told."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+        if node < 0:
+            return set()
+        cpus = _parse_cpulist(open("/sys/devices/system/node/node%d/cpulist" % node).read())
+        if physical_only:
+            first = set()
+            for c in cpus:
+                sib = _parse_cpulist(open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read())
+                first.add(min(sib))
+            cpus &= first
+        return cpus
+    except (OSError, ValueError, AttributeError, RuntimeError, AssertionError):
+        return set()
+
+
+def pin_to_device_numa(device_index, min_cpus=1):
+    """Restrict this process (and the threads it creates from now on) to the GPU's NUMA node.
+    The host side of the path is a random walk over per-stream maps: keeping its threads and their
+    memory on one socket cut the CPU time per frame by ~15 % on a 2-socket EPYC host
+    (tools/numa.sh).  No-op unless at least min_cpus allowed CPUs remain.  Returns the CPU set used."""
+    if not hasattr(os, "sched_setaffinity"):
+        return set()
+    allowed = os.sched_getaffinity(0)
+    cpus = device_numa_cpus(device_index) & allowed
+    if len(cpus) < max(1, min_cpus):
+        cpus = device_numa_cpus(device_index, physical_only=False) & allowed
+    if len(cpus) < max(1, min_cpus):
+        return set()
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError:
+        return set()
+    return cpus
