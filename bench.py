@@ -109,6 +109,8 @@ def main():
                     help="threads per group for the per-stream host bookkeeping (Frontend/Map/Backend glue)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pin", action="store_true", help="do not restrict the host threads to the GPU's NUMA node")
+    ap.add_argument("--low-latency", action="store_true",
+                    help="latency shape of the serial kernels (svslam_set_low_latency); for a few streams per GPU")
     ap.add_argument("--backend-mode", type=int, default=1, choices=(1, 2),
                     help="1 (default): local BA completes before the next frame; 2: it runs beside the next "
                          "frame like the reference's backend thread and lands exactly one frame late "
@@ -151,7 +153,8 @@ def main():
     Sg = S // G
     F = Wm + K
     cfg = pl.default_config(W, H, host_threads=max(1, args.host_threads), backend_on=args.backend_mode,
-                            src_width=SW if args.full_res else 0, src_height=SH if args.full_res else 0)
+                            src_width=SW if args.full_res else 0, src_height=SH if args.full_res else 0,
+                            low_latency=1 if args.low_latency else 0)
     pipes = [pl.Pipeline(cfg, nstreams=Sg, device=local_rank) for _ in range(G)]
     ctxs = [svs.Context.borrow(p.kernel_ctx(), W, H) for p in pipes]   # alloc / timing through the pipelines' contexts
     ctx = ctxs[0]
@@ -267,6 +270,13 @@ def main():
         abytes = algorithmic_bytes(dom, cnt, launches)
         avg_s = (ms / 1e3) / max(launches, 1)
         achieved = (abytes / max(launches, 1)) / max(avg_s, 1e-12) / 1e9
+        by_fam = {}
+        for f, (fms, fl, _) in fam_t.items():
+            fb = algorithmic_bytes(f, cnt, fl)
+            if fl and fms > 0:
+                by_fam[f] = {"achieved": round(fb / (fms / 1e3) / 1e9, 2), "frac": round(fb / (fms / 1e3) / 1e9 / HBM_PEAK_GBS, 6),
+                             "avg_launch_us": round(1e3 * fms / fl, 2), "launches": fl}
+        all_bytes = sum(algorithmic_bytes(f, cnt, fam_t[f][1]) for f in fam_t)
         out = {
             "metric": "stereo frames/sec (track + local BA), KITTI-00-shaped synthetic stereo 1241x376 "
                       "(620x188 after the reference's 1/2 decimation)",
@@ -297,6 +307,13 @@ def main():
                          "traffic": measured_traffic(dom, cnt, launches),
                          "avg_launch_us": round(avg_s * 1e6, 2), "launches": launches,
                          "algorithmic_bytes_per_launch": round(abytes / max(launches, 1), 1)},
+            # every kernel family priced the same way (launches of different groups overlap, so each
+            # family's duration is its own HIP-event time, not a share of the wall clock), and the
+            # whole step: all algorithmic bytes of the timed region over its wall time
+            "roofline_by_family": by_fam,
+            "roofline_whole_step": {"achieved": round(all_bytes * world / elapsed / 1e9, 2), "unit": "GB/s (all ranks)",
+                                    "frac_of_peak_per_gpu": round(all_bytes / elapsed / 1e9 / HBM_PEAK_GBS, 6),
+                                    "algorithmic_bytes_per_frame": round(all_bytes / max(cnt["frames"], 1), 1)},
             "kernel_ms": {f: round(fam_t[f][0], 3) for f in fam_t},
             "host_ms_per_step": {"in_step": round(cnt["ns_step"] / 1e6 / K / G, 3),
                                  "in_abi_calls": round(cnt["ns_kernel_calls"] / 1e6 / K / G, 3),

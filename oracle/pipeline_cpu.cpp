@@ -32,6 +32,7 @@ public:
     const char *last_error() { return err_.c_str(); }
 
     int set_source_size(int src_w, int src_h) { src_w_ = src_w; src_h_ = src_h; return 0; }
+    int set_low_latency(int) { return 0; }      // a kernel shape of the HIP library; nothing to emulate
     int pyramid(int n, const int *slots, const void *const *imgs, const int *strides, int)
     {
         for (int i = 0; i < n; ++i) {

@@ -18,7 +18,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 
 ABI_SYMBOLS = [
     "svslam_create", "svslam_destroy", "svslam_last_error", "svslam_build_info",
-    "svslam_pyramid_batch", "svslam_pyramid_decimate_batch", "svslam_set_source_size", "svslam_pyramid_read",
+    "svslam_pyramid_batch", "svslam_pyramid_decimate_batch", "svslam_set_source_size", "svslam_set_low_latency", "svslam_pyramid_read",
     "svslam_lk_batch", "svslam_gftt_batch", "svslam_gftt_eigmap", "svslam_triangulate_batch",
     "svslam_pose_only_batch", "svslam_local_ba_batch", "svslam_local_ba_submit", "svslam_local_ba_collect",
     "svslam_track_batch", "svslam_rtrack_batch", "svslam_rtrack_upload",
@@ -187,6 +187,10 @@ class Context:
         self._chk(self.L.svslam_sync(self.h), "sync")
 
     # ---- timing ----------------------------------------------------------
+    def low_latency(self, on=True):
+        """latency shape of the serial kernels (svslam_set_low_latency): a few jobs per launch"""
+        self._chk(self.L.svslam_set_low_latency(self.h, 1 if on else 0), "set_low_latency")
+
     def timing(self, on=True):
         self.L.svslam_timing_enable(self.h, 1 if on else 0)
         self.L.svslam_timing_reset(self.h)

@@ -200,6 +200,34 @@ __device__ __forceinline__ void d_se3_mul(const double *A, const double *B, doub
     C[0] = q0; C[1] = q1; C[2] = q2; C[3] = q3;
     C[4] = A[4] + t[0]; C[5] = A[5] + t[1]; C[6] = A[6] + t[2];
 }
+// sin and cos for the rotation steps of an LM update: |x| < 0.5 almost always, where the Taylor
+// sums below are exact to the last place or two (truncation x^19/19!, x^18/18! < 1e-21); the
+// library routine (argument reduction, several branches) is only the fallback.
+__device__ __forceinline__ void d_sincos_small(double x, double &s, double &c)
+{
+    if (fabs(x) < 0.5) {
+        const double z = x * x;
+        double ps = -1.0 / 355687428096000.0;                 // -1/17!
+        ps = ps * z + 1.0 / 1307674368000.0;                  //  1/15!
+        ps = ps * z - 1.0 / 6227020800.0;                     // -1/13!
+        ps = ps * z + 1.0 / 39916800.0;                       //  1/11!
+        ps = ps * z - 1.0 / 362880.0;                         // -1/9!
+        ps = ps * z + 1.0 / 5040.0;                           //  1/7!
+        ps = ps * z - 1.0 / 120.0;                            // -1/5!
+        ps = ps * z + 1.0 / 6.0;                              //  1/3!
+        s = x - x * z * ps;
+        double pc = 1.0 / 20922789888000.0;                   //  1/16!
+        pc = pc * z - 1.0 / 87178291200.0;                    // -1/14!
+        pc = pc * z + 1.0 / 479001600.0;                      //  1/12!
+        pc = pc * z - 1.0 / 3628800.0;                        // -1/10!
+        pc = pc * z + 1.0 / 40320.0;                          //  1/8!
+        pc = pc * z - 1.0 / 720.0;                            // -1/6!
+        pc = pc * z + 1.0 / 24.0;                             //  1/4!
+        c = 1.0 - z * (0.5 - z * pc);
+    } else {
+        s = sin(x); c = cos(x);
+    }
+}
 __device__ __forceinline__ void d_se3_exp(const double *xi, double *T)
 {
     const double EPS = 1e-10;
@@ -213,17 +241,20 @@ __device__ __forceinline__ void d_se3_exp(const double *xi, double *T)
         real = 1.0 - (1.0 / 8.0) * th2 + (1.0 / 384.0) * th4;
     } else {
         theta = sqrt(th2);
-        double half = 0.5 * theta;
-        imag = sin(half) / theta;
-        real = cos(half);
+        double sh, ch;
+        d_sincos_small(0.5 * theta, sh, ch);
+        imag = sh / theta;
+        real = ch;
     }
     T[0] = imag * om[0]; T[1] = imag * om[1]; T[2] = imag * om[2]; T[3] = real;
     double V[9];
     if (theta < EPS) {
         d_quat_to_R(T, V);
     } else {
-        double a = (1.0 - cos(theta)) / th2;
-        double b = (theta - sin(theta)) / (th2 * theta);
+        double st, ct;
+        d_sincos_small(theta, st, ct);
+        double a = (1.0 - ct) / th2;
+        double b = (theta - st) / (th2 * theta);
         double O[9] = { 0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0 };
 #pragma unroll
         for (int i = 0; i < 3; ++i)

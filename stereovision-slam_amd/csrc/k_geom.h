@@ -101,7 +101,7 @@ struct PoseJob { int pt_ofs, npts; double pose[7]; int n_inlier; int pad; };
 // Executed redundantly by every lane on wave-uniform data.
 __device__ __forceinline__ bool d_ldlt6(const double *H, const double *b, double *x)
 {
-    double L[6][6], D[6], y[6];
+    double L[6][6], D[6], Dinv[6], y[6];
     bool ok = true;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
@@ -111,6 +111,7 @@ __device__ __forceinline__ bool d_ldlt6(const double *H, const double *b, double
         D[k] = dk;
         ok = ok && (dk > 0);
         const double inv = 1.0 / dk;
+        Dinv[k] = inv;
 #pragma unroll
         for (int i = k + 1; i < 6; ++i) {
             double v = H[i * 6 + k];
@@ -127,7 +128,7 @@ __device__ __forceinline__ bool d_ldlt6(const double *H, const double *b, double
         y[i] = v;
     }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) y[i] = y[i] / D[i];
+    for (int i = 0; i < 6; ++i) y[i] = y[i] * Dinv[i];       // the reciprocals of the pivots are already there
 #pragma unroll
     for (int i = 5; i >= 0; --i) {
         double v = y[i];
@@ -140,7 +141,7 @@ __device__ __forceinline__ bool d_ldlt6(const double *H, const double *b, double
     return ok;
 }
 
-#define PO_MAX_PER_LANE 8     // up to 512 edges per job
+#define PO_MAX_EDGES 512       // per job: 64 * PO_WAVES threads x (8 / PO_WAVES) register slots
 
 __device__ __forceinline__ void po_error(const double *cam, const double *T, const double *P,
                                          double u, double v, double &e0, double &e1)
@@ -149,31 +150,111 @@ __device__ __forceinline__ void po_error(const double *cam, const double *T, con
     d_se3_act(T, P, pc);
     double px = cam[0] * pc[0] + cam[2] * pc[2];
     double py = cam[1] * pc[1] + cam[3] * pc[2];
-    e0 = u - px / pc[2];
-    e1 = v - py / pc[2];
+    const double iz = 1.0 / pc[2];              // one reciprocal instead of two divisions (<= 1 ulp apart)
+    e0 = u - px * iz;
+    e1 = v - py * iz;
 }
 
-// One wave per job.  Edge e of the job lives in lane e%64, register slot e/64.
+// ---- block sum of 32 f64 values per thread -------------------------------------------------------
+// The normal equations of one LM step are 28 sums (21 + 6 + chi2) over all edges.  Reducing them one
+// by one costs 28 x (4 DPP steps + 4 readlanes) ~ 640 VALU instructions per step, most of the wave's
+// time.  Here the 16 lanes of a DPP row run a recursive-halving butterfly instead: at each of 4 steps
+// a lane hands half of its values to its partner and accumulates the partner's copy of the half it
+// keeps (16 + 8 + 4 + 2 = 30 adds), ending with the row totals of 2 of the 32 values.  The partners
+// are the four single-instruction DPP permutations (xor 1, xor 2, row_half_mirror, row_mirror); the
+// mirrors flip several lane bits at once, so the half a lane keeps at step k is selected by
+//   s0 = b0^b2, s1 = b1^b2, s2 = b2^b3, s3 = b3   (b = bits of the lane id)
+// which flips under the step's own permutation and is invariant under the later ones.  Row totals
+// meet in LDS ([row of the block][32]); after one barrier every wave adds the rows in a fixed order
+// and broadcasts the 28 totals with v_readlane, so all threads of the block get bit-identical sums.
+template <int CTRL, int HALF>
+__device__ __forceinline__ void po_bfly(double *v, bool sel)
+{
+#pragma unroll
+    for (int i = 0; i < HALF; ++i) {
+        const double lo = v[i], hi = v[i + HALF];
+        const double keep = sel ? hi : lo, send = sel ? lo : hi;
+        v[i] = keep + dpp_f64<CTRL>(send);
+    }
+}
+
+template <int WAVES>
+__device__ __forceinline__ void po_block_sum32(double *v, double *buf, int tid)
+{
+    const int lane = tid & 63;
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+    const bool s0 = b0 != b2, s1 = b1 != b2, s2 = b2 != b3, s3 = b3;
+    po_bfly<SVS_DPP_XOR1, 16>(v, s0);
+    po_bfly<SVS_DPP_XOR2, 8>(v, s1);
+    po_bfly<SVS_DPP_HALF_MIRROR, 4>(v, s2);
+    po_bfly<SVS_DPP_MIRROR, 2>(v, s3);
+    const int code = (s0 ? 8 : 0) + (s1 ? 4 : 0) + (s2 ? 2 : 0) + (s3 ? 1 : 0);
+    double2 *row = reinterpret_cast<double2 *>(buf + 32 * (tid >> 4));
+    row[code] = make_double2(v[0], v[1]);
+    __syncthreads();
+    double tot = 0;
+#pragma unroll
+    for (int r = 0; r < 4 * WAVES; ++r) tot += buf[32 * r + (lane & 31)];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] = readlane_f64(tot, i);
+}
+
+template <int WAVES>
+__device__ __forceinline__ double po_block_sum1(double x, double *buf, int tid)
+{
+    x = row_sum_f64(x);
+    if ((tid & 15) == 0) buf[tid >> 4] = x;
+    __syncthreads();
+    double tot = 0;
+#pragma unroll
+    for (int r = 0; r < 4 * WAVES; ++r) tot += buf[r];
+    return tot;
+}
+
+template <int WAVES>
+__device__ __forceinline__ int po_block_sum_i32(int x, int *buf, int tid)
+{
+    x = wave_sum_i32(x);
+    if (WAVES == 1) return x;
+    __syncthreads();                 // previous readers of buf are done
+    if ((tid & 63) == 0) buf[tid >> 6] = x;
+    __syncthreads();
+    int tot = 0;
+#pragma unroll
+    for (int r = 0; r < WAVES; ++r) tot += buf[r];
+    return tot;
+}
+
+// One block of WAVES wavefronts per job.  Edge e of the job lives in thread e % (64*WAVES),
+// register slot e / (64*WAVES).  WAVES = 1 is the throughput shape (thousands of jobs per launch,
+// least total work); WAVES = 4 the latency shape (a few jobs: one slot per thread up to 256 edges,
+// the per-step critical path about half as long; the wave-uniform 6x6 algebra is simply repeated
+// by every wave).  The two shapes sum in different orders, so they agree to rounding, not bit for bit.
 // status_in (optional): edges whose status_in==0 are not part of the problem
 // (used by the fused tracking path: LK failures / points without a map point).
-__global__ void __launch_bounds__(64)
+template <int WAVES>
+__global__ void __launch_bounds__(64 * WAVES)
 k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *uv,
             const uint8_t *edge_valid, uint8_t *outlier, double chi2_th, int rounds, int iters)
 {
+    constexpr int NT = 64 * WAVES, SLOTS = PO_MAX_EDGES / NT;
+    __shared__ __attribute__((aligned(16))) double s_red[4 * WAVES * 32];
+    __shared__ double s_one[2][4 * WAVES];
+    __shared__ int s_int[WAVES];
     PoseJob &jb = jobs[blockIdx.x];
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x;
     const int n = jb.npts;
     const double cam[4] = { cam4[0], cam4[1], cam4[2], cam4[3] };
     double T0[7], T[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i) { T0[i] = jb.pose[i]; T[i] = T0[i]; }
 
-    double P[PO_MAX_PER_LANE][3], mu[PO_MAX_PER_LANE], mv[PO_MAX_PER_LANE];
-    double e0[PO_MAX_PER_LANE], e1[PO_MAX_PER_LANE];
-    bool valid[PO_MAX_PER_LANE], outl[PO_MAX_PER_LANE];
+    double P[SLOTS][3], mu[SLOTS], mv[SLOTS];
+    double e0[SLOTS], e1[SLOTS];
+    bool valid[SLOTS], outl[SLOTS];
 #pragma unroll
-    for (int s = 0; s < PO_MAX_PER_LANE; ++s) {
-        int e = s * 64 + lane;
+    for (int s = 0; s < SLOTS; ++s) {
+        int e = s * NT + tid;
         valid[s] = e < n;
         outl[s] = false; e0[s] = 0; e1[s] = 0;
         if (valid[s]) {
@@ -185,39 +266,40 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
         } else { P[s][0] = P[s][1] = 0; P[s][2] = 1; mu[s] = mv[s] = 0; }
     }
     bool robust = true;
-    int cnt_outlier = 0, n_edges = 0;
+    int cnt_outlier = 0, n_edges = 0, one = 0;
 #pragma unroll
-    for (int s = 0; s < PO_MAX_PER_LANE; ++s) n_edges += valid[s] ? 1 : 0;
-    n_edges = wave_sum_i32(n_edges);
+    for (int s = 0; s < SLOTS; ++s) n_edges += valid[s] ? 1 : 0;
+    n_edges = po_block_sum_i32<WAVES>(n_edges, s_int, tid);
 
     for (int r = 0; r < rounds; ++r) {
 #pragma unroll
         for (int i = 0; i < 7; ++i) T[i] = T0[i];
         int nact = 0;
 #pragma unroll
-        for (int s = 0; s < PO_MAX_PER_LANE; ++s) nact += (valid[s] && !outl[s]) ? 1 : 0;
-        nact = wave_sum_i32(nact);
+        for (int s = 0; s < SLOTS; ++s) nact += (valid[s] && !outl[s]) ? 1 : 0;
+        nact = po_block_sum_i32<WAVES>(nact, s_int, tid);
         if (nact > 0) {
             double lambda = 0, ni = 2;
             for (int it = 0; it < iters; ++it) {
-                // errors + chi2 + normal equations at T
-                double acc[27];
+                // errors + chi2 + normal equations at T: acc[0..20] upper triangle of H, [21..26] b, [27] chi2
+                double acc[32];
 #pragma unroll
-                for (int i = 0; i < 27; ++i) acc[i] = 0;
-                double chi = 0;
+                for (int i = 0; i < 32; ++i) acc[i] = 0;
 #pragma unroll
-                for (int s = 0; s < PO_MAX_PER_LANE; ++s) {
+                for (int s = 0; s < SLOTS; ++s) {
                     if (!(valid[s] && !outl[s])) continue;
                     double pc[3];
                     d_se3_act(T, P[s], pc);
                     double X = pc[0], Y = pc[1], Z = pc[2];
                     double px = cam[0] * X + cam[2] * Z, py = cam[1] * Y + cam[3] * Z;
-                    double ex = mu[s] - px / Z, ey = mv[s] - py / Z;
+                    const double iz = 1.0 / Z;
+                    double ex = mu[s] - px * iz, ey = mv[s] - py * iz;
                     e0[s] = ex; e1[s] = ey;
                     double e2 = ex * ex + ey * ey, w = 1.0, rho = e2;
                     if (robust) d_huber(e2, 1.0, rho, w);
-                    chi += rho;
-                    double Zinv = 1.0 / (Z + 1e-18), Zinv2 = Zinv * Zinv;
+                    acc[27] += rho;
+                    const double Ze = Z + 1e-18;                       // g2o_types.h:159 (== Z unless |Z| < ~0.01)
+                    double Zinv = Ze == Z ? iz : 1.0 / Ze, Zinv2 = Zinv * Zinv;
                     double fx = cam[0], fy = cam[1];
                     double J0[6] = { -fx * Zinv, 0, fx * X * Zinv2, fx * X * Y * Zinv2, -fx - fx * X * X * Zinv2, fx * Y * Zinv };
                     double J1[6] = { 0, -fy * Zinv, fy * Y * Zinv2, fy + fy * Y * Y * Zinv2, -fy * X * Y * Zinv2, -fy * X * Zinv };
@@ -230,9 +312,8 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
 #pragma unroll
                     for (int a = 0; a < 6; ++a) acc[21 + a] -= w * (J0[a] * ex + J1[a] * ey);
                 }
-#pragma unroll
-                for (int i = 0; i < 27; ++i) acc[i] = wave_sum_f64(acc[i]);
-                double currentChi = wave_sum_f64(chi);
+                po_block_sum32<WAVES>(acc, s_red, tid);
+                double currentChi = acc[27];
                 double H[36], b[6];
                 {
                     int k = 0;
@@ -268,14 +349,16 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
                     for (int i = 0; i < 7; ++i) T[i] = Tn[i];
                     double tchi = 0;
 #pragma unroll
-                    for (int s = 0; s < PO_MAX_PER_LANE; ++s) {
+                    for (int s = 0; s < SLOTS; ++s) {
                         if (!(valid[s] && !outl[s])) continue;
                         po_error(cam, T, P[s], mu[s], mv[s], e0[s], e1[s]);
                         double e2 = e0[s] * e0[s] + e1[s] * e1[s], w, rr = e2;
                         if (robust) d_huber(e2, 1.0, rr, w);
                         tchi += rr;
                     }
-                    double tempChi = wave_sum_f64(tchi);
+                    // two alternating buffers: a rejected trial writes again before the next barrier
+                    double tempChi = po_block_sum1<WAVES>(tchi, s_one[one], tid);
+                    one ^= 1;
                     if (!ok2) tempChi = 1.7976931348623157e308;
                     rho = currentChi - tempChi;
                     double scale = 0;
@@ -303,22 +386,22 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
         // classify (src/frontend.cpp:495-525)
         int co = 0;
 #pragma unroll
-        for (int s = 0; s < PO_MAX_PER_LANE; ++s) {
+        for (int s = 0; s < SLOTS; ++s) {
             if (!valid[s]) continue;
             if (outl[s]) po_error(cam, T, P[s], mu[s], mv[s], e0[s], e1[s]);
             double chi2 = e0[s] * e0[s] + e1[s] * e1[s];
             outl[s] = chi2 > chi2_th;
             co += outl[s] ? 1 : 0;
         }
-        cnt_outlier = wave_sum_i32(co);
+        cnt_outlier = po_block_sum_i32<WAVES>(co, s_int, tid);
         if (r == 2) robust = false;
     }
 #pragma unroll
-    for (int s = 0; s < PO_MAX_PER_LANE; ++s) {
-        int e = s * 64 + lane;
+    for (int s = 0; s < SLOTS; ++s) {
+        int e = s * NT + tid;
         if (e < n) outlier[jb.pt_ofs + e] = (valid[s] && outl[s]) ? 1 : 0;
     }
-    if (lane == 0) {
+    if (tid == 0) {
 #pragma unroll
         for (int i = 0; i < 7; ++i) jb.pose[i] = T[i];
         jb.n_inlier = n_edges - cnt_outlier;

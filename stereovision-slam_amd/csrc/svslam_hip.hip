@@ -75,6 +75,7 @@ struct svslam_ctx {
     // host-side wall time (ns): 0 h2d enqueue, 1 d2h enqueue, 2 stream wait, 3 launches, 4 staging memcpy/prep
     long long host_ns[8] = { 0 };
     bool wait_poll = true;
+    bool low_latency = false;   // svslam_set_low_latency: 4-wave pose-only blocks
     int src_w = 0, src_h = 0;     // > 0: level 0 is the 2:1 decimation of src_w x src_h inputs
     // resident feature lists (svslam_rtrack_*): two alternating buffers per stream
     RtStore rt = {};
@@ -145,6 +146,15 @@ void tm_end(svslam_ctx *c)
     if (!c->timing || c->nev >= 8) return;
     (void)hipEventRecord(c->ev[2 * c->nev + 1], c->stream);
     c->nev++;
+}
+// pose-only LM: one wave per job by default, four when the context is in low-latency mode
+void launch_pose_only(svslam_ctx *c, int njobs, PoseJob *jobs, const double *cam, const double *xyz, const float2 *uv,
+                      const uint8_t *valid, uint8_t *outlier, double chi2_th, int rounds, int iters)
+{
+    if (c->low_latency)
+        hipLaunchKernelGGL(k_pose_only<4>, dim3(njobs), dim3(256), 0, c->stream, jobs, cam, xyz, uv, valid, outlier, chi2_th, rounds, iters);
+    else
+        hipLaunchKernelGGL(k_pose_only<1>, dim3(njobs), dim3(64), 0, c->stream, jobs, cam, xyz, uv, valid, outlier, chi2_th, rounds, iters);
 }
 void tm_collect(svslam_ctx *c)
 {
@@ -350,7 +360,7 @@ int svslam_create(const svslam_limits *lim, svslam_ctx **out)
     if (lim->device < 0 || lim->device >= ndev) return -3;
     if (lim->width < 16 || lim->height < 16 || lim->max_slots < 1 || lim->max_jobs < 1 || lim->max_pts < 1)
         return -4;
-    if (lim->max_pts > 64 * PO_MAX_PER_LANE) return -5;
+    if (lim->max_pts > PO_MAX_EDGES) return -5;
     if (lim->max_corners < 1 || lim->max_corners > GF_MAX_CORNERS) return -6;
     svslam_ctx *c = new (std::nothrow) svslam_ctx();
     if (!c) return -7;
@@ -471,6 +481,12 @@ int svslam_pyramid_batch(svslam_ctx *c, int n, const int *slots, const void *con
     const bool dec = c->src_w > 0;
     return pyramid_common(c, n, slots, imgs, strides, src_is_device, dec, dec ? c->src_w : c->geom.w[0],
                           dec ? c->src_h : c->geom.h[0], true);
+}
+
+int svslam_set_low_latency(svslam_ctx *c, int on)
+{
+    c->low_latency = on != 0;
+    return 0;
 }
 
 int svslam_set_source_size(svslam_ctx *c, int src_w, int src_h)
@@ -717,9 +733,8 @@ int svslam_pose_only_batch(svslam_ctx *c, int njobs, svslam_pose_job *jobs, int 
     memcpy(hp<void>(c, ojobs), jobs, sizeof(PoseJob) * njobs);
     if (h2d(c, 0, in_end)) return -1;
     tm_begin(c, FAM_POSE, njobs);
-    hipLaunchKernelGGL(k_pose_only, dim3(njobs), dim3(64), 0, c->stream, dp<PoseJob>(c, ojobs), dp<double>(c, ocam),
-                       dp<double>(c, oxyz), dp<float2>(c, ouv), (const uint8_t *)nullptr, dp<uint8_t>(c, oout),
-                       chi2_th, rounds, iters);
+    launch_pose_only(c, njobs, dp<PoseJob>(c, ojobs), dp<double>(c, ocam), dp<double>(c, oxyz), dp<float2>(c, ouv),
+                     nullptr, dp<uint8_t>(c, oout), chi2_th, rounds, iters);
     tm_end(c);
     HIPCHK(c, hipGetLastError());
     if (d2h_sync(c, ojobs, c->ar.off)) return -1;
@@ -969,9 +984,8 @@ int svslam_track_batch(svslam_ctx *c, int njobs, svslam_track_job *jobs, const v
                            c->geom.w[0], c->geom.h[0]);
     }
     tm_begin(c, FAM_POSE, njobs);
-    hipLaunchKernelGGL(k_pose_only, dim3(njobs), dim3(64), 0, c->stream, dp<PoseJob>(c, opj), dp<double>(c, ocam),
-                       dp<double>(c, oxyz), dp<float2>(c, onext), dp<uint8_t>(c, oval), dp<uint8_t>(c, oout),
-                       chi2_th, 4, 10);
+    launch_pose_only(c, njobs, dp<PoseJob>(c, opj), dp<double>(c, ocam), dp<double>(c, oxyz), dp<float2>(c, onext),
+                     dp<uint8_t>(c, oval), dp<uint8_t>(c, oout), chi2_th, 4, 10);
     tm_end(c);
     HIPCHK(c, hipGetLastError());
     // readback: pose jobs .. n_tracked (next_xy sits between; one contiguous copy)
@@ -1065,9 +1079,8 @@ int svslam_rtrack_batch(svslam_ctx *c, int njobs, svslam_rtrack_job *jobs, const
                            c->geom.w[0], c->geom.h[0]);
     }
     tm_begin(c, FAM_POSE, njobs);
-    hipLaunchKernelGGL(k_pose_only, dim3(njobs), dim3(64), 0, c->stream, dp<PoseJob>(c, opj), dp<double>(c, ocam),
-                       dp<double>(c, oxyz), dp<float2>(c, onext), dp<uint8_t>(c, oval), dp<uint8_t>(c, oout),
-                       chi2_th, 4, 10);
+    launch_pose_only(c, njobs, dp<PoseJob>(c, opj), dp<double>(c, ocam), dp<double>(c, oxyz), dp<float2>(c, onext),
+                     dp<uint8_t>(c, oval), dp<uint8_t>(c, oout), chi2_th, 4, 10);
     tm_end(c);
     hipLaunchKernelGGL(k_rt_finish, dim3(njobs), dim3(64), 0, c->stream, dp<RtJob>(c, ort), c->rt, dp<float2>(c, onext),
                        dp<uint8_t>(c, ostat), dp<uint8_t>(c, oout), dp<double>(c, oxyz), dp<float2>(c, oxy), dp<int>(c, ompo));

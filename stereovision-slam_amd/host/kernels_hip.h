@@ -48,6 +48,7 @@ public:
     }
     svslam_ctx *backend_ctx() { return ba_ctx_ ? ba_ctx_ : ctx_; }
     int set_source_size(int src_w, int src_h) { return svslam_set_source_size(ctx_, src_w, src_h); }
+    int set_low_latency(int on) { return svslam_set_low_latency(ctx_, on); }
 
     int pyramid(int n, const int *slots, const void *const *imgs, const int *strides, int is_device)
     { return svslam_pyramid_batch(ctx_, n, slots, imgs, strides, is_device); }

@@ -23,6 +23,8 @@ typedef struct svs_pipe_config {
                                   resize of Dataset::NextFrame, src/dataset.cpp:126-129, fused)        */
     int resident_track;       /* 1: the features of every stream's last frame stay in device memory
                                   (svslam_rtrack_*); used when backend_on <= 1                      */
+    int low_latency;          /* 1: latency shape of the serial kernels (svslam_set_low_latency), for a
+                                  few streams per GPU                                                */
 } svs_pipe_config;
 
 typedef struct svs_frame_result {

@@ -60,6 +60,7 @@ void *svs_pipe_create(const svs_pipe_config *cfg, int nstreams, int device)
             h->kernels->enable_backend_context(lim_ba);
         }
         h->kernels->set_host_threads(cfg->host_threads > 0 ? cfg->host_threads : 1);
+        h->kernels->set_low_latency(cfg->low_latency);
         if (cfg->src_width > 0 && h->kernels->set_source_size(cfg->src_width, cfg->src_height) != 0)
             throw std::runtime_error(std::string("source size: ") + h->kernels->last_error());
         h->pipe.reset(new svs::Pipeline<SVS_PIPE_KERNELS>(to_config(*cfg), *h->kernels, nstreams,

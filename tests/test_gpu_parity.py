@@ -184,14 +184,21 @@ def _pose_problem(rng, n, noise=0.5, outliers=0.1):
     return T_true, P, uv.astype(np.float32)
 
 
-def test_pose_only(ctx, orc):
+@pytest.mark.parametrize("low_latency", [0, 1])
+def test_pose_only(ctx, orc, low_latency):
+    """both kernel shapes (one wave per job / four waves per job, svslam_set_low_latency)"""
     rng = np.random.default_rng(21)
     jobs, truths = [], []
-    for n in (230, 64, 5, 0, 400):
+    for n in (230, 64, 5, 0, 400, 257, 512, 130):
         T_true, P, uv = _pose_problem(rng, n)
         jobs.append((cm.EXT_L.copy(), P, uv)); truths.append(T_true)
-    res = ctx.pose_only(jobs, cm.CAM)
-    for (T, outl, ninl), (T0, P, uv), T_true in zip(res, jobs, truths):
+    ctx.low_latency(bool(low_latency))
+    try:
+        res = ctx.pose_only(jobs, cm.CAM)
+        res2 = ctx.pose_only(jobs[::-1], cm.CAM)[::-1]
+    finally:
+        ctx.low_latency(False)
+    for (T, outl, ninl), (T2, outl2, ninl2), (T0, P, uv), T_true in zip(res, res2, jobs, truths):
         T_ref, outl_ref, ninl_ref = orc.pose_only(cm.CAM, T0, P, uv)
         # tolerance (SURVEY §8d): translation 1e-6 m, rotation 1e-7 rad vs the oracle
         assert np.allclose(T[4:], T_ref[4:], atol=1e-6), np.abs(T - T_ref).max()
@@ -200,6 +207,8 @@ def test_pose_only(ctx, orc):
         assert ninl == ninl_ref
         if len(P) >= 64:
             assert np.linalg.norm(T[4:] - T_true[4:]) < 0.05
+        # deterministic: independent of the job's position in the batch
+        assert np.array_equal(T, T2) and np.array_equal(outl, outl2) and ninl == ninl2
 
 
 def test_local_ba(ctx, orc):

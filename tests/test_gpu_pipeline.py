@@ -189,3 +189,24 @@ def test_pipeline_seq05_shape_seven_keyframe_window(svs, monkeypatch):
         assert ag < 0.15 and ac < 0.15 and abs(ag - ac) < 3e-2, (ag, ac)
         assert pl.ate_rmse(eg[:, k], ec[:, k]) < 8e-2
     gpu.close(); cpu.close()
+
+
+def test_pipeline_low_latency_shape_matches_cpu_twin(svs):
+    """low_latency = 1 (svslam_set_low_latency: four wavefronts per pose-only job): same bounds as the
+    default shape against the CPU twin, and deterministic."""
+    import pipe_cpu
+    pl = importlib.import_module("stereovision-slam_amd.pipeline")
+    seeds, N = [41], 16
+    cfg = pl.default_config(low_latency=1)
+    a = pl.Pipeline(cfg, nstreams=1); b = pl.Pipeline(cfg, nstreams=1)
+    cpu = pipe_cpu.make(pl.default_config(), nstreams=1)
+    ea, ma = _run(a, svs, seeds, N)
+    eb, _ = _run(b, svs, seeds, N)
+    ec, mc = _run(cpu, svs, seeds, N)
+    assert np.array_equal(ea, eb)
+    for f in range(5):
+        for k in ("status", "is_keyframe", "n_features", "n_inliers", "keyframe_id"):
+            assert np.array_equal(ma[f][k], mc[f][k]), (f, k, ma[f][k], mc[f][k])
+    assert np.allclose(ea[:4], ec[:4], atol=1e-5)
+    assert np.allclose(ea[..., 4:], ec[..., 4:], atol=2e-2), np.abs(ea - ec).max()
+    a.close(); b.close(); cpu.close()
