@@ -411,6 +411,77 @@ __device__ __forceinline__ void ba_linearize(const double *PT, const double *CT,
             L.jl[3 * r + c] = M[3 * r] * PT[c] + M[3 * r + 1] * PT[3 + c] + M[3 * r + 2] * PT[6 + c];
 }
 
+// One Schur task of a tile: S(a, b) rows 2 rg, 2 rg + 1 (and the same rows of bs when a == b) lose
+// sum_items Y W_b^T with Y = W_a (Hll + lambda I)^-1, the items striding over the LANES (8 or 16)
+// lanes of a DPP row.  (Wider groups for the diagonal pairs — 32 / 64 lanes with row_bcast
+// reductions — pushed the kernel into VGPR spills and were slower.)
+template <int LANES>
+__device__ __forceinline__ void ba_schur_task(int a, int b2, int rg, int c0, int c1, int gl, int it0,
+                                              const int *Pit, const int *__restrict__ pitem, const double *Wt,
+                                              const double *Dl, const double *Bl, double *S, double *bs, int ld)
+{
+    const bool diag = a == b2;
+    double acc[12], accb[2];
+#pragma unroll
+    for (int z = 0; z < 12; ++z) acc[z] = 0;
+    accb[0] = accb[1] = 0;
+    for (int c = c0 + gl; c < c1; c += LANES) {
+        const int it3 = (c - it0 < BA_PIT_CAP) ? Pit[c - it0] : pitem[c];
+        const int by = it3 & 1023, bw = (it3 >> 10) & 1023, lq = it3 >> 20;
+        double yy[6], ww[18];
+        {
+            const double *wy = Wt + 18 * by + 6 * rg;       // rows 2 rg, 2 rg + 1 of W_y
+            const double *Di = Dl + 6 * lq;
+            const double d00 = Di[0], d01 = Di[1], d02 = Di[2], d11 = Di[3], d12 = Di[4], d22 = Di[5];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const double x0 = wy[r * 3], x1 = wy[r * 3 + 1], x2 = wy[r * 3 + 2];
+                yy[r * 3 + 0] = x0 * d00 + x1 * d01 + x2 * d02;
+                yy[r * 3 + 1] = x0 * d01 + x1 * d11 + x2 * d12;
+                yy[r * 3 + 2] = x0 * d02 + x1 * d12 + x2 * d22;
+            }
+        }
+        if (diag) {
+            const double g0 = Bl[3 * lq], g1 = Bl[3 * lq + 1], g2 = Bl[3 * lq + 2];
+            accb[0] += yy[0] * g0 + yy[1] * g1 + yy[2] * g2;
+            accb[1] += yy[3] * g0 + yy[4] * g1 + yy[5] * g2;
+        }
+        {
+            const double *w2 = Wt + 18 * bw;
+#pragma unroll
+            for (int z = 0; z < 18; ++z) ww[z] = w2[z];
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc)
+                acc[r * 6 + cc] += yy[r * 3] * ww[cc * 3] + yy[r * 3 + 1] * ww[cc * 3 + 1] + yy[r * 3 + 2] * ww[cc * 3 + 2];
+    }
+    double red14[14];
+#pragma unroll
+    for (int z = 0; z < 14; ++z) {
+        double v = z < 12 ? acc[z] : accb[z - 12];
+        v += dpp_f64<SVS_DPP_XOR1>(v);
+        v += dpp_f64<SVS_DPP_XOR2>(v);
+        v += dpp_f64<SVS_DPP_HALF_MIRROR>(v);
+        if (LANES == 16) v += dpp_f64<SVS_DPP_MIRROR>(v);
+        red14[z] = v;
+    }
+    // every lane of the group holds the 14 sums; lane l retires entry l (and l + 8 in 8-lane groups)
+#pragma unroll
+    for (int g = 0; g < 16 / LANES; ++g) {
+        double mine = red14[LANES * g];
+#pragma unroll
+        for (int z = 1; z < LANES; ++z) if (LANES * g + z < 14) mine = (gl == z) ? red14[LANES * g + z] : mine;
+        const int e = LANES * g + gl;
+        if (e < 12) {
+            const int r = 2 * rg + e / 6, cc = e % 6;
+            S[(size_t)(6 * a + r) * ld + 6 * b2 + cc] -= mine;
+            if (!diag) S[(size_t)(6 * b2 + cc) * ld + 6 * a + r] -= mine;
+        } else if (e < 14 && diag) bs[6 * a + 2 * rg + (e - 12)] -= mine;
+    }
+}
+
 __global__ void __launch_bounds__(BA_THREADS, BA_MIN_WAVES_PER_SIMD)
 k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all, const BaRec *recs_all,
            const int *aux_all, BaWork wk, double delta, int iters, double *edge_chi2_all, long long *prof_all,
@@ -671,77 +742,26 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
                 __syncthreads();
                 BA_PROF(8);
                 {
-                    // task = (pose pair, two of the six output rows): 8-lane groups, 64 per workgroup.
-                    // Splitting a pair by output rows (not by items) keeps every S entry owned by one
-                    // group, so no partial sums have to be combined, and cuts the per-item arithmetic
-                    // and the reduction to a third, which is what balances the heavy diagonal pairs.
-                    const int grp = tid >> 3, gl = tid & 7;
-                    for (int tk = grp; tk < 3 * npairs; tk += BA_THREADS / 8) {
+                    // task = (pose pair, two of the six output rows).  Splitting a pair by output rows
+                    // (not by items) keeps every S entry owned by one lane group, so no partial sums have
+                    // to be combined.  Diagonal pairs get every block of their keyframe in the tile (a tile
+                    // of single-view landmarks is nothing but two to five diagonal pairs), so they run on
+                    // 16-lane rows, 32 at a time; the sparse off-diagonal pairs on 8-lane groups.
+                    for (int tk = tid >> 4; tk < 3 * na; tk += BA_THREADS / 16) {
+                        const int a = tk / 3, rg = tk - 3 * a;
+                        const int pr = a * na - a * (a - 1) / 2;
+                        const int c0 = Pcs[pr], c1 = Pcs[pr + 1];
+                        if (c0 == c1) continue;
+                        ba_schur_task<16>(a, a, rg, c0, c1, tid & 15, it0, Pit, pitem, Wt, Dl, Bl, S, bs, ld);
+                    }
+                    for (int tk = tid >> 3; tk < 3 * npairs; tk += BA_THREADS / 8) {
                         const int pr = tk / 3, rg = tk - 3 * pr;
                         const int c0 = Pcs[pr], c1 = Pcs[pr + 1];
                         if (c0 == c1) continue;
                         int a = 0, rem = pr;
                         while (rem >= na - a) { rem -= na - a; ++a; }
-                        const int b2 = a + rem;
-                        const bool diag = a == b2;
-                        double acc[12], accb[2];
-#pragma unroll
-                        for (int z = 0; z < 12; ++z) acc[z] = 0;
-                        accb[0] = accb[1] = 0;
-                        for (int c = c0 + gl; c < c1; c += 8) {
-                            const int it3 = (c - it0 < BA_PIT_CAP) ? Pit[c - it0] : pitem[c];
-                            const int by = it3 & 1023, bw = (it3 >> 10) & 1023, lq = it3 >> 20;
-                            double yy[6], ww[18];
-                            {
-                                const double *wy = Wt + 18 * by + 6 * rg;       // rows 2 rg, 2 rg + 1 of W_y
-                                const double *Di = Dl + 6 * lq;
-                                const double d00 = Di[0], d01 = Di[1], d02 = Di[2], d11 = Di[3], d12 = Di[4], d22 = Di[5];
-#pragma unroll
-                                for (int r = 0; r < 2; ++r) {
-                                    const double x0 = wy[r * 3], x1 = wy[r * 3 + 1], x2 = wy[r * 3 + 2];
-                                    yy[r * 3 + 0] = x0 * d00 + x1 * d01 + x2 * d02;
-                                    yy[r * 3 + 1] = x0 * d01 + x1 * d11 + x2 * d12;
-                                    yy[r * 3 + 2] = x0 * d02 + x1 * d12 + x2 * d22;
-                                }
-                            }
-                            if (diag) {
-                                const double g0 = Bl[3 * lq], g1 = Bl[3 * lq + 1], g2 = Bl[3 * lq + 2];
-                                accb[0] += yy[0] * g0 + yy[1] * g1 + yy[2] * g2;
-                                accb[1] += yy[3] * g0 + yy[4] * g1 + yy[5] * g2;
-                            }
-                            {
-                                const double *w2 = Wt + 18 * bw;
-#pragma unroll
-                                for (int z = 0; z < 18; ++z) ww[z] = w2[z];
-                            }
-#pragma unroll
-                            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                                for (int cc = 0; cc < 6; ++cc)
-                                    acc[r * 6 + cc] += yy[r * 3] * ww[cc * 3] + yy[r * 3 + 1] * ww[cc * 3 + 1] + yy[r * 3 + 2] * ww[cc * 3 + 2];
-                        }
-                        double red14[14];
-#pragma unroll
-                        for (int z = 0; z < 14; ++z) {
-                            double v = z < 12 ? acc[z] : accb[z - 12];
-                            v += dpp_f64<SVS_DPP_XOR1>(v);
-                            v += dpp_f64<SVS_DPP_XOR2>(v);
-                            v += dpp_f64<SVS_DPP_HALF_MIRROR>(v);
-                            red14[z] = v;
-                        }
-                        // every lane of the group holds the 14 sums; lane l retires entries l and l + 8
-#pragma unroll
-                        for (int g = 0; g < 2; ++g) {
-                            double mine = red14[8 * g];
-#pragma unroll
-                            for (int z = 1; z < 8; ++z) if (8 * g + z < 14) mine = (gl == z) ? red14[8 * g + z] : mine;
-                            const int e = 8 * g + gl;
-                            if (e < 12) {
-                                const int r = 2 * rg + e / 6, cc = e % 6;
-                                S[(size_t)(6 * a + r) * ld + 6 * b2 + cc] -= mine;
-                                if (!diag) S[(size_t)(6 * b2 + cc) * ld + 6 * a + r] -= mine;
-                            } else if (e < 14 && diag) bs[6 * a + 2 * rg + (e - 12)] -= mine;
-                        }
+                        if (rem == 0) continue;                 // diagonal: done above
+                        ba_schur_task<8>(a, a + rem, rg, c0, c1, tid & 7, it0, Pit, pitem, Wt, Dl, Bl, S, bs, ld);
                     }
                 }
                 __syncthreads();
