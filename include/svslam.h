@@ -82,7 +82,8 @@ int svslam_set_source_size(svslam_ctx *ctx, int src_w, int src_h);
  * hundreds of streams.  1: a few streams per launch (one camera per GPU, BASELINE config 4) —
  * the pose-only LM of EstimateCurrentPose (src/frontend.cpp:394-558) runs on four wavefronts per
  * job instead of one (about half the latency per frame, ~1.3x the arithmetic).  The two shapes
- * sum the normal equations in different orders: results agree to rounding, each is deterministic. */
+ * sum the normal equations in different orders: results agree to rounding, each is deterministic.
+ * In this mode the blocking calls also wait inside the HIP runtime instead of sleep-polling.     */
 int svslam_set_low_latency(svslam_ctx *ctx, int on);
 /* test hook: read one level back (tight rows of *w bytes) */
 int svslam_pyramid_read(svslam_ctx *ctx, int slot, int level, uint8_t *out,

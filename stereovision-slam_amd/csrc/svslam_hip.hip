@@ -486,6 +486,9 @@ int svslam_pyramid_batch(svslam_ctx *c, int n, const int *slots, const void *con
 int svslam_set_low_latency(svslam_ctx *c, int on)
 {
     c->low_latency = on != 0;
+    // a caller that waits for one camera's frame wants the result, not its core back: block in the
+    // runtime instead of sleep-polling the event (SVSLAM_WAIT=poll|spin still overrides)
+    if (!std::getenv("SVSLAM_WAIT")) c->wait_poll = !c->low_latency;
     return 0;
 }
 
