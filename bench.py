@@ -125,6 +125,8 @@ def main():
     import torch
     svs = importlib.import_module("stereovision-slam_amd")
     pl = importlib.import_module("stereovision-slam_amd.pipeline")
+    if os.environ.get("SVS_MALLOC_TUNING", "1") == "1":
+        pl.tune_allocator()
     sdist = importlib.import_module("stereovision-slam_amd.dist")
     rk = sdist.init("nccl")                          # RCCL; one process per GPU
     rank, local_rank, world = rk.rank, rk.local_rank, rk.world
@@ -321,6 +323,7 @@ def main():
                                  "stream_wait": round(hostns[2] / 1e6 / K / G, 3), "event_collect": round(hostns[5] / 1e6 / K / G, 3), "ba_host_prep": round(hostns[4] / 1e6 / K / G, 3),
                                  "cpus_busy": round(cpu_busy, 2), "cpus_allowed": effective_cpus(),
                                  "pinned_to_gpu_numa_cpus": len(pinned),
+                                 "minor_page_faults_per_step": round((ru1.ru_minflt - ru0.ru_minflt) / K, 1),
                                  "cpus_busy_by_thread_name": cpu_by_thread},
         }
         if world == 1 and not args.no_cpu_baseline:

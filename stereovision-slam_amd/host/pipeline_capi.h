@@ -42,6 +42,11 @@ typedef struct svs_pipe_counters {
 void *svs_pipe_create(const svs_pipe_config *cfg, int nstreams, int device);
 void svs_pipe_destroy(void *p);
 const char *svs_pipe_last_error(void);
+/* Process-wide glibc malloc settings for a host that drives thousands of streams: the per-frame
+ * Frame / feature-list churn otherwise makes every thread's heap top shrink and regrow (munmap /
+ * mmap / page faults, all under the process' mm lock).  Never trims, serves large vectors from the
+ * heaps, grows them in 64 MB steps.  Optional; call once before creating pipelines.            */
+void svs_pipe_tune_allocator(void);
 /* completes a backend optimisation still in flight (backend_on 2) */
 int svs_pipe_flush(void *p);
 /* one frame for every stream; left/right: nstreams image pointers (host or device) */

@@ -3,6 +3,7 @@
 // SVS_PIPE_MAKE_KERNELS defined.
 #pragma once
 #include <cstring>
+#include <malloc.h>
 #include <memory>
 #include <string>
 #include "pipeline_capi.h"
@@ -39,6 +40,13 @@ svs::Config to_config(const svs_pipe_config &c)
 extern "C" {
 
 const char *svs_pipe_last_error(void) { return g_err.c_str(); }
+
+void svs_pipe_tune_allocator(void)
+{
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TOP_PAD, 64 << 20);
+}
 
 void *svs_pipe_create(const svs_pipe_config *cfg, int nstreams, int device)
 {

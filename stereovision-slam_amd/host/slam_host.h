@@ -203,6 +203,12 @@ public:
             if (rm->right[i].mp >= 0) RemoveObservation(point(rm->right[i].mp), ObsRef{ rm, (int)i, false });
         }
         CleanMap();
+        // Nothing refers to the features of a keyframe that left the window any more (its
+        // observations were just removed; Map::keyframes_ keeps the frame for its pose): give the
+        // lists back so the next keyframe reuses the memory instead of faulting in fresh pages.
+        std::vector<Feature>().swap(rm->left);
+        std::vector<Feature>().swap(rm->right);
+        std::vector<uint8_t>().swap(rm->right_ok);
     }
 
     std::vector<Frame *> keyframes_, active_keyframes_;   // id-ascending

@@ -39,6 +39,11 @@ RESULT_DTYPE = np.dtype([("pose", np.float64, 7), ("status", np.int32), ("is_key
 assert RESULT_DTYPE.itemsize == C.sizeof(FrameResult)
 
 
+def tune_allocator(lib=None):
+    """process-wide malloc settings for many-stream hosts (svs_pipe_tune_allocator)"""
+    (_bind(lib) if lib is not None else product_lib()).svs_pipe_tune_allocator()
+
+
 def default_config(width=620, height=188, cam=(359.428, 359.428, 303.5964, 92.60785), baseline=0.537166, **kw):
     """config/stereo_slam_configs/config-00.yaml of the reference + KITTI-00 halved calibration"""
     c = PipeConfig()
@@ -89,6 +94,7 @@ def _bind(L):
     L.svs_pipe_counters_get.argtypes = [C.c_void_p, C.POINTER(Counters)]
     L.svs_pipe_save_outputs.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int]
     L.svs_pipe_flush.argtypes = [C.c_void_p]
+    L.svs_pipe_tune_allocator.restype = None
     L.svs_pipe_backend_ctx.restype = C.c_void_p
     L.svs_pipe_backend_ctx.argtypes = [C.c_void_p]
     L.svs_pipe_kernel_ctx.restype = C.c_void_p
