@@ -226,6 +226,7 @@ def main():
     barrier()
     import resource
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
+    rss0 = int(open("/proc/self/statm").read().split()[1]) * os.sysconf("SC_PAGE_SIZE")
     tc0 = thread_cpu_seconds()
     t0 = time.perf_counter()
     res_g = run_all(Wm, K, True)
@@ -233,6 +234,7 @@ def main():
         torch.cuda.synchronize()
     t1 = time.perf_counter()
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    rss1 = int(open("/proc/self/statm").read().split()[1]) * os.sysconf("SC_PAGE_SIZE")
     tc1 = thread_cpu_seconds()
     cpu_by_thread = {k: round((tc1[k] - tc0.get(k, 0.0)) / max(t1 - t0, 1e-9), 2) for k in tc1
                      if tc1[k] - tc0.get(k, 0.0) > 0.005 * (t1 - t0)}
@@ -324,6 +326,7 @@ def main():
                                  "cpus_busy": round(cpu_busy, 2), "cpus_allowed": effective_cpus(),
                                  "pinned_to_gpu_numa_cpus": len(pinned),
                                  "minor_page_faults_per_step": round((ru1.ru_minflt - ru0.ru_minflt) / K, 1),
+                                 "rss_growth_bytes_per_frame": round((rss1 - rss0) / max(S * K, 1), 1),
                                  "cpus_busy_by_thread_name": cpu_by_thread},
         }
         if world == 1 and not args.no_cpu_baseline:
