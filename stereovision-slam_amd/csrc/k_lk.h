@@ -84,7 +84,9 @@ __device__ __forceinline__ LkW lk_weights(float a, float b)
 __device__ __forceinline__ int lk_sample_u8(const uint32_t *base32, int a, int row_stride, LkW w)
 {
     const uint32_t sel = lk_pair_sel(a);
-    const uint32_t t = lk_pair_at(base32, a, sel), b = lk_pair_at(base32, a + row_stride, sel);
+    const uint32_t *q = base32 + (a >> 2);            // one address; the lower row is an immediate offset
+    const int rs = row_stride >> 2;
+    const uint32_t t = __builtin_amdgcn_perm(q[1], q[0], sel), b = __builtin_amdgcn_perm(q[rs + 1], q[rs], sel);
     return lk_dot2(t, w.top, lk_dot2(b, w.bot, 1 << (LK_W_BITS - 5 - 1))) >> (LK_W_BITS - 5);
 }
 
@@ -112,12 +114,18 @@ __device__ __forceinline__ void lk_stage_J(uint32_t *sJ, const uint8_t *J0, int 
     __builtin_amdgcn_wave_barrier();
 }
 
-// exact int64 -> f32 (round to nearest even); the sums fit int32 except for adversarial patches
-__device__ __forceinline__ float lk_i64_to_f32(long long s)
+// (float)s * scale for a wave-uniform 64-bit sum, |s| < 2^32 (121 x 8160 x 4080), scale a power of
+// two.  The sums fit int32 except for adversarial patches; beyond that the value is halved with a
+// sticky low bit, which rounds to the same float (the rounding position is far above bit 1), and
+// the factor 2 moves into the scale.  Both cases are integer selects on the scalar unit plus one
+// v_cvt_f32_i32 and one multiply — no 64-bit or f64 vector arithmetic in the iteration loop.
+__device__ __forceinline__ float lk_sum_to_f32(long long s, float scale)
 {
     const int lo = (int)s;
-    if ((long long)lo == s) return (float)lo;
-    return (float)(double)s;
+    const bool fits = (long long)lo == s;
+    const int t = fits ? lo : (int)((s >> 1) | (s & 1));
+    const uint32_t kb = fits ? __float_as_uint(scale) : __float_as_uint(2.f * scale);   // integer select: stays scalar
+    return (float)t * __uint_as_float(kb);
 }
 
 __global__ void __launch_bounds__(64 * LK_WAVES_PER_BLOCK)
@@ -285,7 +293,7 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
             const int pb2 = __mul24(d0, iy0) + __mul24(d1, iy1);
             const long long sb1 = wave_sum_i32_wide(pb1);
             const long long sb2 = wave_sum_i32_wide(pb2);
-            const float b1 = lk_i64_to_f32(sb1) * FLT_SCALE, b2 = lk_i64_to_f32(sb2) * FLT_SCALE;
+            const float b1 = lk_sum_to_f32(sb1, FLT_SCALE), b2 = lk_sum_to_f32(sb2, FLT_SCALE);
             const float dx = (A12 * b2 - A22 * b1) * D;
             const float dy = (A12 * b1 - A11 * b2) * D;
             nx += dx; ny += dy;
