@@ -118,6 +118,45 @@ def test_lk_no_initial_flow_and_params(ctx, orc, svs, frames):
         assert np.array_equal(q.view(np.uint32), q_ref.view(np.uint32)), (lvl, it, eps, use)
 
 
+def test_lk_sums_beyond_int32(svs, orc):
+    """Adversarial patches: period-4 column stripes against the same stripes shifted by one pixel make
+    every other column of the 11x11 window contribute |diff * Ix| = 8160 * 4080 with one sign, so the
+    b-sums pass 2^31 (6 columns x 11 rows x 33.3e6 = 2.2e9); a few grey dots give the patch the
+    vertical gradient the min-eigenvalue test wants.  The kernel converts such a wave-uniform 64-bit
+    sum to f32 by halving it with a sticky bit; the oracle casts the int64."""
+    W, H = 96, 64
+    x = np.arange(W + 1)
+    stripes = (((x // 2) & 1) * 255).astype(np.int64)
+    full = np.tile(stripes[None, :], (H, 1)); full[::12, ::4] = 128
+    I = full[:, :W].astype(np.uint8); J = full[:, 1:W + 1].astype(np.uint8)
+    # the windows whose zero-flow b1 really leaves int32 while the patch passes the min-eig test
+    p = np.pad(I.astype(np.int64), 1, mode="reflect")
+    t0 = 3 * (p[:-2, :] + p[2:, :]) + 10 * p[1:-1, :]; t1 = p[2:, :] - p[:-2, :]
+    gx = t0[:, 2:] - t0[:, :-2]; gy = 3 * (t1[:, :-2] + t1[:, 2:]) + 10 * t1[:, 1:-1]
+    pts = []
+    for cy in range(8, H - 8):
+        for cx in range(8, W - 9):
+            sl = (slice(cy - 5, cy + 6), slice(cx - 5, cx + 6))
+            d = 32 * (J[sl].astype(np.int64) - I[sl]); ix, iy = gx[sl], gy[sl]
+            A11, A12, A22 = (ix * ix).sum() / 2 ** 20, (ix * iy).sum() / 2 ** 20, (iy * iy).sum() / 2 ** 20
+            mineig = (A22 + A11 - np.sqrt((A11 - A22) ** 2 + 4 * A12 * A12)) / 242
+            if abs(int((d * ix).sum())) > 2 ** 31 and mineig > 1e-3:
+                pts.append((cx, cy))
+    assert len(pts) >= 16
+    pts = np.array(pts[::max(1, len(pts) // 12)][:12] + [(20.25, 18.5), (33.5, 30.75)], np.float32)
+    c = svs.Context(W, H, max_slots=2, max_jobs=2, max_pts=16, max_kf=0, max_lm=0, max_obs=0)
+    c.pyramid([0, 1], [I, J])
+    for it in (1, 2, 30):
+        prm = (0, it, 0.01, 1e-4, 0)
+        (q, st, err), = c.lk([(0, 1, pts, pts)], params=svs.LkParams(*prm))
+        q_ref, st_ref, err_ref = orc.lk(I, J, pts, pts, params=orc.lk_params(*prm))
+        assert st_ref[:12].all()                   # the patches are tracked, i.e. the sums were formed
+        assert np.array_equal(st, st_ref), it
+        assert np.array_equal(q.view(np.uint32), q_ref.view(np.uint32)), (it, q, q_ref)
+        assert np.array_equal(err.view(np.uint32), err_ref.view(np.uint32))
+    c.close()
+
+
 def test_gftt_eigmap_bit_exact(ctx, orc, frames):
     l0, _ = frames[0]
     ctx.pyramid([0], [l0])
