@@ -128,8 +128,10 @@ def main():
     if os.environ.get("SVS_MALLOC_TUNING", "1") == "1":
         pl.tune_allocator()
     sdist = importlib.import_module("stereovision-slam_amd.dist")
-    rk = sdist.init("nccl")                          # RCCL; one process per GPU
+    rk = sdist.init(os.environ.get("SVS_DIST_BACKEND", "nccl"))   # RCCL; one process per GPU
     rank, local_rank, world = rk.rank, rk.local_rank, rk.world
+    if "SVS_FORCE_DEVICE" in os.environ:            # dry run of the N-rank path on a 1-GPU box (with gloo)
+        local_rank = int(os.environ["SVS_FORCE_DEVICE"])
     if world == 1 and torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
     svs.load()                                      # fails loudly if the HIP library is missing
