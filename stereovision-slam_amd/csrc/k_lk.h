@@ -64,6 +64,14 @@ __device__ __forceinline__ uint32_t lk_pair_at(const uint32_t *base32, int a, ui
     return __builtin_amdgcn_perm(q[1], q[0], sel);
 }
 
+// (int)floorf(x) in one VALU instruction (v_cvt_flr_i32_f32) instead of v_floor + v_cvt
+__device__ __forceinline__ int lk_floor_i(float x)
+{
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 struct LkW { uint32_t top, bot; };   // (w00 | w01 << 16), (w10 | w11 << 16); w11 may be -1 (kept signed)
 
 __device__ __forceinline__ LkW lk_weights(float a, float b)
@@ -88,6 +96,17 @@ __device__ __forceinline__ int lk_sample_u8(const uint32_t *base32, int a, int r
     const int rs = row_stride >> 2;
     const uint32_t t = __builtin_amdgcn_perm(q[1], q[0], sel), b = __builtin_amdgcn_perm(q[rs + 1], q[rs], sel);
     return lk_dot2(t, w.top, lk_dot2(b, w.bot, 1 << (LK_W_BITS - 5 - 1))) >> (LK_W_BITS - 5);
+}
+
+// lk_sample_u8(...) - iv with the subtraction folded into the accumulator: the caller passes
+// acc0 = (1 << 8) - (iv << 9); (x - 512 iv) >> 9 == (x >> 9) - iv for the arithmetic shift.
+__device__ __forceinline__ int lk_sample_diff(const uint32_t *base32, int a, int row_stride, LkW w, int acc0)
+{
+    const uint32_t sel = lk_pair_sel(a);
+    const uint32_t *q = base32 + (a >> 2);
+    const int rs = row_stride >> 2;
+    const uint32_t t = __builtin_amdgcn_perm(q[1], q[0], sel), b = __builtin_amdgcn_perm(q[rs + 1], q[rs], sel);
+    return lk_dot2(t, w.top, lk_dot2(b, w.bot, acc0)) >> (LK_W_BITS - 5);
 }
 
 __device__ __forceinline__ void lk_stage_J(uint32_t *sJ, const uint8_t *J0, int pitch, int w, int h,
@@ -183,7 +202,7 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
         nextp.x = nx; nextp.y = ny;
 
         px -= 5.f; py -= 5.f;
-        const int ipx = __builtin_amdgcn_readfirstlane((int)floorf(px)), ipy = __builtin_amdgcn_readfirstlane((int)floorf(py));
+        const int ipx = __builtin_amdgcn_readfirstlane(lk_floor_i(px)), ipy = __builtin_amdgcn_readfirstlane(lk_floor_i(py));
         if (ipx < -LK_WIN || ipx >= w || ipy < -LK_WIN || ipy >= h) {
             if (level == 0) { st = false; errv = 0.f; }
             continue;
@@ -268,13 +287,14 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
             continue;
         }
         D = 1.f / D;
+        const int acc00 = (1 << (LK_W_BITS - 5 - 1)) - (iv0 << (LK_W_BITS - 5)), acc01 = (1 << (LK_W_BITS - 5 - 1)) - (iv1 << (LK_W_BITS - 5));
         nx -= 5.f; ny -= 5.f;
         float pdx = 0.f, pdy = 0.f;
         int rx0, ry0;
-        lk_stage_J(sJ, J0, pitch, w, h, (int)floorf(nx), (int)floorf(ny), lane, rx0, ry0);
+        lk_stage_J(sJ, J0, pitch, w, h, lk_floor_i(nx), lk_floor_i(ny), lane, rx0, ry0);
 
         for (int j = 0; j < prm.max_count; ++j) {
-            const int inx = __builtin_amdgcn_readfirstlane((int)floorf(nx)), iny = __builtin_amdgcn_readfirstlane((int)floorf(ny));
+            const int inx = __builtin_amdgcn_readfirstlane(lk_floor_i(nx)), iny = __builtin_amdgcn_readfirstlane(lk_floor_i(ny));
             if (inx < -LK_WIN || inx >= w || iny < -LK_WIN || iny >= h) {
                 if (level == 0) st = false;
                 break;
@@ -286,8 +306,8 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
             }
             const LkW jw = lk_weights(nx - (float)inx, ny - (float)iny);
             const int jo = oy * LK_REG + ox;
-            const int d0 = lk_sample_u8(sJ, jo + oJ0, LK_REG, jw) - iv0;
-            const int d1 = lk_sample_u8(sJ, jo + oJ1, LK_REG, jw) - iv1;
+            const int d0 = lk_sample_diff(sJ, jo + oJ0, LK_REG, jw, acc00);
+            const int d1 = lk_sample_diff(sJ, jo + oJ1, LK_REG, jw, acc01);
             // |d| < 2^14, |Ix|,|Iy| < 2^13: 24-bit multiplies, 16-lane row sums fit int32
             const int pb1 = __mul24(d0, ix0) + __mul24(d1, ix1);
             const int pb2 = __mul24(d0, iy0) + __mul24(d1, iy1);
@@ -310,7 +330,7 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
         if (st && level == 0) {
             // level-0 residual ("err" output); can still clear status
             const float fx = nextp.x - 5.f, fy = nextp.y - 5.f;
-            const int inx = __builtin_amdgcn_readfirstlane((int)floorf(fx)), iny = __builtin_amdgcn_readfirstlane((int)floorf(fy));
+            const int inx = __builtin_amdgcn_readfirstlane(lk_floor_i(fx)), iny = __builtin_amdgcn_readfirstlane(lk_floor_i(fy));
             if (inx < -LK_WIN || inx >= w || iny < -LK_WIN || iny >= h) {
                 st = false;
                 continue;
