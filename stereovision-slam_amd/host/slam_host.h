@@ -203,12 +203,21 @@ public:
             if (rm->right[i].mp >= 0) RemoveObservation(point(rm->right[i].mp), ObsRef{ rm, (int)i, false });
         }
         CleanMap();
-        // Nothing refers to the features of a keyframe that left the window any more (its
-        // observations were just removed; Map::keyframes_ keeps the frame for its pose): give the
-        // lists back so the next keyframe reuses the memory instead of faulting in fresh pages.
-        std::vector<Feature>().swap(rm->left);
-        std::vector<Feature>().swap(rm->right);
-        std::vector<uint8_t>().swap(rm->right_ok);
+        retired_.push_back(rm);
+    }
+    // The map no longer refers to the features of a keyframe that left the window (its
+    // observations were removed above; Map::keyframes_ keeps the frame for its pose), so their
+    // lists can go back to the allocator and the next keyframe reuses the memory instead of
+    // faulting in fresh pages.  The caller decides when: a local BA still in flight holds
+    // ObsRefs into the frames of the window it was gathered from.
+    void ReleaseRetired()
+    {
+        for (Frame *rm : retired_) {
+            std::vector<Feature>().swap(rm->left);
+            std::vector<Feature>().swap(rm->right);
+            std::vector<uint8_t>().swap(rm->right_ok);
+        }
+        retired_.clear();
     }
 
     std::vector<Frame *> keyframes_, active_keyframes_;   // id-ascending
@@ -216,6 +225,7 @@ public:
 
 private:
     std::deque<MapPoint> store_;
+    std::vector<Frame *> retired_;            // left the window, feature lists not yet released
     Frame *current_frame_ = nullptr;
     int num_active_keyframes_;
 };
@@ -363,10 +373,14 @@ public:
         // reference's Backend thread, and its result lands after that frame — always exactly one
         // frame late, so runs stay reproducible.
         if (cfg_.backend_on == 1) {
+            for (int s : MS) streams_[s]->map.ReleaseRetired();      // nothing in flight
             if (!MS.empty()) { BackendSubmit(MS); BackendCollect(); }
         } else if (cfg_.backend_on >= 2) {
-            BackendCollect();
+            BackendCollect();                                        // may still touch frames retired this step
+            for (int s : MS) streams_[s]->map.ReleaseRetired();
             if (!MS.empty()) BackendSubmit(MS);
+        } else {
+            for (int s : MS) streams_[s]->map.ReleaseRetired();
         }
         // frames whose feature list or map points changed on the host (init, keyframes, BA) replace
         // the resident copy; every other frame's list never left the device
