@@ -247,3 +247,22 @@ def test_stream_sharding_over_gloo_world2(tmp_path):
     assert outs[0]["tmax"] == outs[1]["tmax"] == 2.0        # max over ranks
     assert outs[0]["nstreams"] == outs[1]["nstreams"] == 4.0
     assert outs[0]["z"] < -1.0 and outs[1]["z"] < -1.0       # both ranks tracked ~0.85 m/frame forward
+
+
+def test_numa_pinning_helpers_degrade_gracefully():
+    """dist.pin_to_device_numa: cpulist parsing, and no GPU / no sysfs entry means "leave the affinity alone"."""
+    sdist = importlib.import_module("stereovision-slam_amd.dist")
+    assert sdist._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    assert sdist._parse_cpulist("") == set()
+    before = os.sched_getaffinity(0)
+    got = sdist.pin_to_device_numa(0, min_cpus=1)
+    assert got == set() or got <= before          # CPU-only container: nothing to pin to
+    assert os.sched_getaffinity(0) == (got or before)
+    os.sched_setaffinity(0, before)
+
+
+def test_allocator_tuning_hook_is_exported_and_harmless():
+    import pipe_cpu
+    pl = importlib.import_module("stereovision-slam_amd.pipeline")
+    pl.tune_allocator(pipe_cpu.twin_lib())        # same C API in the twin; process-wide malloc settings
+    a = np.ones(1 << 20); del a
