@@ -210,3 +210,30 @@ def test_pipeline_low_latency_shape_matches_cpu_twin(svs):
     assert np.allclose(ea[:4], ec[:4], atol=1e-5)
     assert np.allclose(ea[..., 4:], ec[..., 4:], atol=2e-2), np.abs(ea - ec).max()
     a.close(); b.close(); cpu.close()
+
+
+def test_bench_contract_small_run():
+    """bench.py prints exactly one JSON line with the driver's keys plus roofline and cpu_baseline."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "3",
+                          "--streams", "16", "--groups", "2", "--host-threads", "1", "--cpu-frames", "40"],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 3 and d["unit"] == "frames/s"
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert abs(d["value"] - 16 * 6 / (d["ms_per_step"] * 6e-3)) <= 1e-3 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6 and r["achieved"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "frames/s" and c["sample"]
+    assert "workload" in d["config"] and d["config"]["checks"]["duplicate_stream_bit_identical"] is True
