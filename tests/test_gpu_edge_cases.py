@@ -187,3 +187,49 @@ def test_resident_track_edge_cases(svs):
     with pytest.raises(RuntimeError, match="out of range"):
         c.rtrack([(7, 2, 3, l1, T, T, 0)], cm.CAM)
     c.close()
+
+
+def test_full_size_batch_properties_without_oracle(svs):
+    """192 KITTI-shaped frames in one batch per call (the size the oracle does not finish in seconds):
+    domain properties that need no reference — GFTT corners are integer, at least min_dist apart,
+    outside the mask squares and at most max_corners; tracking an image onto itself is the identity;
+    stereo matches triangulate to points that re-project onto both pixels."""
+    n = 192
+    frames = [svs.synth_pair(500 + i, i % 7) for i in range(n)]
+    c = svs.Context(cm.W, cm.H, max_slots=2 * n, max_jobs=2 * n, max_pts=256, max_corners=150, max_kf=0, max_lm=0, max_obs=0)
+    c.pyramid(list(range(2 * n)), [f[0] for f in frames] + [f[1] for f in frames])
+    rng = np.random.default_rng(3)
+    rects = [rng.uniform([20, 20], [cm.W - 20, cm.H - 20], (40, 2)).astype(np.float32) for _ in range(n)]
+    corners = c.gftt([(i, rects[i]) for i in range(n)])
+    for i, k in enumerate(corners):
+        assert 20 <= len(k) <= 150
+        assert np.array_equal(k, np.round(k)) and (k >= 1).all() and (k[:, 0] <= cm.W - 2).all() and (k[:, 1] <= cm.H - 2).all()
+        d = np.linalg.norm(k[:, None, :] - k[None, :, :], axis=2) + 1e9 * np.eye(len(k))
+        assert d.min() >= 20.0
+        lo, hi = np.rint(rects[i] - 10), np.rint(rects[i] + 10)          # cv::rectangle on rounded corners, inclusive
+        inside = ((k[:, None, :] >= lo[None]) & (k[:, None, :] <= hi[None])).all(2)
+        assert not inside.any()
+    # identity: I -> I from the exact positions
+    res = c.lk([(i, i, corners[i], corners[i]) for i in range(n)])
+    for (q, st, err), k in zip(res, corners):
+        assert st.all() and np.array_equal(q, k) and (err == 0).all()
+    # stereo: left -> right, triangulate, re-project
+    res = c.lk([(i, n + i, corners[i], corners[i]) for i in range(n)])
+    tri = c.triangulate([(corners[i], res[i][0], None, 0.0) for i in range(n)], cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R)
+    nok = 0
+    for i in range(n):
+        q, st, _ = res[i]
+        xyz, ok = tri[i]
+        m = (st > 0) & (ok > 0)
+        nok += int(m.sum())
+        ident = np.array([0, 0, 0, 1, 0, 0, 0], float)
+        ul, zl = cm.project(cm.CAM, ident, cm.EXT_L, xyz[m])
+        ur, zr = cm.project(cm.CAM, ident, cm.EXT_R, xyz[m])
+        assert (zl > 0).all() and (zr > 0).all()
+        # the DLT point minimises the algebraic error: it re-projects within a fraction of the
+        # vertical disparity the two measurements disagree by
+        dv = np.abs(corners[i][m][:, 1] - q[m][:, 1])
+        assert (np.abs(ul - corners[i][m]).max(1) <= 0.6 * dv + 1e-3).all()
+        assert (np.abs(ur - q[m]).max(1) <= 0.6 * dv + 1e-3).all()
+    assert nok > 60 * n
+    c.close()
