@@ -233,3 +233,37 @@ def test_full_size_batch_properties_without_oracle(svs):
         assert (np.abs(ur - q[m]).max(1) <= 0.6 * dv + 1e-3).all()
     assert nok > 60 * n
     c.close()
+
+
+def test_local_ba_batch_properties_without_oracle(svs):
+    """48 full-size problems (10 keyframes, ~1200 landmarks, ~8000 edges) in one launch: a problem gives
+    bit-identical results wherever it sits in the batch, the same result (to rounding) when its edges
+    arrive in another order, a lower robust cost than it started with, and — without noise — the
+    reprojection error of the truth."""
+    rng = np.random.default_rng(77)
+    base = [cm.make_ba_problem(rng, 10, 1200) for _ in range(15)] + [cm.make_ba_problem(rng, 10, 1200, noise=0.0, outlier_frac=0.0)]
+    job = lambda p, perm=None: (p["poses0"], p["pts0"]) + tuple(p[k] if perm is None else p[k][perm] for k in ("okf", "olm", "ori", "ouv"))
+    jobs = [job(p) for p in base] + [job(p) for p in base[::-1]] + [job(p, rng.permutation(len(p["okf"]))) for p in base]
+    nobs = max(len(p["okf"]) for p in base)
+    c = svs.Context(cm.W, cm.H, max_slots=1, max_jobs=len(jobs), max_kf=10, max_lm=1200, max_obs=nobs)
+    res = c.local_ba(jobs, cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R)
+    huber = lambda chi2: np.where(chi2 <= 5.991 ** 2, chi2, 2 * 5.991 * np.sqrt(chi2) - 5.991 ** 2).sum()
+    for i, p in enumerate(base):
+        poses, pts, chi2, it = res[i]
+        poses_d, pts_d, chi2_d, it_d = res[2 * len(base) - 1 - i]
+        assert np.array_equal(poses, poses_d) and np.array_equal(pts, pts_d) and np.array_equal(chi2, chi2_d) and it == it_d
+        poses_s, pts_s, chi2_s, it_s = res[2 * len(base) + i]
+        assert it_s == it and np.allclose(poses_s, poses, atol=1e-9) and np.allclose(pts_s, pts, atol=1e-8)
+        # cost at the start: reprojection of the perturbed state (numpy), against the kernel's final edge chi2
+        start = 0.0
+        for cam_i, ext in enumerate((cm.EXT_L, cm.EXT_R)):
+            m = p["ori"] == cam_i
+            for k in range(10):
+                mk = m & (p["okf"] == k)
+                uv, _ = cm.project(cm.CAM, p["poses0"][k], ext, p["pts0"][p["olm"][mk]])
+                start += huber(((uv - p["ouv"][mk]) ** 2).sum(1))
+        # (5 % gross outliers at sigma 25 px keep a Huber floor of ~60 % of the initial cost)
+        assert huber(chi2) < 0.75 * start and np.median(chi2) < 1.0, (huber(chi2), start, np.median(chi2))
+    # the noise-free problem ends at (numerically) zero reprojection error: f32 pixel rounding only
+    assert res[len(base) - 1][2].max() < 1e-4 and np.median(res[len(base) - 1][2]) < 1e-7
+    c.close()
