@@ -8,10 +8,9 @@
 //
 // Kernels (all batched over jobs in grid.z / grid.y):
 //   k_gftt_mask   rasterise the 21x21 exclusion squares of the existing features
-//   k_gftt_eig    fused Sobel -> covariance -> 3x3 box -> min-eigenvalue tile
-//                 kernel (image tile + halo 2 staged in LDS, covariance tile +
-//                 halo 1 kept in LDS; the reference makes ~10 unfused passes),
-//                 plus the masked global maximum (wave reduce + 1 atomic/block)
+//   k_gftt_eig2   fused Sobel -> covariance -> 3x3 box -> min-eigenvalue on DPP wave
+//                 shifts + register windows (the reference makes ~10 unfused passes),
+//                 plus the masked global maximum (wave reduce + 1 atomic/wave)
 //   k_gftt_cand   threshold + 3x3 non-max suppression + mask -> compacted
 //                 64-bit keys (ordered value << 32 | pixel index)
 //   k_gftt_select one workgroup per job: bitonic sort of the keys (LDS, or
@@ -71,96 +70,6 @@ __global__ void k_gftt_mask(const GfttJob *jobs, GfttWork wk, const float2 *rect
     for (int i = threadIdx.x; i < rw * rh; i += blockDim.x) {
         int yy = i / rw, xx = i - yy * rw;
         m[(size_t)(y1 + yy) * w + x1 + xx] = 0;
-    }
-}
-
-#define GF_TW 32
-#define GF_TH 16
-#define GF_IW (GF_TW + 4)   // image tile with halo 2
-#define GF_IH (GF_TH + 4)
-#define GF_CW (GF_TW + 2)   // covariance tile with halo 1
-#define GF_CH (GF_TH + 2)
-
-__global__ void __launch_bounds__(256)
-k_gftt_eig(const GfttJob *jobs, const uint8_t *pyr, PyrGeom g, GfttWork wk)
-{
-    __shared__ uint8_t sImg[GF_IH][GF_IW + 4];
-    __shared__ float sXX[GF_CH][GF_CW + 1], sXY[GF_CH][GF_CW + 1], sYY[GF_CH][GF_CW + 1];
-    __shared__ unsigned int sMax[4];
-
-    const int job = blockIdx.z;
-    const GfttJob jb = jobs[job];
-    const int w = g.w[0], h = g.h[0], pitch = g.pitch[0];
-    const uint8_t *img = lvl_origin(pyr + (size_t)jb.slot * g.slot_bytes, g, 0);
-    const size_t P = (size_t)w * h;
-    float *eig = wk.eig + (size_t)job * P;
-    const uint8_t *mask = wk.mask + (size_t)job * ((P + 3) & ~(size_t)3);
-    const int x0 = blockIdx.x * GF_TW, y0 = blockIdx.y * GF_TH;
-    const int tid = threadIdx.x;
-
-    // image tile: coordinates x0-2 .. x0+TW+1 (stored border supplies REFLECT_101;
-    // clamp only guards the far side of partial tiles, whose values are unused)
-    for (int i = tid; i < GF_IH * GF_IW; i += 256) {
-        int r = i / GF_IW, c = i - r * GF_IW;
-        int gx = min(x0 - 2 + c, w + SVS_BORDER - 1), gy = min(y0 - 2 + r, h + SVS_BORDER - 1);
-        sImg[r][c] = img[(ptrdiff_t)gy * pitch + gx];
-    }
-    __syncthreads();
-
-    const float s1 = (float)(1.0 / 3060.0);
-    const float s2 = (float)(2.0 * (1.0 / 3060.0));
-    // covariance at positions x0-1 .. x0+TW (REFLECT_101 of the *covariance map*:
-    // evaluate the gradient at the reflected pixel)
-    for (int i = tid; i < GF_CH * GF_CW; i += 256) {
-        int r = i / GF_CW, c = i - r * GF_CW;
-        int gx = x0 - 1 + c, gy = y0 - 1 + r;
-        float xx = 0.f, xy = 0.f, yy = 0.f;
-        if (gx <= w && gy <= h) {
-            int rx = reflect101(gx, w), ry = reflect101(gy, h);
-            // centre in tile coordinates; neighbours are in range
-            int cx = rx - (x0 - 2), cy = ry - (y0 - 2);
-            float p00 = sImg[cy - 1][cx - 1], p01 = sImg[cy - 1][cx], p02 = sImg[cy - 1][cx + 1];
-            float p10 = sImg[cy][cx - 1], p12 = sImg[cy][cx + 1];
-            float p20 = sImg[cy + 1][cx - 1], p21 = sImg[cy + 1][cx], p22 = sImg[cy + 1][cx + 1];
-            float d0 = p02 - p00, d1 = p12 - p10, d2 = p22 - p20;
-            float dx = (d0 + d2) * s1 + d1 * s2;
-            float c0 = (s1 * p00 + s2 * p01) + s1 * p02;
-            float c2 = (s1 * p20 + s2 * p21) + s1 * p22;
-            float dy = c2 - c0;
-            xx = dx * dx; xy = dx * dy; yy = dy * dy;
-        }
-        sXX[r][c] = xx; sXY[r][c] = xy; sYY[r][c] = yy;
-    }
-    __syncthreads();
-
-    unsigned int best = 0; // ordered key, 0 = nothing
-    for (int i = tid; i < GF_TH * GF_TW; i += 256) {
-        int r = i / GF_TW, c = i - r * GF_TW;
-        int gx = x0 + c, gy = y0 + r;
-        if (gx >= w || gy >= h) continue;
-        double sxx = 0, sxy = 0, syy = 0;
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                sxx += (double)sXX[r + j][c + k];
-                sxy += (double)sXY[r + j][c + k];
-                syy += (double)sYY[r + j][c + k];
-            }
-        float a = (float)sxx * 0.5f, b = (float)sxy, cc = (float)syy * 0.5f;
-        float t = a - cc;
-        float e = (a + cc) - sqrtf(t * t + b * b);
-        size_t pi = (size_t)gy * w + gx;
-        eig[pi] = e;
-        if (mask[pi]) best = max(best, f32_ordered(e));
-    }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) best = max(best, (unsigned int)__shfl_xor((int)best, o, 64));
-    if ((tid & 63) == 0) sMax[tid >> 6] = best;
-    __syncthreads();
-    if (tid == 0) {
-        best = max(max(sMax[0], sMax[1]), max(sMax[2], sMax[3]));
-        if (best) atomicMax(&wk.counters[job * GF_CNT_STRIDE + 0], best);
     }
 }
 

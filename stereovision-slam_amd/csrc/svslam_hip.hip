@@ -594,12 +594,8 @@ static int launch_gftt(svslam_ctx *c, int njobs, const GfttJob *djobs, int max_n
     hipLaunchKernelGGL(k_gftt_init, dim3(32, njobs), dim3(256), 0, c->stream, c->gw, w, h, njobs);
     if (max_nrect > 0)
         hipLaunchKernelGGL(k_gftt_mask, dim3(max_nrect, njobs), dim3(256), 0, c->stream, djobs, c->gw, drects, w, h);
-    if (std::getenv("SVSLAM_GFTT_EIG_LDS"))      // the LDS-tile version, kept for A/B measurements
-        hipLaunchKernelGGL(k_gftt_eig, dim3(cdiv(w, GF_TW), cdiv(h, GF_TH), njobs), dim3(256), 0, c->stream, djobs,
-                           c->d_pyr, c->geom, c->gw);
-    else
-        hipLaunchKernelGGL(k_gftt_eig2, dim3(cdiv(w, GE_COLS), cdiv(h, GE_ROWS), njobs), dim3(64), 0, c->stream, djobs,
-                           c->d_pyr, c->geom, c->gw);
+    hipLaunchKernelGGL(k_gftt_eig2, dim3(cdiv(w, GE_COLS), cdiv(h, GE_ROWS), njobs), dim3(64), 0, c->stream, djobs,
+                       c->d_pyr, c->geom, c->gw);
     hipLaunchKernelGGL(k_gftt_cand, dim3(cdiv(w, 256), cdiv(h, 4), njobs), dim3(64, 4), 0, c->stream, c->gw, w, h,
                        quality);
     hipLaunchKernelGGL(k_gftt_select, dim3(njobs), dim3(GF_SEL_THREADS), GF_SEL_LDS_BYTES, c->stream, c->gw, w,
@@ -654,7 +650,8 @@ int svslam_gftt_eigmap(svslam_ctx *c, int slot, float *out)
     if (h2d(c, 0, c->ar.off)) return -1;
     const int w = c->geom.w[0], h = c->geom.h[0];
     hipLaunchKernelGGL(k_gftt_init, dim3(32, 1), dim3(256), 0, c->stream, c->gw, w, h, 1);
-    hipLaunchKernelGGL(k_gftt_eig, dim3(cdiv(w, GF_TW), cdiv(h, GF_TH), 1), dim3(256), 0, c->stream,
+    // the production kernel (the one launch_gftt runs), so the eig-map parity tests check what ships
+    hipLaunchKernelGGL(k_gftt_eig2, dim3(cdiv(w, GE_COLS), cdiv(h, GE_ROWS), 1), dim3(64), 0, c->stream,
                        dp<GfttJob>(c, ojobs), c->d_pyr, c->geom, c->gw);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -25,6 +25,7 @@ typedef struct svs_pipe_config {
                                   (svslam_rtrack_*); used when backend_on <= 1                      */
     int low_latency;          /* 1: latency shape of the serial kernels (svslam_set_low_latency), for a
                                   few streams per GPU                                                */
+    int max_pts;              /* features per frame the kernel provider holds per stream (0 = 512)   */
 } svs_pipe_config;
 
 typedef struct svs_frame_result {
@@ -37,6 +38,7 @@ typedef struct svs_pipe_counters {
     long long frames, keyframes, track_pts, pose_edges, gftt_calls, gftt_rects, corners, right_pts, tri_pts;
     long long ba_calls, ba_edges, ba_kf, ba_lm, ba_iters, pyr_left, pyr_right;
     long long ns_step, ns_kernel_calls;
+    long long corners_dropped, ba_skipped;   /* per-stream capacity events (max_pts / max_lm / max_obs) */
 } svs_pipe_counters;
 
 void *svs_pipe_create(const svs_pipe_config *cfg, int nstreams, int device);

@@ -33,6 +33,8 @@ svs::Config to_config(const svs_pipe_config &c)
     g.cam_l.pose = svs::SE3(c.ext_l); g.cam_r.pose = svs::SE3(c.ext_r);
     g.src_width = c.src_width; g.src_height = c.src_height;
     g.resident_track = c.resident_track;
+    g.max_pts = c.max_pts > 0 ? c.max_pts : 512;
+    g.max_kf = c.num_active_keyframes + 1; g.max_lm = c.max_lm; g.max_obs = c.max_obs;
     return g;
 }
 } // namespace
@@ -56,7 +58,7 @@ void *svs_pipe_create(const svs_pipe_config *cfg, int nstreams, int device)
         std::memset(&lim, 0, sizeof(lim));
         lim.device = device; lim.width = cfg->width; lim.height = cfg->height;
         lim.max_slots = 3 * nstreams; lim.max_jobs = 2 * nstreams; // one call may build left+right pyramids
-        lim.max_pts = 512; lim.max_corners = cfg->num_features;
+        lim.max_pts = cfg->max_pts > 0 ? cfg->max_pts : 512; lim.max_corners = cfg->num_features;
         lim.max_kf = cfg->num_active_keyframes + 1; lim.max_lm = cfg->max_lm; lim.max_obs = cfg->max_obs;
         lim.max_streams = (cfg->resident_track && cfg->backend_on <= 1) ? nstreams : 0;
         svslam_limits lim_front = lim;
@@ -158,6 +160,7 @@ int svs_pipe_counters_get(void *p, svs_pipe_counters *out)
     out->ba_kf = c.ba_kf; out->ba_lm = c.ba_lm; out->ba_iters = c.ba_iters; out->pyr_left = c.pyr_left;
     out->pyr_right = c.pyr_right;
     out->ns_step = c.ns_step; out->ns_kernel_calls = c.ns_kernel_calls;
+    out->corners_dropped = c.corners_dropped; out->ba_skipped = c.ba_skipped;
     return 0;
 }
 

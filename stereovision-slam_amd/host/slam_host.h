@@ -52,6 +52,13 @@ struct Config {                       // config/stereo_slam_configs/config-00.ya
     double chi2_th = 5.991;
     int width = 620, height = 188;
     Camera cam_l, cam_r;
+    // Capacities of the kernel provider per stream (0 = unlimited).  The reference has no such
+    // limits; a stream that would exceed one is handled on its own BEFORE any shared state is
+    // touched, so the other streams of the lockstep batch never notice: surplus new corners are
+    // not appended (max_pts), an over-sized local BA is skipped for this keyframe (max_kf /
+    // max_lm / max_obs) — the reference's own backend drops optimisation requests too (lossy
+    // notify).  Counters::corners_dropped / ba_skipped report how often.
+    int max_pts = 0, max_kf = 0, max_lm = 0, max_obs = 0;
 };
 
 enum class FrontendStatus { INITING = 0, TRACKING_GOOD = 1, TRACKING_BAD = 2, LOST = 3 };
@@ -191,9 +198,13 @@ public:
             if (dis < min_dis) { min_dis = dis; min_kf = kf; }
         }
         const double min_dis_th = 0.2;
-        // the reference indexes with the ids it found (default id 0 if nothing qualified)
+        // The reference indexes keyframes_ with the ids it found, default id 0 if nothing qualified
+        // (all distances 0, or NaN after a diverged pose): `.at(0)` on a frame that usually left the
+        // window long ago, which erases nothing and lets the window grow.  Here the window always
+        // shrinks: fall back to the oldest active keyframe that is not the current one.
         Frame *rm = (min_dis < min_dis_th) ? min_kf : max_kf;
-        if (!rm) rm = keyframes_.empty() ? nullptr : keyframes_[0];
+        if (!rm)
+            for (Frame *kf : active_keyframes_) if (kf != current_frame_) { rm = kf; break; }
         if (!rm) return;
         active_keyframes_.erase(std::remove(active_keyframes_.begin(), active_keyframes_.end(), rm), active_keyframes_.end());
         for (size_t i = 0; i < rm->left.size(); ++i)
@@ -249,6 +260,7 @@ struct Counters {                      // workload accounting for the roofline (
     long long ba_calls = 0, ba_edges = 0, ba_kf = 0, ba_lm = 0, ba_iters = 0;
     long long pyr_left = 0, pyr_right = 0;
     long long ns_step = 0, ns_kernel_calls = 0;   // wall time inside step() / inside the C-ABI calls
+    long long corners_dropped = 0, ba_skipped = 0; // per-stream capacity events (Config::max_*)
 };
 
 // BA job bookkeeping between gather and scatter (per stream, reused)
@@ -284,7 +296,7 @@ struct Stream {
     // scratch between stages (per stream: the stages run one thread per stream)
     std::vector<int> tri_idx;
     BaGather ba;
-    long long c_pose_edges = 0, c_keyframes = 0, c_corners = 0;   // merged into Counters after the step
+    long long c_pose_edges = 0, c_keyframes = 0, c_corners = 0, c_dropped = 0;   // merged into Counters after the step
 };
 
 // ------------------------------------------------------------------ the staged pipeline
@@ -404,7 +416,8 @@ public:
             st.last = st.current;
             st.last_owned = std::move(st.cur_owned);   // null if the frame moved into kf_store
             cnt_.pose_edges += st.c_pose_edges; cnt_.keyframes += st.c_keyframes; cnt_.corners += st.c_corners;
-            st.c_pose_edges = st.c_keyframes = st.c_corners = 0;
+            cnt_.corners_dropped += st.c_dropped;
+            st.c_pose_edges = st.c_keyframes = st.c_corners = st.c_dropped = 0;
         }
         st_[8] += now_ns() - t_e;
         cnt_.ns_step += now_ns() - t_step0;
@@ -713,13 +726,18 @@ private:
         t_h3 = now_ns();
         pool_.parallel_for(n, [&](int i) {
             Stream &st = *streams_[DS[i]];
-            for (int c = 0; c < ncorners_[i]; ++c) {
+            int take = ncorners_[i];
+            if (cfg_.max_pts > 0) {                                  // capacity of the kernel provider
+                const int room = std::max(0, cfg_.max_pts - (int)st.current->left.size());
+                if (take > room) { st.c_dropped += take - room; take = room; }
+            }
+            for (int c = 0; c < take; ++c) {
                 Feature f;
                 f.x = corners_[((size_t)i * cfg_.num_features + c) * 2];
                 f.y = corners_[((size_t)i * cfg_.num_features + c) * 2 + 1];
                 st.current->left.push_back(f);
             }
-            st.c_corners += ncorners_[i];
+            st.c_corners += take;
         });
         cnt_.gftt_calls += n; cnt_.gftt_rects += ofs;
         st_[3] += now_ns() - t_h3;
@@ -856,12 +874,12 @@ private:
     }
 
     // Backend::UpdateMap -> Optimize (src/backend.cpp:9-248): gather + enqueue ...
-    void BackendSubmit(const std::vector<int> &MS)
+    void BackendSubmit(const std::vector<int> &MS_all)
     {
         long long t_h6 = now_ns();
-        ba_ms_ = MS;
-        const int n = (int)MS.size();
-        jobs_ba_.resize(n);
+        ba_ms_ = MS_all;
+        std::vector<int> &MS = ba_ms_;
+        int n = (int)MS.size();
         // gather per stream (:39-160), in parallel, into the stream's own buffers
         pool_.parallel_for(n, [&](int i) {
             Stream &st = *streams_[MS[i]];
@@ -919,6 +937,21 @@ private:
             g.okf.resize(ne); g.olm.resize(ne); g.right.resize(ne); g.uv.resize(2 * ne); g.edge_feat.resize(ne);
             for (Frame *kf : g.kfs) kf->ba_local = -1;
         });
+        // a problem beyond the provider's capacity is dropped for this keyframe, alone
+        {
+            size_t keep = 0;
+            for (int i = 0; i < n; ++i) {
+                const BaGather &g = streams_[MS[i]]->ba;
+                const bool fits = (cfg_.max_kf <= 0 || (int)g.kfs.size() <= cfg_.max_kf) &&
+                                  (cfg_.max_lm <= 0 || (int)g.lms.size() <= cfg_.max_lm) &&
+                                  (cfg_.max_obs <= 0 || (int)g.edge_feat.size() <= cfg_.max_obs);
+                if (fits) MS[keep++] = MS[i]; else cnt_.ba_skipped++;
+            }
+            MS.resize(keep);
+            n = (int)keep;
+            if (n == 0) { st_[6] += now_ns() - t_h6; return; }
+        }
+        jobs_ba_.resize(n);
         int ko = 0, lo = 0, oo = 0;
         for (int i = 0; i < n; ++i) {
             BaGather &g = streams_[MS[i]]->ba;

@@ -2,10 +2,19 @@
 // per-stream host bookkeeping of the lockstep pipeline and for the per-problem BA
 // structure building inside the library.  Streams / problems are independent, so the
 // loop bodies never share mutable state.
+//
+// Every parallel_for publishes ONE immutable job object {fn, total, next, checked_in}
+// under the lock; a worker snapshots the shared_ptr together with the epoch, so an index
+// it draws can only ever be compared with, and run under, the job it was drawn from — a
+// worker that is still between its last fetch_add and the bounds test when the caller
+// starts the next loop holds the OLD job and simply finds it exhausted.  The caller returns
+// only after every item has finished (remaining == 0); the job object outlives the loop as
+// long as any straggler still holds it.
 #pragma once
 #include <atomic>
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <pthread.h>
 #include <thread>
@@ -35,31 +44,38 @@ public:
     {
         if (n <= 0) return;
         if (n_ == 1 || n == 1) { for (int i = 0; i < n; ++i) fn(i); return; }
+        std::shared_ptr<Job> job = std::make_shared<Job>(fn, n);
         {
             std::unique_lock<std::mutex> lk(m_);
-            fn_ = &fn; total_ = n; next_.store(0); pending_ = n; ++epoch_;
+            job_ = job; ++epoch_;
         }
         cv_.notify_all();
-        run_chunk();
+        run(*job);
         std::unique_lock<std::mutex> lk(m_);
-        done_cv_.wait(lk, [this] { return pending_ == 0; });
-        fn_ = nullptr;
+        done_cv_.wait(lk, [&] { return job->remaining.load(std::memory_order_acquire) == 0; });
+        if (job_ == job) job_.reset();      // stragglers keep their own reference
     }
 
 private:
-    void run_chunk()
+    struct Job {
+        Job(const std::function<void(int)> &f, int n) : fn(f), total(n), remaining(n) {}
+        const std::function<void(int)> fn;   // a copy: stays valid for stragglers of this epoch
+        const int total;
+        std::atomic<int> next{ 0 };
+        std::atomic<int> remaining;
+    };
+    void run(Job &j)
     {
         int done = 0;
         for (;;) {
-            int i = next_.fetch_add(1);
-            if (i >= total_) break;
-            (*fn_)(i);
+            const int i = j.next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= j.total) break;
+            j.fn(i);
             ++done;
         }
-        if (done) {
-            std::unique_lock<std::mutex> lk(m_);
-            pending_ -= done;
-            if (pending_ == 0) done_cv_.notify_all();
+        if (done && j.remaining.fetch_sub(done, std::memory_order_acq_rel) == done) {
+            std::unique_lock<std::mutex> lk(m_);   // pairs with the waiter's predicate check
+            done_cv_.notify_all();
         }
     }
     void worker()
@@ -67,22 +83,22 @@ private:
         (void)pthread_setname_np(pthread_self(), "svs-pool");
         unsigned long seen = 0;
         for (;;) {
+            std::shared_ptr<Job> job;
             {
                 std::unique_lock<std::mutex> lk(m_);
                 cv_.wait(lk, [&] { return stop_ || epoch_ != seen; });
                 if (stop_) return;
                 seen = epoch_;
+                job = job_;
             }
-            run_chunk();
+            if (job) run(*job);
         }
     }
     int n_;
     std::vector<std::thread> workers_;
     std::mutex m_;
     std::condition_variable cv_, done_cv_;
-    const std::function<void(int)> *fn_ = nullptr;
-    std::atomic<int> next_{ 0 };
-    int total_ = 0, pending_ = 0;
+    std::shared_ptr<Job> job_;
     unsigned long epoch_ = 0;
     bool stop_ = false;
 };
