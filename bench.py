@@ -28,7 +28,8 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 W, H = 620, 188                     # KITTI-00 1241x376 after the reference's 1/2 decimation (F3)
-HBM_PEAK_GBS = 8000.0               # spec (MI355X_MICROARCH.md); 6290 GB/s measured streaming
+HBM_PEAK_GBS = 8000.0               # spec (MI355X_MICROARCH.md)
+HBM_PEAK_MEASURED_GBS = 6290.0      # float4 copy on MI355X (MI355X_MICROARCH.md chip table); SURVEY 8d's denominator
 LEVEL_PIX = (620 * 188, 310 * 94, 155 * 47, 78 * 24)
 
 
@@ -115,7 +116,11 @@ def main():
                     help="1 (default): local BA completes before the next frame; 2: it runs beside the next "
                          "frame like the reference's backend thread and lands exactly one frame late "
                          "(measured: no throughput gain, the GPU is already saturated by the other streams)")
-    ap.add_argument("--cpu-frames", type=int, default=1500, help="bound of the CPU baseline sample")
+    ap.add_argument("--cpu-frames", type=int, default=1200, help="timed frames per CPU-baseline thread (after its pre-roll)")
+    ap.add_argument("--preroll", type=int, default=-1,
+                    help="untimed steps before the warm-up so that the timed region is the steady state (every stream's "
+                         "active window holds num_active_keyframes keyframes); -1 = automatic: blocks of warmup+steps "
+                         "frames until the local-BA problems of a block average a full window; 0 = none")
     ap.add_argument("--full-res", action="store_true",
                     help="keep the frames in HBM at the camera's 1241x376 and fuse the reference's 1/2 "
                          "decimation (Dataset::NextFrame) into the pyramid's level 0 (SURVEY 8 row f3); 4x the "
@@ -137,9 +142,12 @@ def main():
     svs.load()                                      # fails loudly if the HIP library is missing
 
     S, Wm, K = args.streams, args.warmup, args.steps
-    # the synthetic frames of the whole run are rendered into HBM up front: keep them under ~190 GB
+    # The synthetic frames live in HBM.  One buffer of FB = warmup + steps frames per stream is rendered
+    # block by block (pre-roll blocks first, then the block that holds the warm-up and the timed steps),
+    # always outside the timed region: keep it under ~190 GB.
     SW, SH = (1241, 376) if args.full_res else (W, H)     # stored frame size
-    cap = int(190e9 // (2 * SW * SH * (Wm + K)))
+    FB = Wm + K
+    cap = int(190e9 // (2 * SW * SH * FB))
     if S > cap:
         S = max(512, cap // 512 * 512) if cap >= 512 else max(1, cap)
     # host layout from the cores this rank may actually use (cgroup quota / ranks on the node):
@@ -155,7 +163,6 @@ def main():
     if args.host_threads <= 0:
         args.host_threads = max(1, min(4, (2 * cores + G - 1) // G))
     Sg = S // G
-    F = Wm + K
     cfg = pl.default_config(W, H, host_threads=max(1, args.host_threads), backend_on=args.backend_mode,
                             src_width=SW if args.full_res else 0, src_height=SH if args.full_res else 0,
                             low_latency=1 if args.low_latency else 0)
@@ -165,21 +172,18 @@ def main():
     if args.backend_mode == 2:       # the backend's own contexts (second HIP stream per pipeline)
         ctxs = ctxs + [svs.Context.borrow(p.backend_ctx(), W, H) for p in pipes]
 
-    # ---- render the synthetic streams straight into HBM: layout [stream][frame][H*W]
     img = SW * SH
     cam_r = tuple(2 * v for v in svs.KITTI00_HALF_CAM) if args.full_res else svs.KITTI00_HALF_CAM
-    d_left = ctx.dev_alloc(S * F * img)
-    d_right = ctx.dev_alloc(S * F * img)
+    d_left = ctx.dev_alloc(S * FB * img)
+    d_right = ctx.dev_alloc(S * FB * img)
     seeds = list(rk.stream_seeds(S))
     twin_of_0 = (S // G) * (G - 1) if G > 1 else (S - 1 if S > 1 else 0)   # first stream of the last group
     if twin_of_0 > 0:
         seeds[twin_of_0] = seeds[0]     # one deliberate duplicate: must come out bit-identical (checked below)
-    CH = 256
-    for s in range(S):
-        for f0 in range(0, F, CH):
-            vl, vr = zip(*[svs.synth_views(seeds[s], f, cam_r) for f in range(f0, min(F, f0 + CH))])
-            svs.synth_render_device(list(vl), SW, SH, d_left + (s * F + f0) * img, device=local_rank)
-            svs.synth_render_device(list(vr), SW, SH, d_right + (s * F + f0) * img, device=local_rank)
+
+    def render_block(frame0):
+        """frames [frame0, frame0 + FB) of every stream -> HBM, layout [stream][FB][img]"""
+        svs.synth_render_streams_device(seeds, frame0, FB, SW, SH, d_left, d_right, device=local_rank, cam=cam_r)
 
     def barrier():
         rk.barrier()
@@ -198,8 +202,8 @@ def main():
             try:
                 import ctypes
                 ctypes.CDLL(None).prctl(15, b"svs-group", 0, 0, 0)      # PR_SET_NAME, for the CPU breakdown
-                base = g * Sg * F * img
-                outs[g] = pipes[g].run_device(d_left + base, d_right + base, F * img, img, first, nframes,
+                base = g * Sg * FB * img
+                outs[g] = pipes[g].run_device(d_left + base, d_right + base, FB * img, img, first, nframes,
                                               want_results=want)
                 pipes[g].flush()     # a backend optimisation still in flight completes inside the timed region
             except Exception as e:   # noqa: BLE001
@@ -220,7 +224,28 @@ def main():
                 tot[k] = tot.get(k, 0) + v
         return tot
 
-    # ---- warmup (includes StereoInit of every stream), untimed
+    # ---- pre-roll (untimed): StereoInit of every stream, then frames until the sliding window of
+    #      local BA is full everywhere, so that the timed region is the steady-state workload whatever
+    #      --warmup / --steps are
+    pre = 0
+    window_full = cfg.num_active_keyframes
+    preroll_kf = 0.0
+    if args.preroll != 0:
+        while True:
+            n = FB if args.preroll < 0 else min(FB, args.preroll - pre)
+            if n <= 0:
+                break
+            cb = counters_sum()
+            render_block(pre)
+            run_all(0, n, False)
+            pre += n
+            ca = counters_sum()
+            calls = ca["ba_calls"] - cb["ba_calls"]
+            preroll_kf = (ca["ba_kf"] - cb["ba_kf"]) / max(calls, 1)
+            if args.preroll < 0 and (preroll_kf >= window_full - 0.05 or pre >= 400):
+                break
+    # ---- warmup, untimed
+    render_block(pre)
     run_all(0, Wm, False)
     c0 = counters_sum()
     for c in ctxs:
@@ -265,7 +290,7 @@ def main():
                                          np.array_equal(res["n_inliers"][:, 0], res["n_inliers"][:, twin_of_0])))
     ate = []
     for s_ in range(0, S, max(1, S // 16))[:16]:
-        gt = np.array([svs.synth_gt(seeds[s_], Wm + f) for f in range(K)])
+        gt = np.array([svs.synth_gt(seeds[s_], pre + Wm + f) for f in range(K)])
         ate.append(pl.ate_rmse(res["pose"][:, s_], gt))
     total_frames = S * K * world
     value = total_frames / elapsed
@@ -296,6 +321,7 @@ def main():
                                    "keyframes)" % ("completes before the next frame" if args.backend_mode == 1 else
                                                    "runs beside the next frame like the reference's backend thread, "
                                                    "lands one frame late, all of it inside the timed region"),
+                       "preroll_steps": pre, "preroll_last_block_ba_keyframes_mean": round(preroll_kf, 2),
                        "streams_per_gpu": S, "host_threads_per_gpu": G, "bookkeeping_threads_per_group": args.host_threads, "frame": "%dx%d u8 stereo pair" % (W, H) + (" decimated on the fly from %dx%d frames in HBM" % (SW, SH) if args.full_res else ""),
                        "keyframes_in_timed_region": cnt["keyframes"],
                        "ba_problem_mean": {"keyframes": round(cnt["ba_kf"] / max(cnt["ba_calls"], 1), 1),
@@ -310,6 +336,7 @@ def main():
                        "parallelism": "%d independent streams/GPU x %d GPU(s), no collective" % (S, world)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                         "peak_measured": HBM_PEAK_MEASURED_GBS, "frac_of_peak_measured": round(achieved / HBM_PEAK_MEASURED_GBS, 6),
                          "traffic": measured_traffic(dom, cnt, launches),
                          "avg_launch_us": round(avg_s * 1e6, 2), "launches": launches,
                          "algorithmic_bytes_per_launch": round(abytes / max(launches, 1), 1)},
@@ -329,44 +356,80 @@ def main():
                                  "pinned_to_gpu_numa_cpus": len(pinned),
                                  "minor_page_faults_per_step": round((ru1.ru_minflt - ru0.ru_minflt) / K, 1),
                                  "rss_growth_bytes_per_frame": round((rss1 - rss0) / max(S * K, 1), 1),
-                                 "cpus_busy_by_thread_name": cpu_by_thread},
+                                 "cpus_busy_by_thread_name": cpu_by_thread,
+                             "capacity_events": {"corners_dropped": cnt.get("corners_dropped", 0), "ba_skipped": cnt.get("ba_skipped", 0)}},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(svs, pl, ctx, cfg, d_left, F, img, S, min(args.cpu_frames, S * F),
-                                               d_right)
+            base = cpu_baseline(svs, pl, ctx, cfg, seeds, max(pre, 0), args.cpu_frames, local_rank, cam_r, (SW, SH),
+                                effective_cpus())
+            out["cpu_baseline"] = base["one_thread"]
+            out["cpu_baseline_all_cores"] = base["all_cores"]
         print(json.dumps(out), flush=True)
     for p in pipes:
         p.close()
     rk.close()
 
 
-def cpu_baseline(svs, pl, ctx, cfg, d_left, F, img, S, budget_frames, d_right):
-    sw, sh = (cfg.src_width, cfg.src_height) if cfg.src_width > 0 else (W, H)
-    cfg = pl.default_config(W, H, backend_on=cfg.backend_on, src_width=cfg.src_width, src_height=cfg.src_height)   # single-threaded twin, same modes
-    """The CPU twin (reference-shaped host logic over the oracle kernels, single thread) on a
-    bounded sample of the same workload: the first streams' frames, downloaded from HBM."""
+def cpu_baseline(svs, pl, ctx, cfg, seeds, preroll, timed_frames, device, cam_r, src, cores):
+    """The CPU twin (reference-shaped host logic over the oracle kernels: pyramids rebuilt per LK call,
+    numeric BA Jacobians like g2o) on a bounded sample of the same workload, at the same operating
+    point: every thread runs ONE stream through the same pre-roll (untimed) and then `timed_frames`
+    frames (timed).  Two legs: 1 thread, and one stream per usable core.  kind = "port": the real
+    OpenCV + g2o binary cannot be built on either box."""
+    import threading
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import pipe_cpu
-    nstreams = max(1, min(S, budget_frames // F))
-    twin = pipe_cpu.make(cfg, nstreams=1)
-    left = np.zeros((F, sh, sw), np.uint8); right = np.zeros((F, sh, sw), np.uint8)
-    total_t, total_f = 0.0, 0
-    for s in range(nstreams):
-        ctx.dev_download(d_left + s * F * img, left)
-        ctx.dev_download(d_right + s * F * img, right)
-        twin.close()
-        twin = pipe_cpu.make(cfg, nstreams=1)
+    sw, sh = src
+    cfg1 = pl.default_config(W, H, backend_on=cfg.backend_on, src_width=cfg.src_width, src_height=cfg.src_height)
+    F = preroll + timed_frames
+    nsrc = max(1, min(4, cores, len(seeds)))           # distinct streams, shared round-robin by the threads
+    img = sw * sh
+    dl = ctx.dev_alloc(nsrc * F * img); dr = ctx.dev_alloc(nsrc * F * img)
+    svs.synth_render_streams_device(seeds[:nsrc], 0, F, sw, sh, dl, dr, device=device, cam=cam_r, block=1024)
+    left = np.zeros((nsrc, F, sh, sw), np.uint8); right = np.zeros((nsrc, F, sh, sw), np.uint8)
+    ctx.dev_download(dl, left); ctx.dev_download(dr, right)
+    ctx.dev_free(dl); ctx.dev_free(dr)
+
+    def leg(nthreads):
+        bar = threading.Barrier(nthreads + 1)
+        errs = []
+
+        def work(t):
+            try:
+                twin = pipe_cpu.make(cfg1, nstreams=1)
+                L, R = left[t % nsrc], right[t % nsrc]
+                for f in range(preroll):
+                    twin.step([L[f]], [R[f]])
+                bar.wait()
+                for f in range(preroll, F):
+                    twin.step([L[f]], [R[f]])
+                twin.flush()
+                bar.wait()
+                twin.close()
+            except Exception as e:   # noqa: BLE001
+                errs.append(e)
+                bar.abort()
+        th = [threading.Thread(target=work, args=(t,)) for t in range(nthreads)]
+        for t_ in th:
+            t_.start()
+        bar.wait()
         t0 = time.perf_counter()
-        for f in range(F):
-            twin.step([left[f]], [right[f]])
-        twin.flush()
-        total_t += time.perf_counter() - t0
-        total_f += F
-    twin.close()
-    return {"value": round(total_f / total_t, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d stream(s) x %d frames of the same synthetic workload, CPU restatement "
-                      "(oracle kernels: pyramids rebuilt per LK call, numeric BA Jacobians like g2o), "
-                      "1 thread, %s" % (nstreams, F, cpu_model())}
+        bar.wait()
+        dt = time.perf_counter() - t0
+        for t_ in th:
+            t_.join()
+        if errs:
+            raise errs[0]
+        return nthreads * timed_frames / dt
+
+    what = ("%%d stream(s) x %d frames after a %d-frame untimed pre-roll (same synthetic workload and operating "
+            "point as the GPU run), CPU restatement (oracle kernels: pyramids rebuilt per LK call, numeric BA "
+            "Jacobians like g2o), %%d thread(s), %s" % (timed_frames, preroll, cpu_model()))
+    v1 = leg(1)
+    vn = leg(cores) if cores > 1 else v1
+    return {"one_thread": {"value": round(v1, 2), "unit": "frames/s", "cores": 1, "kind": "port", "sample": what % (1, 1)},
+            "all_cores": {"value": round(vn, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+                          "sample": what % (cores, cores) + "; one stream per thread"}}
 
 
 def cpu_model():

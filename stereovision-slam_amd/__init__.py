@@ -466,6 +466,25 @@ def synth_views(seed, frame, cam=KITTI00_HALF_CAM, baseline=KITTI00_BASELINE):
     return vl, vr
 
 
+def synth_render_streams_device(seeds, frame0, nframes, w, h, d_left, d_right, device=0, cam=KITTI00_HALF_CAM,
+                                baseline=KITTI00_BASELINE, block=4096):
+    """render frames [frame0, frame0 + nframes) of every stream in `seeds` into the device buffers
+    d_left / d_right, laid out [stream][nframes][h*w]; a few launches per `block` images."""
+    n = len(seeds)
+    per = max(1, block // max(nframes, 1))            # streams per launch
+    camv = (C.c_double * 4)(*cam)
+    img = w * h
+    for s0 in range(0, n, per):
+        m = min(per, n - s0)
+        sd = (C.c_uint32 * m)(*[int(x) & 0xFFFFFFFF for x in seeds[s0:s0 + m]])
+        vl = (SynthView * (m * nframes))(); vr = (SynthView * (m * nframes))()
+        synth_lib().svs_synth_make_views_batch(m, sd, frame0, nframes, camv, C.c_double(baseline), vl, vr)
+        for arr, base in ((vl, d_left), (vr, d_right)):
+            rc = load().svslam_synth_render_batch(device, m * nframes, arr, w, h, C.c_void_p(base + s0 * nframes * img))
+            if rc != 0:
+                raise RuntimeError("svslam_synth_render_batch failed (%d)" % rc)
+
+
 def synth_render_device(views, w, h, d_out, device=0):
     """render len(views) images into the device buffer d_out (tight w*h each)."""
     n = len(views)

@@ -28,3 +28,12 @@ void svs_synth_make_views(uint32_t seed, int frame, const double cam[4], double 
 {
     svs_synth_views(seed, frame, cam, baseline, vl, vr);
 }
+
+/* views of nframes consecutive frames of n streams, laid out [stream][frame] (bench input) */
+void svs_synth_make_views_batch(int n, const uint32_t *seeds, int frame0, int nframes, const double cam[4],
+                                double baseline, svs_synth_view *vl, svs_synth_view *vr)
+{
+    for (int s = 0; s < n; ++s)
+        for (int f = 0; f < nframes; ++f)
+            svs_synth_views(seeds[s], frame0 + f, cam, baseline, vl + (size_t)s * nframes + f, vr + (size_t)s * nframes + f);
+}

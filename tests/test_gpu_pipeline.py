@@ -237,3 +237,9 @@ def test_bench_contract_small_run():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "frames/s" and c["sample"]
     assert "workload" in d["config"] and d["config"]["checks"]["duplicate_stream_bit_identical"] is True
+    # the timed region is the steady state whatever --warmup / --steps are: the pre-roll ran until the
+    # sliding window of local BA was full
+    assert d["config"]["preroll_steps"] >= 60 and d["config"]["ba_problem_mean"]["keyframes"] >= 9.5
+    assert r["peak_measured"] == 6290.0
+    a = d["cpu_baseline_all_cores"]
+    assert a["kind"] == "port" and a["cores"] >= 1 and a["value"] >= 0.8 * c["value"]
