@@ -558,6 +558,21 @@ static void ba_jac_numeric(const ba_cams *c, int cam, const double T[7],
     }
 }
 
+/* test hooks: the Jacobians as the oracle evaluates them, for the symbolic (sympy) pin in
+ * tests/test_oracle_pins.py.  mode 0 analytic, 1 numeric (g2o's central differences). */
+void orc_ba_jacobian(const double cam[4], const double ext[7], const double T[7], const double P[3],
+                     const float uv[2], int mode, double Jp[12], double Jl[6])
+{
+    ba_cams c;
+    c.cam[0] = c.cam[1] = cam; c.ext[0] = c.ext[1] = ext;
+    if (mode == 0) ba_jac_analytic(&c, 0, T, P, Jp, Jl);
+    else ba_jac_numeric(&c, 0, T, P, uv, Jp, Jl);
+}
+void orc_po_jacobian(const double cam[4], const double T[7], const double P[3], double J[12])
+{
+    po_jacobian(cam, T, P, J);
+}
+
 static void inv3(const double A[9], double Ai[9])
 {
     double c0 = A[4] * A[8] - A[5] * A[7];

@@ -112,6 +112,12 @@ int orc_local_ba(const double cam_l[4], const double ext_l[7],
                  double huber_delta, int iters, int jac_mode,
                  double *edge_chi2);
 
+/* test hooks: Jacobians of EdgeProjection (mode 0 analytic, 1 numeric) and of
+ * EdgeProjectionPoseOnly::linearizeOplus as the oracle evaluates them */
+void orc_ba_jacobian(const double cam[4], const double ext[7], const double T[7], const double P[3],
+                     const float uv[2], int mode, double Jp[12], double Jl[6]);
+void orc_po_jacobian(const double cam[4], const double T[7], const double P[3], double J[12]);
+
 #ifdef __cplusplus
 }
 #endif
