@@ -17,3 +17,10 @@ def twin_lib():
 def make(cfg=None, nstreams=1):
     pl = importlib.import_module("stereovision-slam_amd.pipeline")
     return pl.Pipeline(cfg, nstreams, lib=twin_lib())
+
+
+def make_hybrid(cfg=None, nstreams=1):
+    """BASELINE config 2: HIP frontend + CPU (oracle, g2o-shaped) local BA; test infrastructure"""
+    oracle_lib.build()
+    pl = importlib.import_module("stereovision-slam_amd.pipeline")
+    return pl.Pipeline(cfg, nstreams, lib=C.CDLL(os.path.join(oracle_lib.ORC_DIR, "_build", "libsvs_pipeline_hybrid.so")))

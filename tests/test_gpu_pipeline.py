@@ -122,7 +122,7 @@ def test_pipeline_full_resolution_input(svs):
     a.close(); b.close()
 
 
-def test_pipeline_frontend_only_matches_cpu_twin(svs):
+def test_pipeline_backend_off_frontend_only_matches_cpu_twin(svs):
     """BASELINE config 2: HIP frontend with the backend switched off (backend_on = 0, config-00.yaml's
     key).  Per call the kernels are bit-exact (LK, GFTT) or agree to rounding (pose LM), but LK's
     stopping rule makes a frame's output discontinuous in its f32 initial guesses, so a 1e-13 pose
@@ -243,3 +243,31 @@ def test_bench_contract_small_run():
     assert r["peak_measured"] == 6290.0
     a = d["cpu_baseline_all_cores"]
     assert a["kind"] == "port" and a["cores"] >= 1 and a["value"] >= 0.8 * c["value"]
+
+
+def test_pipeline_config2_hip_frontend_with_cpu_backend(svs):
+    """BASELINE config 2 as written: HIP GFTT + LK (+ triangulation, pose-only) frontend with the
+    backend still on the CPU (the oracle's g2o-shaped BA, numeric Jacobians).  Against the full CPU
+    twin the only difference left is the frontend, whose integer stages are bit-exact: metadata must
+    agree for the first frames and the trajectories stay within the LK noise floor."""
+    import pipe_cpu
+    pl = importlib.import_module("stereovision-slam_amd.pipeline")
+    os.environ.pop("SVS_ORACLE_BA_JAC", None)
+    seeds, N = [31, 32], 40
+    hyb = pipe_cpu.make_hybrid(nstreams=len(seeds))
+    cpu = pipe_cpu.make(nstreams=len(seeds))
+    assert hyb.kernel_ctx()                       # really the HIP provider
+    eh, mh = _run(hyb, svs, seeds, N)
+    ec, mc = _run(cpu, svs, seeds, N)
+    keys = ("status", "is_keyframe", "n_features", "n_inliers", "keyframe_id")
+    for f in range(10):
+        for k in keys:
+            assert np.array_equal(mh[f][k], mc[f][k]), (f, k, mh[f][k], mc[f][k])
+    assert np.allclose(eh[:10, :, 4:], ec[:10, :, 4:], atol=5e-4), np.abs(eh[:10] - ec[:10]).max()
+    assert np.allclose(eh[..., 4:], ec[..., 4:], atol=5e-2), np.abs(eh - ec).max()
+    ch, cc = hyb.counters(), cpu.counters()
+    assert ch["ba_calls"] == ch["keyframes"] and abs(ch["keyframes"] - cc["keyframes"]) <= 1
+    for k, sd in enumerate(seeds):
+        gt = np.array([svs.synth_gt(sd, f) for f in range(N)])
+        assert abs(pl.ate_rmse(eh[:, k], gt) - pl.ate_rmse(ec[:, k], gt)) < 1e-2
+    hyb.close(); cpu.close()
