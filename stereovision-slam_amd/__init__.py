@@ -28,6 +28,7 @@ ABI_SYMBOLS = [
 ]
 
 FAMILIES = {"pyramid": 0, "lk": 1, "gftt": 2, "triangulate": 3, "pose_only": 4, "local_ba": 5}
+DEBUG_FAMILIES = {"dbg0": 6, "dbg1": 7, "dbg2": 8, "dbg3": 9}     # per-kernel split (SVSLAM_TIMING_SPLIT=1), development
 
 
 class Limits(C.Structure):
@@ -197,7 +198,8 @@ class Context:
 
     def timing_get(self, family):
         ms, n, u = C.c_double(), C.c_longlong(), C.c_longlong()
-        self._chk(self.L.svslam_timing_get(self.h, FAMILIES[family], C.byref(ms), C.byref(n), C.byref(u)), "timing")
+        fam = FAMILIES[family] if family in FAMILIES else DEBUG_FAMILIES[family]
+        self._chk(self.L.svslam_timing_get(self.h, fam, C.byref(ms), C.byref(n), C.byref(u)), "timing")
         return ms.value, n.value, u.value
 
     def ba_profile(self, enable=True, read=False):

@@ -30,7 +30,7 @@
 
 namespace {
 
-enum { FAM_PYR = 0, FAM_LK, FAM_GFTT, FAM_TRI, FAM_POSE, FAM_BA, FAM_COUNT };
+enum { FAM_PYR = 0, FAM_LK, FAM_GFTT, FAM_TRI, FAM_POSE, FAM_BA, FAM_DBG0, FAM_DBG1, FAM_DBG2, FAM_DBG3, FAM_COUNT };
 
 struct Timing {
     double ms[FAM_COUNT] = { 0 };
@@ -76,6 +76,7 @@ struct svslam_ctx {
     long long host_ns[8] = { 0 };
     bool wait_poll = true;
     bool low_latency = false;   // svslam_set_low_latency: 4-wave pose-only blocks
+    bool timing_split = false;  // SVSLAM_TIMING_SPLIT: per-kernel events of the multi-kernel families (families 6..9)
     int src_w = 0, src_h = 0;     // > 0: level 0 is the 2:1 decimation of src_w x src_h inputs
     // resident feature lists (svslam_rtrack_*): two alternating buffers per stream
     RtStore rt = {};
@@ -371,6 +372,7 @@ int svslam_create(const svslam_limits *lim, svslam_ctx **out)
     {
         const char *wm = std::getenv("SVSLAM_WAIT");        // spin | poll (default)
         c->wait_poll = !(wm && std::strcmp(wm, "spin") == 0);
+        c->timing_split = std::getenv("SVSLAM_TIMING_SPLIT") != nullptr;
     }
     HIPCHK(c, pool_stream(c->device, &c->stream));
     HIPCHK(c, hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
@@ -394,12 +396,14 @@ int svslam_create(const svslam_limits *lim, svslam_ctx **out)
     int cap = 1;
     while ((size_t)cap < P) cap <<= 1;
     c->gw.cap = cap;
-    HIPCHK(c, hipMalloc(&c->gw.eig, sizeof(float) * P * J));
-    HIPCHK(c, hipMalloc(&c->gw.mask, ((P + 3) & ~(size_t)3) * J));
     HIPCHK(c, hipMalloc(&c->gw.keys, sizeof(unsigned long long) * (size_t)cap * J));
     HIPCHK(c, hipMalloc(&c->gw.counters, sizeof(unsigned int) * GF_CNT_STRIDE * J));
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_gftt_select),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, GF_SEL_LDS_BYTES));
+    HIPCHK(c, hipMemsetAsync(c->gw.counters, 0, sizeof(unsigned int) * GF_CNT_STRIDE * J, c->stream));   // kept zero by k_gftt_select2
+    c->gw.prof = nullptr;
+    if (std::getenv("SVSLAM_GFTT_PROF")) {
+        HIPCHK(c, hipMalloc(&c->gw.prof, sizeof(long long) * 16));
+        HIPCHK(c, hipMemsetAsync(c->gw.prof, 0, sizeof(long long) * 16, c->stream));
+    }
     // BA scratch
     if (lim->max_kf > 0) {
         if (6 * lim->max_kf > BA_MAX_NP) return fail(c, "max_kf %d too large (<= %d)", lim->max_kf, BA_MAX_NP / 6);
@@ -435,7 +439,15 @@ void svslam_destroy(svslam_ctx *c)
     if (c->ar.h) (void)hipHostFree(c->ar.h);
     (void)hipFree(c->d_img);
     if (c->h_img) (void)(void)hipHostFree(c->h_img);
-    (void)hipFree(c->gw.eig); (void)hipFree(c->gw.mask); (void)hipFree(c->gw.keys); (void)hipFree(c->gw.counters);
+    if (c->gw.prof) {
+        long long p[16] = { 0 };
+        (void)hipMemcpy(p, c->gw.prof, sizeof(p), hipMemcpyDeviceToHost);
+        const double k = p[7] ? 0.01 / (double)p[7] : 0.0;      // 100 MHz ticks -> us per call
+        fprintf(stderr, "[gftt select2, job 0, %lld calls] us/call: clear %.1f hist %.1f scan %.1f gather %.1f sort %.1f greedy %.1f | candidates %.0f, sorted %.0f\n",
+                p[7], k * p[8], k * p[0], k * p[1], k * p[2], k * p[3], k * p[4], p[7] ? (double)p[5] / p[7] : 0.0, p[7] ? (double)p[6] / p[7] : 0.0);
+        (void)hipFree(c->gw.prof);
+    }
+    (void)hipFree(c->gw.keys); (void)hipFree(c->gw.counters);
     ba_work_free(c->bw);
     if (c->d_ba_prof) (void)hipFree(c->d_ba_prof);
     for (int i = 0; i < 16; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -586,20 +598,16 @@ int svslam_lk_batch(svslam_ctx *c, int njobs, const svslam_lk_job *jobs, int tot
 }
 
 // ------------------------------------------------------------------ GFTT
-static int launch_gftt(svslam_ctx *c, int njobs, const GfttJob *djobs, int max_nrect, const float2 *drects,
+static int launch_gftt(svslam_ctx *c, int njobs, const GfttJob *djobs, const float2 *drects,
                        int max_corners, double quality, double min_dist, float2 *dout, int *dn)
 {
     const int w = c->geom.w[0], h = c->geom.h[0];
-    tm_begin(c, FAM_GFTT, njobs);
-    hipLaunchKernelGGL(k_gftt_init, dim3(32, njobs), dim3(256), 0, c->stream, c->gw, w, h, njobs);
-    if (max_nrect > 0)
-        hipLaunchKernelGGL(k_gftt_mask, dim3(max_nrect, njobs), dim3(256), 0, c->stream, djobs, c->gw, drects, w, h);
-    hipLaunchKernelGGL(k_gftt_eig2, dim3(cdiv(w, GE_COLS), cdiv(h, GE_ROWS), njobs), dim3(64), 0, c->stream, djobs,
-                       c->d_pyr, c->geom, c->gw);
-    hipLaunchKernelGGL(k_gftt_cand, dim3(cdiv(w, 256), cdiv(h, 4), njobs), dim3(64, 4), 0, c->stream, c->gw, w, h,
-                       quality);
-    hipLaunchKernelGGL(k_gftt_select, dim3(njobs), dim3(GF_SEL_THREADS), GF_SEL_LDS_BYTES, c->stream, c->gw, w,
-                       max_corners, min_dist, dout, dn, max_corners);
+    tm_begin(c, c->timing_split ? FAM_DBG0 : FAM_GFTT, njobs);
+    hipLaunchKernelGGL(k_gftt_eig3<false>, dim3(cdiv(w, GE_COLS), cdiv(h, GE_ROWS), njobs), dim3(64), 0, c->stream, djobs,
+                       c->d_pyr, c->geom, c->gw, drects, quality, (float *)nullptr);
+    if (c->timing_split) { tm_end(c); tm_begin(c, FAM_DBG1, njobs); }
+    hipLaunchKernelGGL(k_gftt_select2, dim3(njobs), dim3(GS_THREADS), 0, c->stream, c->gw, w, h, max_corners, quality,
+                       min_dist, dout, dn, max_corners);
     tm_end(c);
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -613,12 +621,10 @@ int svslam_gftt_batch(svslam_ctx *c, int njobs, const svslam_gftt_job *jobs, int
     if (njobs > c->lim.max_jobs) return fail(c, "gftt: %d jobs > max_jobs", njobs);
     if (max_corners < 1 || max_corners > c->lim.max_corners) return fail(c, "gftt: max_corners %d out of [1,%d]", max_corners, c->lim.max_corners);
     if (total_rects > c->lim.max_jobs * c->lim.max_pts) return fail(c, "gftt: too many mask rects");
-    int max_nrect = 0;
     for (int i = 0; i < njobs; ++i) {
         if (check_slot(c, jobs[i].slot)) return -1;
         if (jobs[i].nrect < 0 || jobs[i].rect_ofs < 0 || jobs[i].rect_ofs + jobs[i].nrect > total_rects)
             return fail(c, "gftt: job %d rect range out of bounds", i);
-        max_nrect = std::max(max_nrect, jobs[i].nrect);
     }
     if (c->ba_pending.active) return fail(c, "a submitted local-BA batch owns this context: call svslam_local_ba_collect first");
     c->ar.reset();
@@ -631,7 +637,7 @@ int svslam_gftt_batch(svslam_ctx *c, int njobs, const svslam_gftt_job *jobs, int
     memcpy(hp<void>(c, ojobs), jobs, sizeof(GfttJob) * njobs);
     if (total_rects > 0) memcpy(hp<void>(c, orect), rect_xy, sizeof(float) * 2 * total_rects);
     if (h2d(c, 0, in_end)) return -1;
-    if (launch_gftt(c, njobs, dp<GfttJob>(c, ojobs), max_nrect, dp<float2>(c, orect), max_corners, quality,
+    if (launch_gftt(c, njobs, dp<GfttJob>(c, ojobs), dp<float2>(c, orect), max_corners, quality,
                     min_dist, dp<float2>(c, oout), dp<int>(c, on))) return -1;
     if (d2h_sync(c, oout, c->ar.off)) return -1;
     memcpy(out_n, hp<void>(c, on), sizeof(int) * njobs);
@@ -649,13 +655,18 @@ int svslam_gftt_eigmap(svslam_ctx *c, int slot, float *out)
     j->slot = slot; j->rect_ofs = 0; j->nrect = 0;
     if (h2d(c, 0, c->ar.off)) return -1;
     const int w = c->geom.w[0], h = c->geom.h[0];
-    hipLaunchKernelGGL(k_gftt_init, dim3(32, 1), dim3(256), 0, c->stream, c->gw, w, h, 1);
-    // the production kernel (the one launch_gftt runs), so the eig-map parity tests check what ships
-    hipLaunchKernelGGL(k_gftt_eig2, dim3(cdiv(w, GE_COLS), cdiv(h, GE_ROWS), 1), dim3(64), 0, c->stream,
-                       dp<GfttJob>(c, ojobs), c->d_pyr, c->geom, c->gw);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(out, c->gw.eig, sizeof(float) * (size_t)w * h, hipMemcpyDeviceToHost));
+    float *d_eig = nullptr;
+    HIPCHK(c, hipMalloc(&d_eig, sizeof(float) * (size_t)w * h));
+    // the production kernel with its eigenvalue store compiled in (the product instantiation differs by
+    // exactly that store), so the eig-map parity tests check what ships
+    hipLaunchKernelGGL(k_gftt_eig3<true>, dim3(cdiv(w, GE_COLS), cdiv(h, GE_ROWS), 1), dim3(64), 0, c->stream,
+                       dp<GfttJob>(c, ojobs), c->d_pyr, c->geom, c->gw, (const float2 *)nullptr, 0.01, d_eig);
+    hipError_t e1 = hipGetLastError();
+    hipError_t e2 = hipMemsetAsync(c->gw.counters, 0, sizeof(unsigned int) * GF_CNT_STRIDE, c->stream);   // job 0's counters back to zero
+    hipError_t e3 = hipStreamSynchronize(c->stream);
+    hipError_t e4 = hipMemcpy(out, d_eig, sizeof(float) * (size_t)w * h, hipMemcpyDeviceToHost);
+    (void)hipFree(d_eig);
+    HIPCHK(c, e1); HIPCHK(c, e2); HIPCHK(c, e3); HIPCHK(c, e4);
     return 0;
 }
 

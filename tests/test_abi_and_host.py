@@ -25,7 +25,7 @@ def test_abi_exports_every_declared_symbol(svs):
     assert b"gfx950" in L.svslam_build_info()
     # the kernels are really in there (device code object for gfx950)
     out = subprocess.run(["strings", "-a", svs.lib_path()], capture_output=True, text=True).stdout
-    for k in ("k_lk", "k_gftt_eig", "k_pyr_down", "k_pose_only", "k_local_ba", "k_triangulate"):
+    for k in ("k_lk", "k_gftt_eig3", "k_gftt_select2", "k_pyr_down", "k_pose_only", "k_local_ba", "k_triangulate"):
         assert k in out, k
     assert "gfx950" in out
 

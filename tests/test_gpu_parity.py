@@ -366,3 +366,37 @@ def test_track_fused_matches_separate_calls(ctx, orc, frames):
     assert r["n_inlier"] == ninl_ref
     assert np.allclose(r["pose"], T_ref, atol=1e-6)
     assert np.array_equal(r["outlier"][e], outl_ref)
+
+
+def test_gftt_selection_paths(svs, orc):
+    """the top-K selection of k_gftt_select2 on the inputs that exercise each of its paths: several
+    slices (thousands of candidates above the threshold, small min-distance, many corners wanted),
+    the equal-value fallback (a lattice of identical corners: one histogram bin holds everything),
+    no min-distance at all, and counters that must be clean again on the next call"""
+    rng = np.random.default_rng(17)
+    w, h = 620, 188
+    noise = rng.integers(0, 256, (h, w), dtype=np.uint8)                  # ~10^4 local maxima, flat value spectrum
+    lattice = np.zeros((h, w), np.uint8)
+    lattice[(np.arange(h)[:, None] // 6 + np.arange(w)[None] // 6) % 2 == 0] = 200   # identical corners everywhere
+    blobs = np.zeros((h, w), np.uint8)
+    for k in range(40):
+        y, x = rng.integers(8, h - 8), rng.integers(8, w - 8)
+        blobs[y - 3:y + 3, x - 3:x + 3] = 40 + 5 * k
+    c = svs.Context(w, h, max_slots=3, max_jobs=6, max_corners=1024, max_pts=512, max_kf=0, max_lm=0, max_obs=0)
+    imgs = [noise, lattice, blobs]
+    c.pyramid([0, 1, 2], imgs)
+    rect = np.stack([rng.uniform(-5, w + 5, 300), rng.uniform(-5, h + 5, 300)], 1).astype(np.float32)
+    for rep in range(2):
+        for (mc, q, md) in ((1024, 0.0001, 2.0), (1024, 0.01, 0.0), (150, 0.01, 20.0), (1000, 0.5, 1.0)):
+            jobs = [(0, None), (1, None), (2, None), (0, rect), (1, rect[:64]), (2, rect[:1])]
+            got = c.gftt(jobs, max_corners=mc, quality=q, min_dist=md)
+            for (slot, r), g in zip(jobs, got):
+                ref = orc.gftt(imgs[slot], r, mc, q, md)
+                assert g.shape == ref.shape, (rep, mc, q, md, slot, g.shape, ref.shape)
+                assert np.array_equal(g, ref), (rep, mc, q, md, slot)
+    # the eig-map hook runs the production kernel and leaves the counters clean as well
+    e = c.gftt_eigmap(0)
+    assert np.array_equal(e.view(np.uint32), orc.min_eig_map(noise).view(np.uint32))
+    (g,) = c.gftt([(0, None)], max_corners=150)
+    assert np.array_equal(g, orc.gftt(noise))
+    c.close()

@@ -90,6 +90,35 @@ def lkbench(nj=512, npts=150):
     c.close()
 
 
+def gfttbench(nj=512):
+    """GFTT and pyramid throughput at bench scale: nj images per launch, no mask / 80 / 230 mask squares"""
+    l0, r0 = svs.synth_pair(3, 0)
+    import oracle_lib as orc
+    pts = orc.gftt(l0, max_corners=230, min_dist=8.0)
+    c = svs.Context(cm.W, cm.H, max_slots=nj, max_jobs=nj, max_pts=256, max_kf=0, max_lm=0, max_obs=0)
+    c.pyramid(list(range(nj)), [l0 if i % 2 == 0 else r0 for i in range(nj)])
+    for nr in (0, 80, 230):
+        jobs = [(i, pts[:nr] if nr else None) for i in range(nj)]
+        out = c.gftt(jobs)
+        c.timing(True)
+        for r in range(5):
+            out = c.gftt(jobs)
+        t = c.timing_get("gftt")
+        if t[1] == 0:       # SVSLAM_TIMING_SPLIT=1: eig3 / select2 separately
+            a, b = c.timing_get("dbg0"), c.timing_get("dbg1")
+            print("gftt jobs=%d rects=%3d: eig3 %.1f us + select2 %.1f us per launch" % (nj, nr, 1e3 * a[0] / max(a[1], 1), 1e3 * b[0] / max(b[1], 1)))
+            continue
+        print("gftt jobs=%d rects=%3d: %.1f us/launch (%.3f us/image), corners %.1f" %
+              (nj, nr, 1e3 * t[0] / max(t[1], 1), 1e3 * t[0] / max(t[1], 1) / nj, np.mean([len(o) for o in out])))
+        c.timing(False)
+    c.timing(True)
+    for r in range(5):
+        c.pyramid(list(range(nj)), [l0] * nj)
+    t = c.timing_get("pyramid")
+    print("pyramid jobs=%d (host images, upload not timed): %.1f us/launch (%.3f us/image)" % (nj, 1e3 * t[0] / max(t[1], 1), 1e3 * t[0] / max(t[1], 1) / nj))
+    c.close()
+
+
 def clock():
     import ctypes as C
     c = svs.Context(cm.W, cm.H, max_slots=1, max_jobs=1, max_kf=0, max_lm=0, max_obs=0)
@@ -104,6 +133,8 @@ if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what == "lk":
         lkbench(); sys.exit(0)
+    if what == "gftt":
+        gfttbench(); sys.exit(0)
     if what == "tput":       # chip-time per family at bench scale
         for nj in (1, 64, 256, 512):
             ba(nj, 0, 0, reps=2)
