@@ -89,6 +89,10 @@ int svslam_set_low_latency(svslam_ctx *ctx, int on);
 int svslam_pyramid_read(svslam_ctx *ctx, int slot, int level, uint8_t *out,
                         int *w, int *h);
 
+/* test hook: the level with its stored 16-pixel BORDER_REFLECT_101 continuation (what LK windows, pyrDown taps
+ * and the GFTT stencils read without index arithmetic): (h + 32) tight rows of (w + 32) bytes */
+int svslam_pyramid_read_padded(svslam_ctx *ctx, int slot, int level, uint8_t *out);
+
 /* ---- pyramidal LK -----------------------------------------------------
  * Replaces cv::calcOpticalFlowPyrLK(prev, next, prevPts, nextPts, status, err,
  * Size(11,11), 3, TermCriteria(COUNT+EPS,30,0.01), OPTFLOW_USE_INITIAL_FLOW)

@@ -19,7 +19,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 ABI_SYMBOLS = [
     "svslam_create", "svslam_destroy", "svslam_last_error", "svslam_build_info",
     "svslam_pyramid_batch", "svslam_pyramid_decimate_batch", "svslam_set_source_size", "svslam_set_low_latency", "svslam_pyramid_read",
-    "svslam_lk_batch", "svslam_gftt_batch", "svslam_gftt_eigmap", "svslam_triangulate_batch",
+    "svslam_pyramid_read_padded", "svslam_lk_batch", "svslam_gftt_batch", "svslam_gftt_eigmap", "svslam_triangulate_batch",
     "svslam_pose_only_batch", "svslam_local_ba_batch", "svslam_local_ba_submit", "svslam_local_ba_collect",
     "svslam_track_batch", "svslam_rtrack_batch", "svslam_rtrack_upload",
     "svslam_dev_alloc", "svslam_dev_free", "svslam_dev_upload", "svslam_dev_download", "svslam_sync",
@@ -231,6 +231,14 @@ class Context:
         self._chk(self.L.svslam_pyramid_read(self.h, slot, level, None, C.byref(w), C.byref(h)), "pyramid_read")
         out = np.zeros((h.value, w.value), np.uint8)
         self._chk(self.L.svslam_pyramid_read(self.h, slot, level, _p(out), C.byref(w), C.byref(h)), "pyramid_read")
+        return out
+
+    def pyramid_read_padded(self, slot, level):
+        """the level with its stored 16-px REFLECT_101 border"""
+        w, h = C.c_int(), C.c_int()
+        self._chk(self.L.svslam_pyramid_read(self.h, slot, level, None, C.byref(w), C.byref(h)), "pyramid_read")
+        out = np.zeros((h.value + 32, w.value + 32), np.uint8)
+        self._chk(self.L.svslam_pyramid_read_padded(self.h, slot, level, _p(out)), "pyramid_read_padded")
         return out
 
     # ---- LK --------------------------------------------------------------

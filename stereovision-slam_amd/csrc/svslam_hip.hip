@@ -59,6 +59,8 @@ struct svslam_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     PyrGeom geom;
+    PyrFusedPlan pyr_plan;        // all levels in one launch (k_pyr_fused), when the geometry allows it
+    bool pyr_fused = false;
     uint8_t *d_pyr = nullptr;
     Arena ar;
     // image upload area (host-pointer sources)
@@ -266,6 +268,14 @@ int launch_pyramid(svslam_ctx *c, const PyrJob *djobs, int n, bool decimate, int
 {
     const PyrGeom &g = c->geom;
     tm_begin(c, FAM_PYR, n);
+    if (c->pyr_fused) {
+        const dim3 grd(((n + 7) / 8) * 8 * c->pyr_plan.nstrips);      // jobs in groups of 8 (one per XCD), all strips of a job on its XCD
+        if (decimate) hipLaunchKernelGGL(k_pyr_fused<true>, grd, dim3(PF_THREADS), c->pyr_plan.lds_bytes, c->stream, djobs, n, c->d_pyr, g, src_w, src_h, c->pyr_plan);
+        else hipLaunchKernelGGL(k_pyr_fused<false>, grd, dim3(PF_THREADS), c->pyr_plan.lds_bytes, c->stream, djobs, n, c->d_pyr, g, src_w, src_h, c->pyr_plan);
+        tm_end(c);
+        HIPCHK(c, hipGetLastError());
+        return 0;
+    }
     auto fast_ok = [](int w, int h) { return w >= 18 && h >= 18; };
     if (fast_ok(g.w[0], g.h[0])) {
         dim3 blk(16, 16);
@@ -378,6 +388,11 @@ int svslam_create(const svslam_limits *lim, svslam_ctx **out)
     HIPCHK(c, hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
     for (int i = 0; i < 16; ++i) HIPCHK(c, hipEventCreate(&c->ev[i]));
     make_geom(c->geom, lim->width, lim->height);
+    c->pyr_fused = !std::getenv("SVSLAM_PYR_LEGACY") && pyr_fused_plan(c->geom, 64 * 1024, c->pyr_plan);
+    if (c->pyr_fused && std::getenv("SVSLAM_PYR_PROF")) {
+        HIPCHK(c, hipMalloc(&c->pyr_plan.prof, sizeof(long long) * 8));
+        HIPCHK(c, hipMemset(c->pyr_plan.prof, 0, sizeof(long long) * 8));
+    }
     HIPCHK(c, hipMalloc(&c->d_pyr, c->geom.slot_bytes * (size_t)lim->max_slots));
     HIPCHK(c, hipMemsetAsync(c->d_pyr, 0, c->geom.slot_bytes * (size_t)lim->max_slots, c->stream));
 
@@ -439,6 +454,14 @@ void svslam_destroy(svslam_ctx *c)
     if (c->ar.h) (void)hipHostFree(c->ar.h);
     (void)hipFree(c->d_img);
     if (c->h_img) (void)(void)hipHostFree(c->h_img);
+    if (c->pyr_fused && c->pyr_plan.prof) {
+        long long p[8] = { 0 };
+        (void)hipMemcpy(p, c->pyr_plan.prof, sizeof(p), hipMemcpyDeviceToHost);
+        const double k = p[7] ? 0.01 / (double)p[7] : 0.0;
+        fprintf(stderr, "[pyr fused, workgroup (1,0), %lld launches, %d strips, lds %d] us: fill %.1f | border+store+pyrDown per level %.1f %.1f %.1f | last level %.1f\n",
+                p[7], c->pyr_plan.nstrips, c->pyr_plan.lds_bytes, k * p[0], k * p[1], k * p[2], k * p[3], k * p[5]);
+        (void)hipFree(c->pyr_plan.prof);
+    }
     if (c->gw.prof) {
         long long p[16] = { 0 };
         (void)hipMemcpy(p, c->gw.prof, sizeof(p), hipMemcpyDeviceToHost);
@@ -536,6 +559,19 @@ int svslam_pyramid_read(svslam_ctx *c, int slot, int level, uint8_t *out, int *w
     const uint8_t *src = c->d_pyr + (size_t)slot * g.slot_bytes + g.ofs[level] + (size_t)SVS_BORDER * g.pitch[level] + SVS_BORDER;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy2D(out, g.w[level], src, g.pitch[level], g.w[level], g.h[level], hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// test hook: one level WITH its stored 16-px REFLECT_101 border, tight rows of (w + 32) bytes
+int svslam_pyramid_read_padded(svslam_ctx *c, int slot, int level, uint8_t *out)
+{
+    if (check_slot(c, slot)) return -1;
+    if (level < 0 || level >= c->geom.nlevels) return fail(c, "level %d out of range", level);
+    const PyrGeom &g = c->geom;
+    const int pw = g.w[level] + 2 * SVS_BORDER, ph = g.h[level] + 2 * SVS_BORDER;
+    const uint8_t *src = c->d_pyr + (size_t)slot * g.slot_bytes + g.ofs[level];
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy2D(out, pw, src, g.pitch[level], pw, ph, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -400,3 +400,55 @@ def test_gftt_selection_paths(svs, orc):
     (g,) = c.gftt([(0, None)], max_corners=150)
     assert np.array_equal(g, orc.gftt(noise))
     c.close()
+
+
+def _check_slot_against_oracle(c, orc, slot, img, tag):
+    for lvl, r in enumerate(orc.pyramid(img)):
+        assert np.array_equal(c.pyramid_read(slot, lvl), r), (tag, "level", lvl)
+        # the stored border is the REFLECT_101 continuation, 16 px on every side
+        assert np.array_equal(c.pyramid_read_padded(slot, lvl), np.pad(r, 16, mode="reflect")), (tag, "border of level", lvl)
+
+
+def test_pyramid_all_levels_in_one_launch(svs, orc):
+    """k_pyr_fused (strips of every level per workgroup, through LDS): interiors AND stored borders
+    bit-exact for geometries with different strip counts, odd sizes, 3- and 4-level pyramids; sources
+    in host memory and in device memory at odd addresses / strides; batches of several slots"""
+    rng = np.random.default_rng(21)
+    for (w, h) in ((620, 188), (613, 185), (200, 150), (76, 73), (640, 480), (97, 53)):
+        imgs = [rng.integers(0, 256, (h, w), dtype=np.uint8) for _ in range(3)]
+        c = svs.Context(w, h, max_slots=4, max_jobs=4, max_kf=0, max_lm=0, max_obs=0)
+        c.pyramid([0, 1, 2], imgs)
+        for s in range(3):
+            _check_slot_against_oracle(c, orc, s, imgs[s], (w, h, s))
+        # device-resident source, base address and stride not multiples of 4
+        stride = w + 3
+        buf = np.zeros((h + 1) * stride + 8, np.uint8)
+        view = np.lib.stride_tricks.as_strided(buf[5:], (h, w), (stride, 1))
+        view[:] = imgs[1]
+        d = c.dev_alloc(buf.size)
+        c.dev_upload(d, buf)
+        c.pyramid([3], [d + 5], device=True, strides=[stride])
+        _check_slot_against_oracle(c, orc, 3, imgs[1], (w, h, "device, misaligned"))
+        c.dev_free(d)
+        c.close()
+
+
+def test_pyramid_decimation_fused_into_the_one_launch_kernel(svs, orc):
+    rng = np.random.default_rng(22)
+    for (sw, sh) in ((1241, 376), (1226, 370), (400, 300)):
+        full = rng.integers(0, 256, (sh, sw), dtype=np.uint8)
+        dec = orc.decimate(full)
+        h, w = dec.shape
+        c = svs.Context(w, h, max_slots=2, max_jobs=2, max_kf=0, max_lm=0, max_obs=0)
+        c.pyramid([0], [full], decimate_from=(sw, sh))
+        _check_slot_against_oracle(c, orc, 0, dec, (sw, sh, "host"))
+        stride = sw + 1
+        buf = np.zeros((sh + 1) * stride + 8, np.uint8)
+        view = np.lib.stride_tricks.as_strided(buf[3:], (sh, sw), (stride, 1))
+        view[:] = full
+        d = c.dev_alloc(buf.size)
+        c.dev_upload(d, buf)
+        c.pyramid([1], [d + 3], device=True, strides=[stride], decimate_from=(sw, sh))
+        _check_slot_against_oracle(c, orc, 1, dec, (sw, sh, "device, misaligned"))
+        c.dev_free(d)
+        c.close()
