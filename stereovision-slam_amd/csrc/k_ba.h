@@ -66,6 +66,8 @@ struct BaDev {               // device-side job descriptor (built on the host)
     int aux_ofs;             // offset into the int aux buffer
     int iters_done;
     int rec_ofs;             // offset (records) of this job's 2*nobs records: landmark-major, then pose-major
+    int lay_nblk, lay_na, lay_ntile;   // counts the aux LAYOUT was reserved for: the actual ones (host build) or
+                                       // their upper bounds (device build, k_ba_build.h)
 };
 
 struct BaWork {              // per-job HBM scratch, strided by the context limits
@@ -299,6 +301,7 @@ struct BaHostStruct {        // scratch reused across jobs
         cp(L.pcs, pcs, (size_t)ntile * ((size_t)na * (na + 1) / 2) + 1); cp(L.pitem, pitem, ncontrib);
         d.kf_ofs = j.kf_ofs; d.nkf = j.nkf; d.lm_ofs = j.lm_ofs; d.nlm = j.nlm; d.obs_ofs = j.obs_ofs; d.nobs = j.nobs;
         d.nblk = nblk; d.na = na; d.ncontrib = ncontrib; d.ntile = ntile; d.iters_done = 0; d.rec_ofs = 0;
+        d.lay_nblk = nblk; d.lay_na = na; d.lay_ntile = ntile;
     }
 };
 
@@ -521,7 +524,7 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
     const BaRec *recP = recL + nobs;                   // pose-major
     const int *aux = aux_all + jd.aux_ofs;
     const int ntile = jd.ntile;
-    const BaAuxLayout AL = ba_aux_layout(nkf, nlm, nobs, nblk, na, jd.ncontrib, ntile);
+    const BaAuxLayout AL = ba_aux_layout(nkf, nlm, nobs, jd.lay_nblk, jd.lay_na, jd.ncontrib, jd.lay_ntile);
     const int *lm_estart = aux + AL.lm_estart, *lm_edges = aux + AL.lm_edges;
     const int *kf_estart = aux + AL.kf_estart;
     const int *lm_bstart = aux + AL.lm_bstart;

@@ -1,0 +1,262 @@
+// k_ba_build.h — the structure of a local-BA problem built on the device.
+// k_local_ba (k_ba.h) works on edge records in two orders, landmark ranges, (pose, landmark) blocks,
+// LDS tiles and per-tile lists of block pairs.  BaHostStruct::build derives all of that from the raw
+// observation list the backend gathers (src/backend.cpp:83-160) — on the host it was the largest
+// single consumer of CPU time of the whole path (6 ms of wall time per 100 problems on 4 threads).
+// This kernel produces exactly the same arrays (same numbering, same orders, hence bit-identical
+// optimisation results) with one workgroup per problem: counting sorts become flattened
+// [key][thread] exclusive scans, the per-pair item lists are emitted by one thread per list walking
+// the landmarks' pose bit masks.  The host only validates indices and supplies the edges'
+// (landmark, keyframe) order (the identity for the order the pipeline gathers them in).
+//
+// aux layout: ba_aux_layout() with CAPACITIES for the block / tile counts (BaDev::lay_*), so the
+// space of a problem can be reserved before its counts are known.
+#pragma once
+#include "k_ba.h"
+
+#pragma clang fp contract(off)
+
+#define BB_THREADS 256
+#define BB_MAXKEYS 33            // block counts 0..32 / keyframes 0..31
+
+// upper bound of the number of LDS tiles of a problem (greedy packing with two capacities)
+__host__ __device__ inline int ba_tile_bound(int nlm, int nobs, int nkf, int tile_cap)
+{
+    const int per = tile_cap - nkf > 1 ? tile_cap - nkf : 1;
+    return nobs / per + nlm / tile_cap + 2;
+}
+// pitem capacity: a landmark seen from k keyframes lists k (k + 1) / 2 pairs
+__host__ __device__ inline size_t ba_pitem_bound(int nobs, int nkf) { return (size_t)nobs * (size_t)(nkf + 1) / 2 + 1; }
+
+// exclusive scan of a[0..n) in LDS by the whole workgroup; returns the total.  tmp: BB_THREADS ints.
+__device__ __forceinline__ int bb_exscan(int *a, int n, int *tmp, int tid)
+{
+    const int per = (n + BB_THREADS - 1) / BB_THREADS;
+    const int i0 = min(tid * per, n), i1 = min(i0 + per, n);
+    int s = 0;
+    for (int i = i0; i < i1; ++i) s += a[i];
+    __syncthreads();
+    tmp[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < BB_THREADS; d <<= 1) {
+        const int add = tid >= d ? tmp[tid - d] : 0;
+        __syncthreads();
+        tmp[tid] += add;
+        __syncthreads();
+    }
+    const int total = tmp[BB_THREADS - 1];
+    int run = tmp[tid] - s;
+    for (int i = i0; i < i1; ++i) { const int v = a[i]; a[i] = run; run += v; }
+    __syncthreads();
+    return total;
+}
+
+// LDS ints needed for a batch whose largest problem has max_nlm landmarks
+static inline size_t bb_lds_bytes(int max_nlm)
+{
+    return ((size_t)6 * ((size_t)max_nlm + 2) + (size_t)BB_MAXKEYS * BB_THREADS + BB_THREADS + 4 * BB_MAXKEYS + 64) * sizeof(int);
+}
+
+__global__ void __launch_bounds__(BB_THREADS)
+k_ba_build(BaDev *jobs, const int *obs_kf, const int *obs_lm, const uint8_t *obs_right, const float2 *obs_uv,
+           const int *srt_all, BaRec *recs_all, int *aux_all, int tile_cap, int max_nlm, int *err_flag)
+{
+    extern __shared__ __attribute__((aligned(16))) int bb_lds[];
+    BaDev &jd = jobs[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int nkf = jd.nkf, nlm = jd.nlm, nobs = jd.nobs;
+    const int *okf = obs_kf + jd.obs_ofs, *olm = obs_lm + jd.obs_ofs, *srt = srt_all + jd.obs_ofs;
+    const uint8_t *ori = obs_right + jd.obs_ofs;
+    const float2 *ouv = obs_uv + jd.obs_ofs;
+    BaRec *recL = recs_all + jd.rec_ofs, *recP = recL + nobs;
+    int *aux = aux_all + jd.aux_ofs;
+    if (nobs <= 0 || nlm <= 0 || nkf <= 0) {
+        if (tid == 0) { jd.nblk = 0; jd.na = 0; jd.ncontrib = 0; jd.ntile = 0; }
+        return;
+    }
+    const BaAuxLayout AL = ba_aux_layout(nkf, nlm, nobs, jd.lay_nblk, jd.lay_na, 0, jd.lay_ntile);
+    int *g_lm_estart = aux + AL.lm_estart, *g_lm_edges = aux + AL.lm_edges, *g_kf_estart = aux + AL.kf_estart;
+    int *g_lm_orig = aux + AL.lm_orig, *g_lm_bstart = aux + AL.lm_bstart, *g_blk_kf = aux + AL.blk_kf, *g_blk_lm = aux + AL.blk_lm;
+    int *g_kf_pidx = aux + AL.kf_pidx, *g_act_kf = aux + AL.act_kf, *g_tile_lm = aux + AL.tile_lm, *g_pcs = aux + AL.pcs;
+    int *g_pitem = aux + AL.pitem;
+
+    // LDS carve
+    const int N1 = max_nlm + 2;
+    int *ostart = bb_lds;                 // [nlm + 1] edge range of landmark l (caller numbering) in sorted order
+    int *cnt = ostart + N1;               // [nlm]     blocks of landmark l
+    int *lm_orig = cnt + N1;              // [nlm]     new -> caller
+    int *lm_bs = lm_orig + N1;            // [nlm + 1] block range (new numbering)
+    int *lm_es = lm_bs + N1;              // [nlm + 1] edge range (new numbering)
+    int *pmask = lm_es + N1;              // [nlm]     active-pose bits of a landmark (new numbering)
+    int *flat = pmask + N1;               // [BB_MAXKEYS * BB_THREADS]
+    int *tmp = flat + BB_MAXKEYS * BB_THREADS;   // [BB_THREADS]
+    int *kcnt = tmp + BB_THREADS;         // [BB_MAXKEYS] edges per keyframe, then kf_estart
+    int *pidx = kcnt + BB_MAXKEYS;        // [BB_MAXKEYS]
+    int *small = pidx + BB_MAXKEYS;       // scalars: 0 maxc, 1 na, 2 ntile, 3 ncontrib
+
+    for (int l = tid; l <= nlm; l += BB_THREADS) { cnt[l] = 0; }
+    if (tid < BB_MAXKEYS) { kcnt[tid] = 0; pidx[tid] = -1; }
+    if (tid < 8) small[tid] = 0;
+    __syncthreads();
+    // ---- 1. edge ranges per landmark (the edges arrive landmark-major through srt), blocks per landmark,
+    //         edges per keyframe
+    for (int i = tid; i < nobs; i += BB_THREADS) {
+        const int e = srt[i], l = olm[e], k = okf[e];
+        int lp = -1, kp = -1;
+        if (i > 0) { const int ep = srt[i - 1]; lp = olm[ep]; kp = okf[ep]; }
+        if (l != lp) for (int q = lp + 1; q <= l; ++q) ostart[q] = i;
+        if (i == nobs - 1) for (int q = l + 1; q <= nlm; ++q) ostart[q] = nobs;
+        if (l != lp || k != kp) atomicAdd(&cnt[l], 1);
+        atomicAdd(&kcnt[k], 1);
+    }
+    __syncthreads();
+    // ---- 2. keyframes: edge ranges, active poses (tiny, one thread)
+    if (tid == 0) {
+        int run = 0, na = 0;
+        for (int k = 0; k < nkf; ++k) {
+            const int c = kcnt[k];
+            g_kf_estart[k] = run;
+            if (c > 0) { pidx[k] = na; g_act_kf[na] = k; ++na; }
+            g_kf_pidx[k] = pidx[k];
+            kcnt[k] = run;                // now: kf_estart
+            run += c;
+        }
+        g_kf_estart[nkf] = run;
+        for (int a = na; a < nkf; ++a) g_act_kf[a] = -1;
+        small[1] = na;
+    }
+    // max block count
+    {
+        int m = 0;
+        for (int l = tid; l < nlm; l += BB_THREADS) m = max(m, cnt[l]);
+        atomicMax(&small[0], m);
+    }
+    __syncthreads();
+    const int maxc = small[0], na = small[1];
+    const int npairs = na * (na + 1) / 2;
+    // ---- 3. landmarks renumbered by descending block count, stable: flattened [key][thread] counting sort
+    const int nkeys = maxc + 1;
+    const int lper = (nlm + BB_THREADS - 1) / BB_THREADS;
+    {
+        const int l0 = min(tid * lper, nlm), l1 = min(l0 + lper, nlm);
+        for (int key = 0; key < nkeys; ++key) flat[key * BB_THREADS + tid] = 0;
+        for (int l = l0; l < l1; ++l) flat[(maxc - cnt[l]) * BB_THREADS + tid]++;
+        __syncthreads();
+        bb_exscan(flat, nkeys * BB_THREADS, tmp, tid);
+        for (int l = l0; l < l1; ++l) {
+            const int pos = flat[(maxc - cnt[l]) * BB_THREADS + tid]++;
+            lm_orig[pos] = l;
+        }
+    }
+    __syncthreads();
+    // ---- 4. edge and block ranges in the new numbering
+    for (int jn = tid; jn < nlm; jn += BB_THREADS) {
+        const int l = lm_orig[jn];
+        lm_es[jn] = ostart[l + 1] - ostart[l];
+        lm_bs[jn] = cnt[l];
+        g_lm_orig[jn] = l;
+    }
+    if (tid == 0) { lm_es[nlm] = 0; lm_bs[nlm] = 0; }
+    __syncthreads();
+    bb_exscan(lm_es, nlm + 1, tmp, tid);
+    const int nblk = bb_exscan(lm_bs, nlm + 1, tmp, tid);
+    for (int jn = tid; jn <= nlm; jn += BB_THREADS) { g_lm_estart[jn] = lm_es[jn]; g_lm_bstart[jn] = lm_bs[jn]; }
+    // ---- 5. landmark-major records, blocks, pose masks (thread per landmark; lanes of a wave walk
+    //         similar edge counts because of the renumbering)
+    for (int jn = tid; jn < nlm; jn += BB_THREADS) {
+        const int l = lm_orig[jn];
+        int i = lm_es[jn], b = lm_bs[jn] - 1, prev_kf = -1;
+        unsigned int mask = 0;
+        for (int q = ostart[l]; q < ostart[l + 1]; ++q, ++i) {
+            const int e = srt[q], k = okf[e];
+            if (k != prev_kf) { ++b; g_blk_kf[b] = k; g_blk_lm[b] = jn; prev_kf = k; mask |= 1u << pidx[k]; }
+            g_lm_edges[i] = e;
+            const float2 uv = ouv[e];
+            BaRec r;
+            r.u = uv.x; r.v = uv.y;
+            r.lmkc = jn | (((pidx[k] << 1) | (ori[e] ? 1 : 0)) << 24);
+            r.blk = b;
+            recL[i] = r;
+        }
+        pmask[jn] = (int)mask;
+    }
+    __syncthreads();
+    // ---- 6. pose-major copy of the records, landmark-ascending inside a pose: stable partition of the
+    //         landmark-major order by keyframe, again as a flattened [keyframe][thread] scan
+    {
+        const int eper = (nobs + BB_THREADS - 1) / BB_THREADS;
+        const int i0 = min(tid * eper, nobs), i1 = min(i0 + eper, nobs);
+        for (int k = 0; k < nkf; ++k) flat[k * BB_THREADS + tid] = 0;
+        for (int i = i0; i < i1; ++i) flat[okf[g_lm_edges[i]] * BB_THREADS + tid]++;
+        __syncthreads();
+        bb_exscan(flat, nkf * BB_THREADS, tmp, tid);
+        for (int i = i0; i < i1; ++i) {
+            const int k = okf[g_lm_edges[i]];
+            recP[flat[k * BB_THREADS + tid]++] = recL[i];
+        }
+    }
+    // ---- 7. LDS tiles: greedy packing of consecutive landmarks under two capacities (sequential by nature)
+    if (tid == 0) {
+        int nt = 0, nl_t = 0, nb_t = 0;
+        g_tile_lm[0] = 0;
+        for (int l = 0; l < nlm; ++l) {
+            const int k = lm_bs[l + 1] - lm_bs[l];
+            if (nl_t + 1 > tile_cap || nb_t + k > tile_cap) {
+                ++nt;
+                if (nt <= jd.lay_ntile) g_tile_lm[nt] = l;
+                nl_t = 0; nb_t = 0;
+            }
+            ++nl_t; nb_t += k;
+        }
+        ++nt;
+        if (nt <= jd.lay_ntile) g_tile_lm[nt] = nlm; else atomicExch(err_flag, 1);
+        small[2] = nt;
+    }
+    __syncthreads();
+    const int ntile = small[2];
+    if (ntile > jd.lay_ntile) return;
+    // ---- 8. block pairs of every (tile, pose pair): one thread per list walks the tile's landmarks;
+    //         a landmark that sees poses a and b contributes the pair of its blocks popcount(mask below a / b)
+    const int nlist = ntile * npairs;
+    for (int q0 = 0; q0 < nlist; q0 += BB_MAXKEYS * BB_THREADS) {
+        // counts (flat doubles as the count / offset table of up to BB_MAXKEYS * BB_THREADS lists at a time)
+        const int nq = min(nlist - q0, BB_MAXKEYS * BB_THREADS);
+        for (int q = tid; q < nq; q += BB_THREADS) {
+            const int t = (q0 + q) / npairs, pr = (q0 + q) - t * npairs;
+            int a = 0, rem = pr;
+            while (rem >= na - a) { rem -= na - a; ++a; }
+            const unsigned int need = (1u << a) | (1u << (a + rem));
+            int c = 0;
+            for (int l = g_tile_lm[t]; l < g_tile_lm[t + 1]; ++l) c += ((unsigned int)pmask[l] & need) == need;
+            flat[q] = c;
+        }
+        __syncthreads();
+        const int base = small[3];
+        const int tot = bb_exscan(flat, nq, tmp, tid);
+        for (int q = tid; q < nq; q += BB_THREADS) g_pcs[q0 + q] = base + flat[q];
+        if ((size_t)(base + tot) > ba_pitem_bound(nobs, nkf)) { if (tid == 0) atomicExch(err_flag, 2); return; }
+        for (int q = tid; q < nq; q += BB_THREADS) {
+            const int t = (q0 + q) / npairs, pr = (q0 + q) - t * npairs;
+            int a = 0, rem = pr;
+            while (rem >= na - a) { rem -= na - a; ++a; }
+            const int b2 = a + rem;
+            const unsigned int need = (1u << a) | (1u << b2);
+            const int l0 = g_tile_lm[t], bt0 = lm_bs[l0];
+            int w = base + flat[q];
+            for (int l = l0; l < g_tile_lm[t + 1]; ++l) {
+                const unsigned int m = (unsigned int)pmask[l];
+                if ((m & need) != need) continue;
+                const int u = lm_bs[l] - bt0 + __popc(m & ((1u << a) - 1u));
+                const int v = lm_bs[l] - bt0 + __popc(m & ((1u << b2) - 1u));
+                g_pitem[w++] = u | (v << 10) | ((l - l0) << 20);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) small[3] = base + tot;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        g_pcs[nlist] = small[3];
+        jd.nblk = nblk; jd.na = na; jd.ncontrib = small[3]; jd.ntile = ntile;
+    }
+}

@@ -27,6 +27,7 @@
 #include "k_gftt.h"
 #include "k_geom.h"
 #include "k_ba.h"
+#include "k_ba_build.h"
 
 namespace {
 
@@ -79,6 +80,7 @@ struct svslam_ctx {
     bool wait_poll = true;
     bool low_latency = false;   // svslam_set_low_latency: 4-wave pose-only blocks
     bool timing_split = false;  // SVSLAM_TIMING_SPLIT: per-kernel events of the multi-kernel families (families 6..9)
+    bool ba_host_build = false; // SVSLAM_BA_HOST_BUILD: problem structure on the host (the checker of k_ba_build), A/B
     int src_w = 0, src_h = 0;     // > 0: level 0 is the 2:1 decimation of src_w x src_h inputs
     // resident feature lists (svslam_rtrack_*): two alternating buffers per stream
     RtStore rt = {};
@@ -86,7 +88,7 @@ struct svslam_ctx {
     hipEvent_t done = nullptr;   // recorded after the last enqueue of a call; the stream may be shared
     // a submitted, not yet collected local-BA batch owns the staging arena
     struct { bool active = false; int njobs = 0, total_kf = 0, total_lm = 0, total_obs = 0;
-             size_t ojobs = 0, oposes = 0, opts = 0, ochi = 0; } ba_pending;
+             size_t ojobs = 0, oposes = 0, opts = 0, ochi = 0, oflag = 0; } ba_pending;
     // timing
     bool timing = false;
     Timing tm;
@@ -383,6 +385,7 @@ int svslam_create(const svslam_limits *lim, svslam_ctx **out)
         const char *wm = std::getenv("SVSLAM_WAIT");        // spin | poll (default)
         c->wait_poll = !(wm && std::strcmp(wm, "spin") == 0);
         c->timing_split = std::getenv("SVSLAM_TIMING_SPLIT") != nullptr;
+        c->ba_host_build = std::getenv("SVSLAM_BA_HOST_BUILD") != nullptr;
     }
     HIPCHK(c, pool_stream(c->device, &c->stream));
     HIPCHK(c, hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
@@ -400,7 +403,10 @@ int svslam_create(const svslam_limits *lim, svslam_ctx **out)
     const size_t J = lim->max_jobs, N = lim->max_pts;
     size_t per_job_pts = N * (8 + 8 + 1 + 4 + 24 + 8 + 1 + 1 + 8) + 1024;
     size_t per_job_ba = (size_t)lim->max_kf * 56 + (size_t)lim->max_lm * 24 +
-                        (size_t)lim->max_obs * (4 + 4 + 1 + 8 + 8 + 24 + 4 * (size_t)(lim->max_kf + 1)) + (size_t)lim->max_lm * 8 + 4096;
+                        (size_t)lim->max_obs * (21 + 8 + 32 + 12 + 2 * (size_t)(lim->max_kf + 1) + 8) + (size_t)lim->max_lm * 16 + 8192;
+    // (per edge: raw 21 B, chi2 8 B, two records 32 B, edge + block lists 12 B, pair items <= 2 (K + 1) B)
+    per_job_ba += 4 * (size_t)(ba_tile_bound(lim->max_lm, lim->max_obs, lim->max_kf, std::max(ba_tile_cap(lim->max_kf), 64)) + 2) *
+                  ((size_t)lim->max_kf * (lim->max_kf + 1) / 2 + 1);          // per-tile pair ranges at their upper bound
     size_t per_job = std::max(per_job_pts, per_job_ba) + (size_t)lim->max_corners * 8 + 4096;
     c->ar.cap = per_job * J + (1 << 20);
     HIPCHK(c, hipHostMalloc(&c->ar.h, c->ar.cap));
@@ -427,6 +433,10 @@ int svslam_create(const svslam_limits *lim, svslam_ctx **out)
             return fail(c, "BA workspace allocation failed");
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_local_ba),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ba_lds_bytes(lim->max_kf)));
+        if (bb_lds_bytes(lim->max_lm) > 160 * 1024 || lim->max_kf > 32)
+            return fail(c, "max_lm %d / max_kf %d: problem structure does not fit LDS", lim->max_lm, lim->max_kf);
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_build),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bb_lds_bytes(lim->max_lm)));
     }
     if (lim->max_streams > 0) {
         const size_t n = (size_t)lim->max_streams * lim->max_pts;
@@ -811,27 +821,38 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
     if (c->ba_pending.active) return fail(c, "a submitted local-BA batch owns this context: call svslam_local_ba_collect first");
     c->ar.reset();
     static_assert(sizeof(BaJob) == sizeof(svslam_ba_job), "job layout");
-    // arena: cams | records | jobs | poses | points | chi2 (out) | aux (bump-allocated below, last)
+    const size_t TO = (size_t)std::max(total_obs, 1);
+    const int tile_cap = ba_tile_cap(c->lim.max_kf);
+    // arena: cams | jobs | poses | points | [raw edges + order (device build)] | chi2 + flag (out) |
+    //        records | aux  (records and aux are device-only when the device builds the structure)
     size_t ocams = c->ar.take(sizeof(BaCams));
-    size_t orecs = c->ar.take(sizeof(BaRec) * 2 * std::max(total_obs, 1));   // landmark-major + pose-major edge records
-    size_t ojobs = c->ar.take(sizeof(BaDev) * njobs);
+    size_t okf_o = 0, olm_o = 0, ori_o = 0, ouv_o = 0, osrt_o = 0;
+    if (!c->ba_host_build) {
+        okf_o = c->ar.take(sizeof(int) * TO); olm_o = c->ar.take(sizeof(int) * TO); osrt_o = c->ar.take(sizeof(int) * TO);
+        ouv_o = c->ar.take(sizeof(float) * 2 * TO); ori_o = c->ar.take(TO);
+    }
+    size_t ojobs = c->ar.take(sizeof(BaDev) * njobs);          // read back from here ...
     size_t oposes = c->ar.take(sizeof(double) * 7 * std::max(total_kf, 1));
     size_t opts = c->ar.take(sizeof(double) * 3 * std::max(total_lm, 1));
     size_t in_end = c->ar.off;
-    size_t ochi = c->ar.take(sizeof(double) * std::max(total_obs, 1));
+    size_t ochi = c->ar.take(sizeof(double) * TO);
+    size_t oflag = c->ar.take(sizeof(int) * 4);
     size_t out_end = c->ar.off;
+    size_t orecs = c->ar.take(sizeof(BaRec) * 2 * TO);   // landmark-major + pose-major edge records
     size_t oaux = c->ar.take(0);
     if (oaux > c->ar.cap) return fail(c, "local_ba: staging arena too small (%zu > %zu bytes)", oaux, c->ar.cap);
     BaCams *cams = hp<BaCams>(c, ocams);
     memcpy(cams->cam[0], cam_l, 32); memcpy(cams->cam[1], cam_r, 32);
     memcpy(cams->ext[0], ext_l, 56); memcpy(cams->ext[1], ext_r, 56);
     BaDev *dj = hp<BaDev>(c, ojobs);
-    // Host-side structure of every problem (edge records, blocks, pose-pair lists), built by the
-    // pool with one scratch structure per thread (stays cache-hot) and written straight into the
-    // arena; the aux space of a problem comes from a bump allocator, so its position depends on
-    // thread timing but nothing else does (every problem carries its own offsets).
+    hp<int>(c, oflag)[0] = 0;
     size_t aux_total = 0;
-    {
+    int max_nlm = 1;
+    if (c->ba_host_build) {
+        // Host-side structure of every problem (edge records, blocks, pose-pair lists), built by the
+        // pool with one scratch structure per thread (stays cache-hot) and written straight into the
+        // arena; the aux space of a problem comes from a bump allocator, so its position depends on
+        // thread timing but nothing else does (every problem carries its own offsets).
         std::vector<int> bad((size_t)njobs, 0);
         std::atomic<size_t> bump{ 0 };
         const size_t aux_cap_ints = (c->ar.cap - oaux) / sizeof(int);
@@ -841,7 +862,7 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
             static thread_local BaHostStruct hs;
             BaJob bj;
             memcpy(&bj, &jobs[i], sizeof(bj));
-            if (!hs.build(bj, obs_kf, obs_lm, obs_is_right, obs_uv, ba_tile_cap(c->lim.max_kf))) { bad[(size_t)i] = 1; return; }   // index out of range
+            if (!hs.build(bj, obs_kf, obs_lm, obs_is_right, obs_uv, tile_cap)) { bad[(size_t)i] = 1; return; }   // index out of range
             const size_t need = hs.aux_ints(bj);
             const size_t at = bump.fetch_add(need);
             if (at + need > aux_cap_ints) { bad[(size_t)i] = 2; return; }
@@ -857,19 +878,71 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
         }
         aux_total = bump.load();
         (void)c->ar.take(sizeof(int) * aux_total);
+    } else {
+        // The device builds the structure (k_ba_build).  The host validates the indices and tells the
+        // device the (landmark, keyframe) order of the edges: the identity for the order the backend
+        // gathers them in (src/backend.cpp:83-160), a stable sort otherwise.
+        std::vector<int> bad((size_t)njobs, 0);
+        int *srt = hp<int>(c, osrt_o);
+        auto check_one = [&](int i) {
+            const svslam_ba_job &j = jobs[i];
+            const int *kf = obs_kf + j.obs_ofs, *lm = obs_lm + j.obs_ofs;
+            int *sr = srt + j.obs_ofs;
+            bool sorted = true;
+            for (int e = 0; e < j.nobs; ++e) {
+                const int k = kf[e], l = lm[e];
+                if (k < 0 || k >= j.nkf || l < 0 || l >= j.nlm) { bad[(size_t)i] = 1; return; }
+                if (e && !((lm[e - 1] < l) || (lm[e - 1] == l && kf[e - 1] <= k))) sorted = false;
+                sr[e] = e;
+            }
+            if (!sorted)
+                std::stable_sort(sr, sr + j.nobs, [&](int a, int b) { return lm[a] != lm[b] ? lm[a] < lm[b] : kf[a] < kf[b]; });
+        };
+        if (c->pool && njobs > 1) c->pool->parallel_for(njobs, check_one);
+        else for (int i = 0; i < njobs; ++i) check_one(i);
+        size_t at = 0;
+        for (int i = 0; i < njobs; ++i) {
+            if (bad[(size_t)i]) return fail(c, "local_ba: job %d has an edge index out of range", i);
+            const svslam_ba_job &j = jobs[i];
+            BaDev &d = dj[i];
+            d.kf_ofs = j.kf_ofs; d.nkf = j.nkf; d.lm_ofs = j.lm_ofs; d.nlm = j.nlm; d.obs_ofs = j.obs_ofs; d.nobs = j.nobs;
+            d.nblk = d.na = d.ncontrib = d.ntile = 0; d.iters_done = 0;
+            d.rec_ofs = 2 * j.obs_ofs;
+            d.lay_nblk = j.nobs; d.lay_na = j.nkf; d.lay_ntile = ba_tile_bound(j.nlm, j.nobs, j.nkf, tile_cap);
+            d.aux_ofs = (int)at;
+            at += ba_aux_layout(j.nkf, j.nlm, j.nobs, d.lay_nblk, d.lay_na, 0, d.lay_ntile).total + ba_pitem_bound(j.nobs, j.nkf);
+            max_nlm = std::max(max_nlm, j.nlm);
+        }
+        aux_total = at;
+        (void)c->ar.take(sizeof(int) * aux_total);
+        if (c->ar.off > c->ar.cap) return fail(c, "local_ba: staging arena too small for the problem structure (%zu > %zu bytes)", c->ar.off, c->ar.cap);
+        if (total_obs > 0) {
+            memcpy(hp<void>(c, okf_o), obs_kf, sizeof(int) * total_obs);
+            memcpy(hp<void>(c, olm_o), obs_lm, sizeof(int) * total_obs);
+            memcpy(hp<void>(c, ouv_o), obs_uv, sizeof(float) * 2 * total_obs);
+            memcpy(hp<void>(c, ori_o), obs_is_right, (size_t)total_obs);
+        }
     }
     if (total_kf > 0) memcpy(hp<void>(c, oposes), poses, sizeof(double) * 7 * total_kf);
     if (total_lm > 0) memcpy(hp<void>(c, opts), pts, sizeof(double) * 3 * total_lm);
     c->host_ns[4] += now_ns() - t_prep0;
     if (h2d(c, 0, in_end)) return -1;
-    if (h2d(c, oaux, c->ar.off)) return -1;
-    tm_begin(c, FAM_BA, njobs);
+    if (h2d(c, oflag, oflag + sizeof(int) * 4)) return -1;
+    if (c->ba_host_build) { if (h2d(c, orecs, c->ar.off)) return -1; }
+    tm_begin(c, c->timing_split ? FAM_DBG2 : FAM_BA, njobs);
+    if (!c->ba_host_build) {
+        hipLaunchKernelGGL(k_ba_build, dim3(njobs), dim3(BB_THREADS), bb_lds_bytes(max_nlm), c->stream, dp<BaDev>(c, ojobs),
+                           dp<int>(c, okf_o), dp<int>(c, olm_o), dp<uint8_t>(c, ori_o), dp<float2>(c, ouv_o), dp<int>(c, osrt_o),
+                           dp<BaRec>(c, orecs), dp<int>(c, oaux), tile_cap, max_nlm, dp<int>(c, oflag));
+        if (c->timing_split) { tm_end(c); tm_begin(c, FAM_DBG3, njobs); }
+    }
     hipLaunchKernelGGL(k_local_ba, dim3(njobs), dim3(BA_THREADS), ba_lds_bytes(c->lim.max_kf), c->stream,
                        dp<BaDev>(c, ojobs), dp<BaCams>(c, ocams), dp<double>(c, oposes), dp<double>(c, opts),
                        dp<BaRec>(c, orecs), dp<int>(c, oaux), c->bw, huber_delta, iters, dp<double>(c, ochi), c->d_ba_prof,
-                       ba_tile_cap(c->lim.max_kf));
+                       tile_cap);
     tm_end(c);
     HIPCHK(c, hipGetLastError());
+    c->ba_pending.oflag = oflag;
     if (d2h_enqueue(c, ojobs, out_end)) return -1;
     c->ba_pending.active = true; c->ba_pending.njobs = njobs;
     c->ba_pending.total_kf = total_kf; c->ba_pending.total_lm = total_lm; c->ba_pending.total_obs = total_obs;
@@ -886,6 +959,8 @@ int svslam_local_ba_collect(svslam_ctx *c, int njobs, svslam_ba_job *jobs, int t
         return fail(c, "local_ba_collect: sizes differ from the submitted batch");
     c->ba_pending.active = false;
     if (finish(c)) return -1;
+    if (const int fl = hp<int>(c, c->ba_pending.oflag)[0])
+        return fail(c, "local_ba: the device structure build overflowed a capacity (code %d)", fl);
     const BaDev *dj = hp<BaDev>(c, c->ba_pending.ojobs);
     for (int i = 0; i < njobs; ++i) jobs[i].iters_done = dj[i].iters_done;
     if (total_kf > 0) memcpy(poses, hp<void>(c, c->ba_pending.oposes), sizeof(double) * 7 * total_kf);

@@ -452,3 +452,34 @@ def test_pyramid_decimation_fused_into_the_one_launch_kernel(svs, orc):
         _check_slot_against_oracle(c, orc, 1, dec, (sw, sh, "device, misaligned"))
         c.dev_free(d)
         c.close()
+
+
+def test_local_ba_structure_built_on_device_equals_host_build(svs, monkeypatch):
+    """k_ba_build produces the arrays BaHostStruct::build produces (same numbering, same orders), so the
+    optimisation is bit-identical whichever side built the problem structure: sorted edges (the order the
+    pipeline gathers them in), unsorted edges, landmarks and keyframes without edges, a batch of sizes"""
+    rng = np.random.default_rng(31)
+    jobs = []
+    for (nkf, nlm, keep) in ((7, 300, 0.5), (10, 1200, 0.3), (3, 40, 1.0), (10, 700, 0.15)):
+        p = cm.make_ba_problem(rng, nkf, nlm)
+        m = rng.random(len(p["okf"])) < keep
+        m &= (p["olm"] != 5) & (p["okf"] != 2 if nkf > 3 else True)          # a landmark / keyframe without edges
+        okf, olm, ori, ouv = p["okf"][m], p["olm"][m], p["ori"][m], p["ouv"][m]
+        jobs.append((p["poses0"], p["pts0"], okf, olm, ori, ouv))             # shuffled order
+        o = np.lexsort((okf, olm))
+        jobs.append((p["poses0"], p["pts0"], okf[o], olm[o], ori[o], ouv[o])) # landmark-major, keyframes ascending
+    jobs.append((jobs[0][0], jobs[0][1], np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.uint8), np.zeros((0, 2), np.float32)))
+    kw = dict(max_slots=1, max_jobs=len(jobs), max_kf=11, max_lm=2048, max_obs=20000)
+    cd = svs.Context(cm.W, cm.H, **kw)
+    monkeypatch.setenv("SVSLAM_BA_HOST_BUILD", "1")
+    ch = svs.Context(cm.W, cm.H, **kw)
+    monkeypatch.delenv("SVSLAM_BA_HOST_BUILD")
+    rd = cd.local_ba(jobs, cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R)
+    rh = ch.local_ba(jobs, cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R)
+    for i, ((pd, xd, cd2, itd), (ph, xh, ch2, ith)) in enumerate(zip(rd, rh)):
+        assert itd == ith, i
+        assert np.array_equal(pd, ph) and np.array_equal(xd, xh) and np.array_equal(cd2, ch2), i
+    # the sorted and the shuffled statement of one problem are the same problem
+    for i in range(0, 8, 2):
+        assert np.array_equal(rd[i][0], rd[i + 1][0]) and np.array_equal(rd[i][1], rd[i + 1][1])
+    cd.close(); ch.close()
