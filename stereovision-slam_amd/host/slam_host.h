@@ -26,6 +26,7 @@
 #include <cstring>
 #include <deque>
 #include <fstream>
+#include <functional>
 #include <iomanip>
 #include <memory>
 #include <stdexcept>
@@ -384,19 +385,21 @@ public:
         // thread was fast").  backend_on 2: it runs beside the next frame's Track() like the
         // reference's Backend thread, and its result lands after that frame — always exactly one
         // frame late, so runs stay reproducible.
-        if (cfg_.backend_on == 1) {
+        if (cfg_.backend_on == 1 && backend_enabled_) {
             for (int s : MS) streams_[s]->map.ReleaseRetired();      // nothing in flight
             if (!MS.empty()) { BackendSubmit(MS); BackendCollect(); }
-        } else if (cfg_.backend_on >= 2) {
+        } else if (cfg_.backend_on >= 2 && backend_enabled_) {
             BackendCollect();                                        // may still touch frames retired this step
             for (int s : MS) streams_[s]->map.ReleaseRetired();
             if (!MS.empty()) BackendSubmit(MS);
         } else {
+            BackendCollect();
             for (int s : MS) streams_[s]->map.ReleaseRetired();
         }
         // frames whose feature list or map points changed on the host (init, keyframes, BA) replace
         // the resident copy; every other frame's list never left the device
         if (resident() && !DS.empty()) UploadFeatures(DS);
+        if (on_keyframe) for (int s : MS) on_keyframe(s, *streams_[s]->current);
         long long t_e = now_ns();
         for (int s : TS) {
             Stream &st = *streams_[s];
@@ -1060,7 +1063,27 @@ private:
 public:
     // completes a backend optimisation that is still in flight (backend_on 2)
     void Flush() { BackendCollect(); }
+    // Backend::PauseRequest / Resume (src/backend.cpp:296-343): keyframes inserted while the backend is
+    // paused are not optimised
+    void SetBackendEnabled(bool on) { backend_enabled_ = on; }
+    bool BackendEnabled() const { return backend_enabled_; }
+    // Backend::UpdateMap called from outside the frontend (include/StereoVisionSLAM/backend.h:30): one local
+    // BA over every stream's active window, now.  Needs the host-side feature lists (resident_track = 0).
+    void OptimizeNow()
+    {
+        if (resident()) throw std::runtime_error("OptimizeNow: the feature lists live on the device (resident_track)");
+        BackendCollect();
+        std::vector<int> MS;
+        for (int s = 0; s < nstreams(); ++s) if (!streams_[s]->map.active_keyframes_.empty()) MS.push_back(s);
+        if (MS.empty()) return;
+        BackendSubmit(MS);
+        BackendCollect();
+    }
+    // the hooks the reference fires at the end of InsertKeyframe / StereoInit (src/frontend.cpp:618-640,
+    // 236-246): backend_->UpdateMap() is the pipeline's own BA; loop closure and viewer are callbacks
+    std::function<void(int stream, const Frame &)> on_keyframe;
 private:
+    bool backend_enabled_ = true;
     std::vector<int> ba_ms_;
     bool ba_inflight_ = false;
     int ba_ko_ = 0, ba_lo_ = 0, ba_oo_ = 0;
