@@ -215,6 +215,27 @@ int svslam_local_ba_collect(svslam_ctx *ctx, int njobs, svslam_ba_job *jobs,
                             int total_kf, double *poses, int total_lm, double *pts,
                             int total_obs, double *edge_chi2);
 
+/* ---- shared-map bundle adjustment (BASELINE config 5; not in the reference) -----------
+ * ONE local-BA problem whose landmarks are sharded over the GPUs of a node: every rank holds all
+ * nkf poses and its landmarks with their edges.  The rank opens its shard, then runs the pieces of
+ * an LM trial; the host sums what the pieces hand out over the ranks (one RCCL all-reduce of
+ * (6 nkf)^2 + 2 (6 nkf) + 1 doubles per trial — 3 781 at nkf = 10) and feeds the reduced camera
+ * system back.  The LM control flow (g2o's, exactly as in svslam_local_ba_batch) lives in the
+ * caller: stereovision-slam_amd/shared_ba.py.  io layout (svslam_sba_io_doubles(nkf) doubles):
+ *   S[np*np] | bs[np] | bp[np] | diag(Hpp)[np] | scalars[8],  np = 6 nkf
+ *   scalars: 0 chi2, 1 largest landmark diagonal, 2 Cholesky ok, 3 rho denominator (landmarks),
+ *            4 rho denominator (poses, identical on every rank), 5 chi2 of the trial state
+ * phase 1: diag(Hpp) and scalar 1 out.  phase 2 (lambda): S (without lambda I), bs, bp, scalar 0 out.
+ * phase 3 (lambda): reduced S (with lambda I), bs, bp in; scalars 2-5 out; state updated.
+ * phase 4: reject the trial (restore).  phase 5: finalise (per-edge chi2).                     */
+int svslam_sba_io_doubles(int nkf);
+int svslam_sba_open(svslam_ctx *ctx, const double cam_l[4], const double ext_l[7],
+                    const double cam_r[4], const double ext_r[7], int nkf, const double *poses,
+                    int nlm, const double *pts, int nobs, const int *obs_kf, const int *obs_lm,
+                    const uint8_t *obs_is_right, const float *obs_uv, double huber_delta);
+int svslam_sba_phase(svslam_ctx *ctx, int phase, double lambda, double *io);
+int svslam_sba_close(svslam_ctx *ctx, double *poses, double *pts, double *edge_chi2);
+
 /* test hook: accumulated per-phase ticks (wall_clock64, 100 MHz) of BA job 0;
  * out12[11] = LM trials.  enable=1 allocates the counters, out12 != NULL reads
  * and clears them.                                                            */

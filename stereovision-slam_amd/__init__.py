@@ -22,6 +22,7 @@ ABI_SYMBOLS = [
     "svslam_pyramid_read_padded", "svslam_lk_batch", "svslam_gftt_batch", "svslam_gftt_eigmap", "svslam_triangulate_batch",
     "svslam_pose_only_batch", "svslam_local_ba_batch", "svslam_local_ba_submit", "svslam_local_ba_collect",
     "svslam_track_batch", "svslam_rtrack_batch", "svslam_rtrack_upload",
+    "svslam_sba_io_doubles", "svslam_sba_open", "svslam_sba_phase", "svslam_sba_close",
     "svslam_dev_alloc", "svslam_dev_free", "svslam_dev_upload", "svslam_dev_download", "svslam_sync",
     "svslam_timing_enable", "svslam_timing_reset", "svslam_timing_get", "svslam_ba_profile",
     "svslam_set_host_threads", "svslam_debug_host_ns", "svslam_debug_clock_mhz",
@@ -365,6 +366,27 @@ class Context:
             out.append((P[j.kf_ofs:j.kf_ofs + j.nkf].copy(), X[j.lm_ofs:j.lm_ofs + j.nlm].copy(),
                         chi2[j.obs_ofs:j.obs_ofs + j.nobs].copy(), j.iters_done))
         return out
+
+    # ---- shared-map BA (one rank's shard; the LM driver is shared_ba.py) ---------
+    def sba_open(self, cam_l, ext_l, cam_r, ext_r, poses, pts, okf, olm, ori, ouv, huber_delta=5.991):
+        poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 7); pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 3)
+        okf = np.ascontiguousarray(okf, np.int32); olm = np.ascontiguousarray(olm, np.int32)
+        ori = np.ascontiguousarray(ori, np.uint8); ouv = _f32(ouv, 2)
+        self._sba = (poses.shape[0], pts.shape[0], okf.shape[0])
+        self._chk(self.L.svslam_sba_open(self.h, _p(_d(cam_l)), _p(_d(ext_l)), _p(_d(cam_r)), _p(_d(ext_r)), poses.shape[0], _p(poses),
+                                         pts.shape[0], _p(pts), okf.shape[0], _p(okf), _p(olm), _p(ori), _p(ouv),
+                                         C.c_double(huber_delta)), "sba_open")
+        return self.L.svslam_sba_io_doubles(poses.shape[0])
+
+    def sba_phase(self, phase, lam, io):
+        self._chk(self.L.svslam_sba_phase(self.h, phase, C.c_double(lam), _p(io)), "sba_phase")
+        return io
+
+    def sba_close(self):
+        nkf, nlm, nobs = self._sba
+        poses = np.zeros((nkf, 7)); pts = np.zeros((nlm, 3)); chi2 = np.zeros(max(nobs, 1))
+        self._chk(self.L.svslam_sba_close(self.h, _p(poses), _p(pts), _p(chi2)), "sba_close")
+        return poses, pts, chi2[:nobs]
 
     # ---- resident tracking -----------------------------------------------------
     def rtrack_upload(self, lists):

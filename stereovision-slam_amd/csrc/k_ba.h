@@ -485,10 +485,25 @@ __device__ __forceinline__ void ba_schur_task(int a, int b2, int rg, int c0, int
     }
 }
 
+// Shared-map BA (BASELINE config 5): the same kernel cut at the points where ranks have to meet.  Every rank
+// holds all K poses and a shard of the landmarks with their edges; MODE 1 runs ONE piece of an LM trial per
+// launch and hands the host what must be summed over the ranks (RCCL all-reduce, host/shared_ba in
+// stereovision-slam_amd/shared_ba.py drives g2o's LM control flow exactly as the loop below does):
+//   phase 1  diag(Hpp) (to be summed) and the largest landmark diagonal (to be max-ed): lambda_0
+//   phase 2  pose pass + Schur sweep of the local landmarks at the given lambda -> S, bs, bp, chi2 partials
+//   phase 3  the REDUCED system comes back: Cholesky, back-substitution of the local landmarks, update,
+//            errors -> chi2 partial of the trial state, the landmark / pose parts of the rho denominator
+//   phase 4  reject: restore the backup      phase 5  finalise: per-edge chi2, positions in caller numbering
+// io layout per job (doubles): S[np*np] | bs[np] | bp[np] | hdiag[np] | scalars[8]
+//   scalars: 0 chi2, 1 landmark diagonal max, 2 cholesky ok, 3 scale (landmarks), 4 scale (poses), 5 chi2 of the trial
+struct SbaArgs { int phase, first; double lambda; double *io; };
+#define SBA_IO_DOUBLES(np) ((size_t)(np) * (np) + 3 * (size_t)(np) + 8)
+
+template <int MODE>
 __global__ void __launch_bounds__(BA_THREADS, BA_MIN_WAVES_PER_SIMD)
-k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all, const BaRec *recs_all,
-           const int *aux_all, BaWork wk, double delta, int iters, double *edge_chi2_all, long long *prof_all,
-           int tile_cap)
+k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all, const BaRec *recs_all,
+             const int *aux_all, BaWork wk, double delta, int iters, double *edge_chi2_all, long long *prof_all,
+             int tile_cap, SbaArgs sba)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int job = blockIdx.x;
@@ -538,10 +553,13 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
     double *pts_b = wk.pts_b + J * 3 * wk.max_lm;
     double *pts = wk.pts_i + J * 3 * wk.max_lm;            // internal numbering (see BaHostStruct::build)
     const int *lm_orig = aux + AL.lm_orig;
-    for (int j = tid; j < nlm; j += BA_THREADS) {
-        const double *s3 = pts_io + 3 * (size_t)lm_orig[j];
-        pts[3 * (size_t)j] = s3[0]; pts[3 * (size_t)j + 1] = s3[1]; pts[3 * (size_t)j + 2] = s3[2];
-    }
+    if (MODE == 0 || sba.first)
+        for (int j = tid; j < nlm; j += BA_THREADS) {
+            const double *s3 = pts_io + 3 * (size_t)lm_orig[j];
+            pts[3 * (size_t)j] = s3[0]; pts[3 * (size_t)j + 1] = s3[1]; pts[3 * (size_t)j + 2] = s3[2];
+        }
+    double *sio = MODE == 1 ? sba.io + (size_t)job * SBA_IO_DOUBLES(np) : nullptr;
+    double *sio_S = sio, *sio_bs = sio + (size_t)np * np, *sio_bp = sio_bs + np, *sio_hd = sio_bp + np, *sio_sc = sio_hd + np;
 
     // camera table (constant) and pose table (rebuilt whenever the poses change)
     if (tid < 2) {
@@ -581,15 +599,23 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
         return block_sum(chi, red, tid);
     };
 
-    double lambda = 0, ni = 2;
+    double lambda = MODE == 1 ? sba.lambda : 0, ni = 2;
     int it_done = 0;
     const int npairs = na * (na + 1) / 2;
     double currentChi = 0;
+    if (MODE == 1 && sba.phase == 4) {                     // reject the trial
+        __syncthreads();
+        for (int i = tid; i < 7 * nkf; i += BA_THREADS) poses[i] = poses_b[i];
+        for (int i = tid; i < 3 * nlm; i += BA_THREADS) pts[i] = pts_b[i];
+        return;
+    }
+    if (MODE == 1 && sba.phase == 5) iters = 0;            // finalise: straight to the write-back
+    const bool lin = MODE == 0 || sba.phase <= 2;          // this launch linearises (pose pass, Schur sweep)
     for (int it = 0; it < iters; ++it) {
         pose_table();
         // ---- pose pass: Hpp (block diagonal), bp -> LDS.  16-lane rows; pose a is shared by
         // the rows a, a + na, a + 2 na ... (< BA_ROWS), partial sums combined in row order
-        {
+        if (lin) {
             const int row = tid >> 4, rl = tid & 15;
             const int rpp = BA_ROWS / na;                 // rows per pose (>= 1: na <= 32)
             double acc[27];
@@ -641,10 +667,11 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
         }
         __syncthreads();
         BA_PROF(1);
-        if (it == 0) {
+        if (it == 0 && (MODE == 0 || sba.phase == 1)) {
             // lambda_0 = 1e-5 * max diagonal of the Hessian: the landmark diagonals need one cheap sweep
             double md = 0;
-            for (int i = tid; i < np; i += BA_THREADS) md = fmax(md, fabs(Hpp[36 * (i / 6) + (i % 6) * 7]));
+            if (MODE == 0) for (int i = tid; i < np; i += BA_THREADS) md = fmax(md, fabs(Hpp[36 * (i / 6) + (i % 6) * 7]));
+            else for (int i = tid; i < np; i += BA_THREADS) sio_hd[i] = Hpp[36 * (i / 6) + (i % 6) * 7];   // summed over the ranks first
             for (int j = tid; j < nlm; j += BA_THREADS) {
                 const double X[3] = { pts[3 * (size_t)j], pts[3 * (size_t)j + 1], pts[3 * (size_t)j + 2] };
                 double h0 = 0, h3 = 0, h5 = 0;
@@ -660,6 +687,7 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
                 if (lm_estart[j + 1] > lm_estart[j]) md = fmax(md, fmax(fabs(h0), fmax(fabs(h3), fabs(h5))));
             }
             md = block_max(md, red, tid);
+            if (MODE == 1) { if (tid == 0) sio_sc[1] = md; return; }
             lambda = 1e-5 * md; ni = 2;
         }
         double tempChi = 0;
@@ -667,21 +695,23 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
         double rho = 0; int qmax = 0;
         do {
             // backup, S = blockdiag(Hpp) + lambda I, bs = bp
+            if (lin) {
             for (int i = tid; i < 7 * nkf; i += BA_THREADS) poses_b[i] = poses[i];
             for (int i = tid; i < 3 * nlm; i += BA_THREADS) pts_b[i] = pts[i];
             for (int i = tid; i < np * np; i += BA_THREADS) {
                 int r = i / np, c = i - r * np;
                 double v = 0;
                 if (r / 6 == c / 6) v = Hpp[36 * (r / 6) + (r % 6) * 6 + (c % 6)];
-                if (r == c) v += lambda;
+                if (r == c && MODE == 0) v += lambda;          // shared map: added once, to the reduced system
                 S[(size_t)r * ld + c] = v;
             }
             for (int i = tid; i < np; i += BA_THREADS) bs[i] = bp[i];
+            }
             __syncthreads();
             BA_PROF(2);
             // ---- tile sweep: linearise the tile's landmarks into LDS, then fold the tile into S / bs
             double chi_part = 0;
-            for (int tl = 0; tl < ntile; ++tl) {
+            for (int tl = 0; lin && tl < ntile; ++tl) {
                 const int l0 = tile_lm[tl], l1 = tile_lm[tl + 1], bt0 = lm_bstart[l0];
                 // the tile's pair ranges and items go to LDS too: issued here, stored after the
                 // landmark work, so their latency hides behind it (the Schur pass then never
@@ -773,6 +803,17 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
             if (!have_chi) { currentChi = block_sum(chi_part, red, tid); have_chi = true; }
             tempChi = currentChi;
             BA_PROF(3);
+            if (MODE == 1 && sba.phase == 2) {                 // hand the partial sums to the host
+                for (int i = tid; i < np * np; i += BA_THREADS) sio_S[i] = S[(size_t)(i / np) * ld + (i % np)];
+                for (int i = tid; i < np; i += BA_THREADS) { sio_bs[i] = bs[i]; sio_bp[i] = bp[i]; }
+                if (tid == 0) sio_sc[0] = currentChi;
+                return;
+            }
+            if (MODE == 1) {                                   // phase 3: the reduced system comes back
+                for (int i = tid; i < np * np; i += BA_THREADS) S[(size_t)(i / np) * ld + (i % np)] = sio_S[i];
+                for (int i = tid; i < np; i += BA_THREADS) { bs[i] = sio_bs[i]; bp[i] = sio_bp[i]; }
+                __syncthreads();
+            }
             // ---- blocked (6x6 = one pose) right-looking Cholesky S = L L^T in LDS on the whole
             // workgroup; the right-hand side rides along as row np, so L y = bs comes out of the
             // same sweep; then L^T x = y on one wave.  Per block column: every thread factors the
@@ -888,7 +929,7 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
             __syncthreads();
             BA_PROF(4);
             const int ok2 = iflag[0];
-            double scale_part = 0;
+            double scale_part = 0, scale_pose_part = 0;
             if (ok2) {
                 // back-substitution with the Jacobians recomputed (the pose table still holds the
                 // linearisation point): dl = Dinv (bl - sum W^T dp) = -Dinv sum Jl^T w (r + Jp dp)
@@ -927,7 +968,12 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
                     const int k = act_kf[a];
                     double dT[7], Tn[7], x6[6];
 #pragma unroll
-                    for (int t = 0; t < 6; ++t) { x6[t] = xp[6 * a + t]; scale_part += x6[t] * (lambda * x6[t] + bp[6 * a + t]); }
+                    for (int t = 0; t < 6; ++t) {
+                        x6[t] = xp[6 * a + t];
+                        // shared map: every rank computes the same pose part; the host counts it once
+                        if (MODE == 0) scale_part += x6[t] * (lambda * x6[t] + bp[6 * a + t]);
+                        else scale_pose_part += x6[t] * (lambda * x6[t] + bp[6 * a + t]);
+                    }
                     d_se3_exp(x6, dT);
                     d_se3_mul(dT, poses + 7 * k, Tn);
 #pragma unroll
@@ -935,10 +981,15 @@ k_local_ba(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all,
                 }
             }
             double scale = block_sum(scale_part, red, tid);
+            const double scale_pose = MODE == 1 ? block_sum(scale_pose_part, red, tid) : 0.0;
             __syncthreads();
             BA_PROF(5);
             tempChi = error_pass();
             BA_PROF(6);
+            if (MODE == 1) {                                   // the host sums the partials and runs the rho test
+                if (tid == 0) { sio_sc[2] = (double)ok2; sio_sc[3] = scale; sio_sc[4] = scale_pose; sio_sc[5] = tempChi; }
+                return;
+            }
             if (!ok2) tempChi = 1.7976931348623157e308;
             rho = currentChi - tempChi;
             scale += 1e-3;

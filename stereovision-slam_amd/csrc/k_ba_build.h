@@ -59,7 +59,7 @@ static inline size_t bb_lds_bytes(int max_nlm)
 
 __global__ void __launch_bounds__(BB_THREADS)
 k_ba_build(BaDev *jobs, const int *obs_kf, const int *obs_lm, const uint8_t *obs_right, const float2 *obs_uv,
-           const int *srt_all, BaRec *recs_all, int *aux_all, int tile_cap, int max_nlm, int *err_flag)
+           const int *srt_all, BaRec *recs_all, int *aux_all, int tile_cap, int max_nlm, int *err_flag, int all_active)
 {
     extern __shared__ __attribute__((aligned(16))) int bb_lds[];
     BaDev &jd = jobs[blockIdx.x];
@@ -116,7 +116,8 @@ k_ba_build(BaDev *jobs, const int *obs_kf, const int *obs_lm, const uint8_t *obs
         for (int k = 0; k < nkf; ++k) {
             const int c = kcnt[k];
             g_kf_estart[k] = run;
-            if (c > 0) { pidx[k] = na; g_act_kf[na] = k; ++na; }
+            // shared-map BA: every keyframe takes part on every rank (a rank's shard may not see all of them)
+            if (c > 0 || all_active) { pidx[k] = na; g_act_kf[na] = k; ++na; }
             g_kf_pidx[k] = pidx[k];
             kcnt[k] = run;                // now: kf_estart
             run += c;

@@ -89,6 +89,9 @@ struct svslam_ctx {
     // a submitted, not yet collected local-BA batch owns the staging arena
     struct { bool active = false; int njobs = 0, total_kf = 0, total_lm = 0, total_obs = 0;
              size_t ojobs = 0, oposes = 0, opts = 0, ochi = 0, oflag = 0; } ba_pending;
+    // an open shared-map BA problem (svslam_sba_*): this rank's shard lives in the arena like a submitted batch
+    struct { bool open = false; int nkf = 0, nlm = 0, nobs = 0, np = 0; size_t ojobs = 0, ocams = 0, oposes = 0, opts = 0, orecs = 0,
+             oaux = 0, ochi = 0, oio = 0; double delta = 0; int launches = 0; } sba;
     // timing
     bool timing = false;
     Timing tm;
@@ -431,7 +434,9 @@ int svslam_create(const svslam_limits *lim, svslam_ctx **out)
         if (ba_tile_cap(lim->max_kf) < std::max(lim->max_kf, 64) || ba_lds_bytes(lim->max_kf) > 160 * 1024) return fail(c, "max_kf %d: reduced system does not fit LDS", lim->max_kf);
         if (ba_work_alloc(c->bw, lim->max_jobs, lim->max_kf, lim->max_lm, lim->max_obs) != hipSuccess)
             return fail(c, "BA workspace allocation failed");
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_local_ba),
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_local_ba_t<0>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ba_lds_bytes(lim->max_kf)));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_local_ba_t<1>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ba_lds_bytes(lim->max_kf)));
         if (bb_lds_bytes(lim->max_lm) > 160 * 1024 || lim->max_kf > 32)
             return fail(c, "max_lm %d / max_kf %d: problem structure does not fit LDS", lim->max_lm, lim->max_kf);
@@ -933,13 +938,13 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
     if (!c->ba_host_build) {
         hipLaunchKernelGGL(k_ba_build, dim3(njobs), dim3(BB_THREADS), bb_lds_bytes(max_nlm), c->stream, dp<BaDev>(c, ojobs),
                            dp<int>(c, okf_o), dp<int>(c, olm_o), dp<uint8_t>(c, ori_o), dp<float2>(c, ouv_o), dp<int>(c, osrt_o),
-                           dp<BaRec>(c, orecs), dp<int>(c, oaux), tile_cap, max_nlm, dp<int>(c, oflag));
+                           dp<BaRec>(c, orecs), dp<int>(c, oaux), tile_cap, max_nlm, dp<int>(c, oflag), 0);
         if (c->timing_split) { tm_end(c); tm_begin(c, FAM_DBG3, njobs); }
     }
-    hipLaunchKernelGGL(k_local_ba, dim3(njobs), dim3(BA_THREADS), ba_lds_bytes(c->lim.max_kf), c->stream,
+    hipLaunchKernelGGL(k_local_ba_t<0>, dim3(njobs), dim3(BA_THREADS), ba_lds_bytes(c->lim.max_kf), c->stream,
                        dp<BaDev>(c, ojobs), dp<BaCams>(c, ocams), dp<double>(c, oposes), dp<double>(c, opts),
                        dp<BaRec>(c, orecs), dp<int>(c, oaux), c->bw, huber_delta, iters, dp<double>(c, ochi), c->d_ba_prof,
-                       tile_cap);
+                       tile_cap, SbaArgs{ 0, 0, 0.0, nullptr });
     tm_end(c);
     HIPCHK(c, hipGetLastError());
     c->ba_pending.oflag = oflag;
@@ -980,6 +985,107 @@ int svslam_local_ba_batch(svslam_ctx *c, int njobs, svslam_ba_job *jobs, const d
                                         total_obs, obs_kf, obs_lm, obs_is_right, obs_uv, huber_delta, iters))
         return rc;
     return svslam_local_ba_collect(c, njobs, jobs, total_kf, poses, total_lm, pts, total_obs, edge_chi2);
+}
+
+// ------------------------------------------------------------------ shared-map BA (BASELINE config 5)
+// One problem, its landmarks sharded over the ranks of a node: this rank opens its shard (all K poses, its
+// landmarks and their edges), then drives the LM trial pieces of k_local_ba_t<1>; what has to be summed over
+// the ranks goes through `io` (host memory; the caller all-reduces it with RCCL).  See k_ba.h:SbaArgs.
+int svslam_sba_io_doubles(int nkf) { return (int)SBA_IO_DOUBLES(6 * nkf); }
+
+int svslam_sba_open(svslam_ctx *c, const double cam_l[4], const double ext_l[7], const double cam_r[4], const double ext_r[7],
+                    int nkf, const double *poses, int nlm, const double *pts, int nobs, const int *obs_kf, const int *obs_lm,
+                    const uint8_t *obs_is_right, const float *obs_uv, double huber_delta)
+{
+    if (c->ba_pending.active || c->sba.open) return fail(c, "sba_open: the context already holds a BA batch");
+    if (nkf < 1 || nkf > c->lim.max_kf || nlm < 1 || nlm > c->lim.max_lm || nobs < 1 || nobs > c->lim.max_obs)
+        return fail(c, "sba_open: shard exceeds limits or is empty (kf %d/%d lm %d/%d obs %d/%d)", nkf, c->lim.max_kf, nlm, c->lim.max_lm, nobs, c->lim.max_obs);
+    c->ar.reset();
+    const int tile_cap = ba_tile_cap(c->lim.max_kf);
+    const size_t TO = (size_t)nobs;
+    size_t ocams = c->ar.take(sizeof(BaCams));
+    size_t okf_o = c->ar.take(sizeof(int) * TO), olm_o = c->ar.take(sizeof(int) * TO), osrt_o = c->ar.take(sizeof(int) * TO);
+    size_t ouv_o = c->ar.take(sizeof(float) * 2 * TO), ori_o = c->ar.take(TO);
+    size_t ojobs = c->ar.take(sizeof(BaDev));
+    size_t oposes = c->ar.take(sizeof(double) * 7 * nkf);
+    size_t opts = c->ar.take(sizeof(double) * 3 * nlm);
+    size_t in_end = c->ar.off;
+    size_t ochi = c->ar.take(sizeof(double) * TO);
+    size_t oflag = c->ar.take(sizeof(int) * 4);
+    size_t oio = c->ar.take(sizeof(double) * SBA_IO_DOUBLES(6 * nkf));
+    size_t orecs = c->ar.take(sizeof(BaRec) * 2 * TO);
+    size_t oaux = c->ar.take(0);
+    BaCams *cams = hp<BaCams>(c, ocams);
+    memcpy(cams->cam[0], cam_l, 32); memcpy(cams->cam[1], cam_r, 32);
+    memcpy(cams->ext[0], ext_l, 56); memcpy(cams->ext[1], ext_r, 56);
+    int *srt = hp<int>(c, osrt_o);
+    bool sorted = true;
+    for (int e = 0; e < nobs; ++e) {
+        const int k = obs_kf[e], l = obs_lm[e];
+        if (k < 0 || k >= nkf || l < 0 || l >= nlm) return fail(c, "sba_open: edge %d index out of range", e);
+        if (e && !((obs_lm[e - 1] < l) || (obs_lm[e - 1] == l && obs_kf[e - 1] <= k))) sorted = false;
+        srt[e] = e;
+    }
+    if (!sorted) std::stable_sort(srt, srt + nobs, [&](int a, int b) { return obs_lm[a] != obs_lm[b] ? obs_lm[a] < obs_lm[b] : obs_kf[a] < obs_kf[b]; });
+    BaDev &d = *hp<BaDev>(c, ojobs);
+    d.kf_ofs = 0; d.nkf = nkf; d.lm_ofs = 0; d.nlm = nlm; d.obs_ofs = 0; d.nobs = nobs;
+    d.nblk = d.na = d.ncontrib = d.ntile = 0; d.iters_done = 0; d.rec_ofs = 0;
+    d.lay_nblk = nobs; d.lay_na = nkf; d.lay_ntile = ba_tile_bound(nlm, nobs, nkf, tile_cap);
+    d.aux_ofs = 0;
+    (void)c->ar.take(sizeof(int) * (ba_aux_layout(nkf, nlm, nobs, d.lay_nblk, d.lay_na, 0, d.lay_ntile).total + ba_pitem_bound(nobs, nkf)));
+    if (c->ar.off > c->ar.cap) return fail(c, "sba_open: staging arena too small");
+    memcpy(hp<void>(c, okf_o), obs_kf, sizeof(int) * TO); memcpy(hp<void>(c, olm_o), obs_lm, sizeof(int) * TO);
+    memcpy(hp<void>(c, ouv_o), obs_uv, sizeof(float) * 2 * TO); memcpy(hp<void>(c, ori_o), obs_is_right, TO);
+    memcpy(hp<void>(c, oposes), poses, sizeof(double) * 7 * nkf);
+    memcpy(hp<void>(c, opts), pts, sizeof(double) * 3 * nlm);
+    hp<int>(c, oflag)[0] = 0;
+    if (h2d(c, 0, in_end)) return -1;
+    if (h2d(c, oflag, oflag + sizeof(int) * 4)) return -1;
+    hipLaunchKernelGGL(k_ba_build, dim3(1), dim3(BB_THREADS), bb_lds_bytes(nlm), c->stream, dp<BaDev>(c, ojobs), dp<int>(c, okf_o),
+                       dp<int>(c, olm_o), dp<uint8_t>(c, ori_o), dp<float2>(c, ouv_o), dp<int>(c, osrt_o), dp<BaRec>(c, orecs),
+                       dp<int>(c, oaux), tile_cap, nlm, dp<int>(c, oflag), 1 /* every keyframe active on every rank */);
+    HIPCHK(c, hipGetLastError());
+    if (d2h_sync(c, oflag, oflag + sizeof(int) * 4)) return -1;
+    if (hp<int>(c, oflag)[0]) return fail(c, "sba_open: the structure build overflowed a capacity");
+    c->sba.open = true; c->sba.nkf = nkf; c->sba.nlm = nlm; c->sba.nobs = nobs; c->sba.np = 6 * nkf;
+    c->sba.ojobs = ojobs; c->sba.ocams = ocams; c->sba.oposes = oposes; c->sba.opts = opts; c->sba.orecs = orecs; c->sba.oaux = oaux;
+    c->sba.ochi = ochi; c->sba.oio = oio; c->sba.delta = huber_delta; c->sba.launches = 0;
+    return 0;
+}
+
+// phase: 1 diagonal (lambda_0), 2 linearise at lambda, 3 solve with the reduced system in io + update + errors,
+//        4 reject (restore), 5 finalise.  io: svslam_sba_io_doubles(nkf) doubles, in for phase 3, out for 1-3.
+int svslam_sba_phase(svslam_ctx *c, int phase, double lambda, double *io)
+{
+    if (!c->sba.open) return fail(c, "sba_phase: no shard is open");
+    if (phase < 1 || phase > 5) return fail(c, "sba_phase: phase %d", phase);
+    const size_t nio = SBA_IO_DOUBLES(c->sba.np) * sizeof(double);
+    if (phase == 3) { memcpy(hp<void>(c, c->sba.oio), io, nio); if (h2d(c, c->sba.oio, c->sba.oio + nio)) return -1; }
+    else HIPCHK(c, hipMemsetAsync(dp<void>(c, c->sba.oio), 0, nio, c->stream));
+    SbaArgs a{ phase, c->sba.launches == 0 ? 1 : 0, lambda, dp<double>(c, c->sba.oio) };
+    tm_begin(c, FAM_BA, 1);
+    hipLaunchKernelGGL(k_local_ba_t<1>, dim3(1), dim3(BA_THREADS), ba_lds_bytes(c->lim.max_kf), c->stream, dp<BaDev>(c, c->sba.ojobs),
+                       dp<BaCams>(c, c->sba.ocams), dp<double>(c, c->sba.oposes), dp<double>(c, c->sba.opts), dp<BaRec>(c, c->sba.orecs),
+                       dp<int>(c, c->sba.oaux), c->bw, c->sba.delta, 1, dp<double>(c, c->sba.ochi), (long long *)nullptr,
+                       ba_tile_cap(c->lim.max_kf), a);
+    tm_end(c);
+    HIPCHK(c, hipGetLastError());
+    c->sba.launches++;
+    if (d2h_sync(c, c->sba.oio, c->sba.oio + nio)) return -1;
+    if (io && phase <= 3) memcpy(io, hp<void>(c, c->sba.oio), nio);
+    return 0;
+}
+
+// poses of all keyframes, the shard's landmark positions and per-edge chi2 (after phase 5); closes the shard
+int svslam_sba_close(svslam_ctx *c, double *poses, double *pts, double *edge_chi2)
+{
+    if (!c->sba.open) return fail(c, "sba_close: no shard is open");
+    c->sba.open = false;
+    if (d2h_sync(c, c->sba.oposes, c->sba.ochi + sizeof(double) * (size_t)c->sba.nobs)) return -1;
+    if (poses) memcpy(poses, hp<void>(c, c->sba.oposes), sizeof(double) * 7 * c->sba.nkf);
+    if (pts) memcpy(pts, hp<void>(c, c->sba.opts), sizeof(double) * 3 * c->sba.nlm);
+    if (edge_chi2) memcpy(edge_chi2, hp<void>(c, c->sba.ochi), sizeof(double) * c->sba.nobs);
+    return 0;
 }
 
 // number of host threads the library may use to prepare batched calls (BA structure

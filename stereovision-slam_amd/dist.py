@@ -40,6 +40,19 @@ class Rank:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
 
+    def allreduce(self, arr, op="sum"):
+        """element-wise sum / max of a float64 numpy vector over the ranks (RCCL on GPUs, gloo in the CPU tests)"""
+        import numpy as np
+        a = np.ascontiguousarray(arr, np.float64)
+        if self.dist is None:
+            return a.copy()
+        import torch
+        t = torch.from_numpy(a.copy())
+        if self.device:
+            t = t.to(self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM if op == "sum" else self.dist.ReduceOp.MAX)
+        return t.cpu().numpy()
+
     def close(self):
         if self.dist is not None:
             self.dist.destroy_process_group()
