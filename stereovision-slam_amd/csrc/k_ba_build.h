@@ -51,15 +51,22 @@ __device__ __forceinline__ int bb_exscan(int *a, int n, int *tmp, int tid)
     return total;
 }
 
-// LDS ints needed for a batch whose largest problem has max_nlm landmarks
-static inline size_t bb_lds_bytes(int max_nlm)
+// LDS ints needed for a batch whose largest problem has max_nlm landmarks (and, when it still fits, one packed
+// word per edge: the edges' landmark / keyframe / camera are then read from global memory once)
+static inline size_t bb_lds_ints(int max_nlm)
 {
-    return ((size_t)6 * ((size_t)max_nlm + 2) + (size_t)BB_MAXKEYS * BB_THREADS + BB_THREADS + 4 * BB_MAXKEYS + 64) * sizeof(int);
+    return (size_t)6 * ((size_t)max_nlm + 2) + (size_t)BB_MAXKEYS * BB_THREADS + BB_THREADS + 5 * BB_MAXKEYS + 64;
+}
+static inline bool bb_edge_cache_fits(int max_nlm, int max_nobs) { return (bb_lds_ints(max_nlm) + (size_t)max_nobs) * sizeof(int) <= 150 * 1024; }
+static inline size_t bb_lds_bytes(int max_nlm, int max_nobs = 0)
+{
+    return (bb_lds_ints(max_nlm) + (bb_edge_cache_fits(max_nlm, max_nobs) ? (size_t)max_nobs : 0)) * sizeof(int);
 }
 
 __global__ void __launch_bounds__(BB_THREADS)
 k_ba_build(BaDev *jobs, const int *obs_kf, const int *obs_lm, const uint8_t *obs_right, const float2 *obs_uv,
-           const int *srt_all, BaRec *recs_all, int *aux_all, int tile_cap, int max_nlm, int *err_flag, int all_active)
+           const int *srt_all, BaRec *recs_all, int *aux_all, int tile_cap, int max_nlm, int *err_flag, int all_active,
+           int edge_cache)
 {
     extern __shared__ __attribute__((aligned(16))) int bb_lds[];
     BaDev &jd = jobs[blockIdx.x];
@@ -92,7 +99,26 @@ k_ba_build(BaDev *jobs, const int *obs_kf, const int *obs_lm, const uint8_t *obs
     int *tmp = flat + BB_MAXKEYS * BB_THREADS;   // [BB_THREADS]
     int *kcnt = tmp + BB_THREADS;         // [BB_MAXKEYS] edges per keyframe, then kf_estart
     int *pidx = kcnt + BB_MAXKEYS;        // [BB_MAXKEYS]
-    int *small = pidx + BB_MAXKEYS;       // scalars: 0 maxc, 1 na, 2 ntile, 3 ncontrib
+    int *small = pidx + BB_MAXKEYS;       // scalars: 0 maxc, 1 na, 2 ntile, 3 ncontrib; + 8: active pose -> keyframe
+    unsigned int *ed = reinterpret_cast<unsigned int *>(small + 8 + BB_MAXKEYS + 8);   // [nobs] landmark | keyframe << 16 | camera << 24, sorted order
+    // the edges' indices, read from global memory ONCE (independent, coalesced loads, four in flight per thread)
+    if (edge_cache) {
+        for (int i0 = tid; i0 < nobs; i0 += 4 * BB_THREADS) {
+            int e4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = i0 + u * BB_THREADS; e4[u] = i < nobs ? srt[i] : 0; }
+            unsigned int v4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v4[u] = (unsigned int)olm[e4[u]] | ((unsigned int)okf[e4[u]] << 16) | ((ori[e4[u]] ? 1u : 0u) << 24);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = i0 + u * BB_THREADS; if (i < nobs) ed[i] = v4[u]; }
+        }
+    }
+    auto edge = [&](int i) -> unsigned int {
+        if (edge_cache) return ed[i];
+        const int e = srt[i];
+        return (unsigned int)olm[e] | ((unsigned int)okf[e] << 16) | ((ori[e] ? 1u : 0u) << 24);
+    };
 
     for (int l = tid; l <= nlm; l += BB_THREADS) { cnt[l] = 0; }
     if (tid < BB_MAXKEYS) { kcnt[tid] = 0; pidx[tid] = -1; }
@@ -101,9 +127,10 @@ k_ba_build(BaDev *jobs, const int *obs_kf, const int *obs_lm, const uint8_t *obs
     // ---- 1. edge ranges per landmark (the edges arrive landmark-major through srt), blocks per landmark,
     //         edges per keyframe
     for (int i = tid; i < nobs; i += BB_THREADS) {
-        const int e = srt[i], l = olm[e], k = okf[e];
+        const unsigned int ev = edge(i);
+        const int l = (int)(ev & 0xffffu), k = (int)((ev >> 16) & 0xffu);
         int lp = -1, kp = -1;
-        if (i > 0) { const int ep = srt[i - 1]; lp = olm[ep]; kp = okf[ep]; }
+        if (i > 0) { const unsigned int pv = edge(i - 1); lp = (int)(pv & 0xffffu); kp = (int)((pv >> 16) & 0xffu); }
         if (l != lp) for (int q = lp + 1; q <= l; ++q) ostart[q] = i;
         if (i == nobs - 1) for (int q = l + 1; q <= nlm; ++q) ostart[q] = nobs;
         if (l != lp || k != kp) atomicAdd(&cnt[l], 1);
@@ -169,13 +196,14 @@ k_ba_build(BaDev *jobs, const int *obs_kf, const int *obs_lm, const uint8_t *obs
         int i = lm_es[jn], b = lm_bs[jn] - 1, prev_kf = -1;
         unsigned int mask = 0;
         for (int q = ostart[l]; q < ostart[l + 1]; ++q, ++i) {
-            const int e = srt[q], k = okf[e];
+            const unsigned int ev = edge(q);
+            const int e = srt[q], k = (int)((ev >> 16) & 0xffu);
             if (k != prev_kf) { ++b; g_blk_kf[b] = k; g_blk_lm[b] = jn; prev_kf = k; mask |= 1u << pidx[k]; }
             g_lm_edges[i] = e;
             const float2 uv = ouv[e];
             BaRec r;
             r.u = uv.x; r.v = uv.y;
-            r.lmkc = jn | (((pidx[k] << 1) | (ori[e] ? 1 : 0)) << 24);
+            r.lmkc = jn | (((pidx[k] << 1) | (int)(ev >> 24)) << 24);
             r.blk = b;
             recL[i] = r;
         }
@@ -185,37 +213,47 @@ k_ba_build(BaDev *jobs, const int *obs_kf, const int *obs_lm, const uint8_t *obs
     // ---- 6. pose-major copy of the records, landmark-ascending inside a pose: stable partition of the
     //         landmark-major order by keyframe, again as a flattened [keyframe][thread] scan
     {
+        // (the keyframe of record i is read back from the record itself — active-pose index -> keyframe through
+        // LDS — instead of through two dependent global loads per edge)
         const int eper = (nobs + BB_THREADS - 1) / BB_THREADS;
         const int i0 = min(tid * eper, nobs), i1 = min(i0 + eper, nobs);
+        int *actk = small + 8;                    // [BB_MAXKEYS] active pose -> keyframe
+        if (tid < BB_MAXKEYS) actk[tid] = tid < na ? g_act_kf[tid] : 0;
         for (int k = 0; k < nkf; ++k) flat[k * BB_THREADS + tid] = 0;
-        for (int i = i0; i < i1; ++i) flat[okf[g_lm_edges[i]] * BB_THREADS + tid]++;
+        __syncthreads();
+        for (int i = i0; i < i1; ++i) flat[actk[(unsigned)recL[i].lmkc >> 25] * BB_THREADS + tid]++;
         __syncthreads();
         bb_exscan(flat, nkf * BB_THREADS, tmp, tid);
         for (int i = i0; i < i1; ++i) {
-            const int k = okf[g_lm_edges[i]];
-            recP[flat[k * BB_THREADS + tid]++] = recL[i];
+            const BaRec r = recL[i];
+            recP[flat[actk[(unsigned)r.lmkc >> 25] * BB_THREADS + tid]++] = r;
         }
     }
-    // ---- 7. LDS tiles: greedy packing of consecutive landmarks under two capacities (sequential by nature)
+    // ---- 7. LDS tiles: greedy packing of consecutive landmarks under two capacities (landmarks and blocks).
+    //         Both running counts are monotone in the landmark index, so the end of a tile that starts at s is
+    //         min(s + cap, first e with lm_bs[e] - lm_bs[s] > cap): a binary search per tile instead of a
+    //         walk over every landmark (the walk was a third of this kernel's time)
+    const int lay_ntile = jd.lay_ntile;
     if (tid == 0) {
-        int nt = 0, nl_t = 0, nb_t = 0;
+        int nt = 0, st = 0;
         g_tile_lm[0] = 0;
-        for (int l = 0; l < nlm; ++l) {
-            const int k = lm_bs[l + 1] - lm_bs[l];
-            if (nl_t + 1 > tile_cap || nb_t + k > tile_cap) {
-                ++nt;
-                if (nt <= jd.lay_ntile) g_tile_lm[nt] = l;
-                nl_t = 0; nb_t = 0;
+        while (st < nlm) {
+            const int lim = lm_bs[st] + tile_cap;
+            int lo = st + 1, hi = min(st + tile_cap, nlm);        // the tile ends in (st, hi]; lm_bs[lo] - lm_bs[st] <= cap holds for lo = st + 1
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (lm_bs[mid] <= lim) lo = mid; else hi = mid - 1;
             }
-            ++nl_t; nb_t += k;
+            st = lo;
+            ++nt;
+            if (nt <= lay_ntile) g_tile_lm[nt] = st;
         }
-        ++nt;
-        if (nt <= jd.lay_ntile) g_tile_lm[nt] = nlm; else atomicExch(err_flag, 1);
+        if (nt > lay_ntile) atomicExch(err_flag, 1);
         small[2] = nt;
     }
     __syncthreads();
     const int ntile = small[2];
-    if (ntile > jd.lay_ntile) return;
+    if (ntile > lay_ntile) return;
     // ---- 8. block pairs of every (tile, pose pair): one thread per list walks the tile's landmarks;
     //         a landmark that sees poses a and b contributes the pair of its blocks popcount(mask below a / b)
     const int nlist = ntile * npairs;
@@ -228,7 +266,8 @@ k_ba_build(BaDev *jobs, const int *obs_kf, const int *obs_lm, const uint8_t *obs
             while (rem >= na - a) { rem -= na - a; ++a; }
             const unsigned int need = (1u << a) | (1u << (a + rem));
             int c = 0;
-            for (int l = g_tile_lm[t]; l < g_tile_lm[t + 1]; ++l) c += ((unsigned int)pmask[l] & need) == need;
+            const int lt0 = g_tile_lm[t], lt1 = g_tile_lm[t + 1];
+            for (int l = lt0; l < lt1; ++l) c += ((unsigned int)pmask[l] & need) == need;
             flat[q] = c;
         }
         __syncthreads();
@@ -242,9 +281,9 @@ k_ba_build(BaDev *jobs, const int *obs_kf, const int *obs_lm, const uint8_t *obs
             while (rem >= na - a) { rem -= na - a; ++a; }
             const int b2 = a + rem;
             const unsigned int need = (1u << a) | (1u << b2);
-            const int l0 = g_tile_lm[t], bt0 = lm_bs[l0];
+            const int l0 = g_tile_lm[t], l1 = g_tile_lm[t + 1], bt0 = lm_bs[l0];
             int w = base + flat[q];
-            for (int l = l0; l < g_tile_lm[t + 1]; ++l) {
+            for (int l = l0; l < l1; ++l) {
                 const unsigned int m = (unsigned int)pmask[l];
                 if ((m & need) != need) continue;
                 const int u = lm_bs[l] - bt0 + __popc(m & ((1u << a) - 1u));

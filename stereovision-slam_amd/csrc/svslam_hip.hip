@@ -441,7 +441,7 @@ int svslam_create(const svslam_limits *lim, svslam_ctx **out)
         if (bb_lds_bytes(lim->max_lm) > 160 * 1024 || lim->max_kf > 32)
             return fail(c, "max_lm %d / max_kf %d: problem structure does not fit LDS", lim->max_lm, lim->max_kf);
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_build),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bb_lds_bytes(lim->max_lm)));
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     if (lim->max_streams > 0) {
         const size_t n = (size_t)lim->max_streams * lim->max_pts;
@@ -852,7 +852,7 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
     BaDev *dj = hp<BaDev>(c, ojobs);
     hp<int>(c, oflag)[0] = 0;
     size_t aux_total = 0;
-    int max_nlm = 1;
+    int max_nlm = 1, max_nobs = 1;
     if (c->ba_host_build) {
         // Host-side structure of every problem (edge records, blocks, pose-pair lists), built by the
         // pool with one scratch structure per thread (stays cache-hot) and written straight into the
@@ -916,7 +916,7 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
             d.lay_nblk = j.nobs; d.lay_na = j.nkf; d.lay_ntile = ba_tile_bound(j.nlm, j.nobs, j.nkf, tile_cap);
             d.aux_ofs = (int)at;
             at += ba_aux_layout(j.nkf, j.nlm, j.nobs, d.lay_nblk, d.lay_na, 0, d.lay_ntile).total + ba_pitem_bound(j.nobs, j.nkf);
-            max_nlm = std::max(max_nlm, j.nlm);
+            max_nlm = std::max(max_nlm, j.nlm); max_nobs = std::max(max_nobs, j.nobs);
         }
         aux_total = at;
         (void)c->ar.take(sizeof(int) * aux_total);
@@ -936,9 +936,10 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
     if (c->ba_host_build) { if (h2d(c, orecs, c->ar.off)) return -1; }
     tm_begin(c, c->timing_split ? FAM_DBG2 : FAM_BA, njobs);
     if (!c->ba_host_build) {
-        hipLaunchKernelGGL(k_ba_build, dim3(njobs), dim3(BB_THREADS), bb_lds_bytes(max_nlm), c->stream, dp<BaDev>(c, ojobs),
+        hipLaunchKernelGGL(k_ba_build, dim3(njobs), dim3(BB_THREADS), bb_lds_bytes(max_nlm, max_nobs), c->stream, dp<BaDev>(c, ojobs),
                            dp<int>(c, okf_o), dp<int>(c, olm_o), dp<uint8_t>(c, ori_o), dp<float2>(c, ouv_o), dp<int>(c, osrt_o),
-                           dp<BaRec>(c, orecs), dp<int>(c, oaux), tile_cap, max_nlm, dp<int>(c, oflag), 0);
+                           dp<BaRec>(c, orecs), dp<int>(c, oaux), tile_cap, max_nlm, dp<int>(c, oflag), 0,
+                           bb_edge_cache_fits(max_nlm, max_nobs) && c->lim.max_lm < 65536 ? 1 : 0);
         if (c->timing_split) { tm_end(c); tm_begin(c, FAM_DBG3, njobs); }
     }
     hipLaunchKernelGGL(k_local_ba_t<0>, dim3(njobs), dim3(BA_THREADS), ba_lds_bytes(c->lim.max_kf), c->stream,
@@ -1041,9 +1042,10 @@ int svslam_sba_open(svslam_ctx *c, const double cam_l[4], const double ext_l[7],
     hp<int>(c, oflag)[0] = 0;
     if (h2d(c, 0, in_end)) return -1;
     if (h2d(c, oflag, oflag + sizeof(int) * 4)) return -1;
-    hipLaunchKernelGGL(k_ba_build, dim3(1), dim3(BB_THREADS), bb_lds_bytes(nlm), c->stream, dp<BaDev>(c, ojobs), dp<int>(c, okf_o),
+    hipLaunchKernelGGL(k_ba_build, dim3(1), dim3(BB_THREADS), bb_lds_bytes(nlm, nobs), c->stream, dp<BaDev>(c, ojobs), dp<int>(c, okf_o),
                        dp<int>(c, olm_o), dp<uint8_t>(c, ori_o), dp<float2>(c, ouv_o), dp<int>(c, osrt_o), dp<BaRec>(c, orecs),
-                       dp<int>(c, oaux), tile_cap, nlm, dp<int>(c, oflag), 1 /* every keyframe active on every rank */);
+                       dp<int>(c, oaux), tile_cap, nlm, dp<int>(c, oflag), 1 /* every keyframe active on every rank */,
+                       bb_edge_cache_fits(nlm, nobs) && c->lim.max_lm < 65536 ? 1 : 0);
     HIPCHK(c, hipGetLastError());
     if (d2h_sync(c, oflag, oflag + sizeof(int) * 4)) return -1;
     if (hp<int>(c, oflag)[0]) return fail(c, "sba_open: the structure build overflowed a capacity");
