@@ -27,12 +27,16 @@ for p_ in (ROOT, os.path.join(ROOT, "tests")):
 W, H = 620, 188
 
 
-def run(n_streams=48, n_frames=320, seed0=0x5EED1000, chunk=80, threads=None, device=0):
-    """returns dict(ate_hip, ate_twin, ate_between, path_len) as arrays over streams"""
+def run(n_streams=48, n_frames=320, seed0=0x5EED1000, chunk=80, threads=None, device=0, twin_jacobians="numeric"):
+    """returns dict(ate_hip, ate_twin, ate_between, path_len) as arrays over streams.  twin_jacobians: "numeric"
+    (g2o's central differences, what the reference runs) or "analytic" (isolates the effect of that choice)"""
     import pipe_cpu
     svs = importlib.import_module("stereovision-slam_amd")
     pl = importlib.import_module("stereovision-slam_amd.pipeline")
-    os.environ.pop("SVS_ORACLE_BA_JAC", None)                     # twin: numeric Jacobians (reference-faithful)
+    if twin_jacobians == "analytic":
+        os.environ["SVS_ORACLE_BA_JAC"] = "0"
+    else:
+        os.environ.pop("SVS_ORACLE_BA_JAC", None)                 # twin: numeric Jacobians (reference-faithful)
     seeds = [seed0 + i for i in range(n_streams)]
     threads = threads or max(1, min(n_streams, len(os.sched_getaffinity(0))))
     gpu = pl.Pipeline(pl.default_config(W, H, host_threads=min(4, threads)), nstreams=n_streams, device=device)
@@ -91,11 +95,11 @@ def bootstrap(a_hip, a_twin, n_boot=20000, seed=1):
     return float(d0), float(lo), float(hi), float(d.std())
 
 
-def report(r, n_frames):
+def report(r, n_frames, twin="reference-faithful CPU twin (numeric-J BA)"):
     a, b, L = r["ate_hip"], r["ate_twin"], r["path_len"]
     d, lo, hi, se = bootstrap(a, b)
-    lines = ["ATE distribution, HIP pipeline vs reference-faithful CPU twin (numeric-J BA), %d streams x %d frames "
-             "(%.0f m mean path), config-00 parameters" % (len(a), n_frames, L.mean()),
+    lines = ["ATE distribution, HIP pipeline vs %s, %d streams x %d frames "
+             "(%.0f m mean path), config-00 parameters" % (twin, len(a), n_frames, L.mean()),
              "%-28s %10s %10s" % ("", "HIP", "CPU twin"),
              "%-28s %10.4f %10.4f" % ("mean ATE [m]", a.mean(), b.mean()),
              "%-28s %10.4f %10.4f" % ("median ATE [m]", np.median(a), np.median(b)),
@@ -118,5 +122,12 @@ if __name__ == "__main__":
     nf = int(sys.argv[2]) if len(sys.argv) > 2 else 320
     res = run(ns, nf)
     print(report(res, nf))
-    print("per-stream ATE [m] hip / twin:")
+    if "--analytic-too" in sys.argv:
+        # the same streams against the twin with ANALYTIC BA Jacobians: what is left is the chaos of two
+        # equally valid runs, the difference to the line above is the numeric differentiation of g2o
+        res2 = run(ns, nf, twin_jacobians="analytic")
+        print()
+        print(report(res2, nf, "CPU twin with analytic BA Jacobians"))
+    print()
+    print("per-stream ATE [m] hip / twin (numeric-J):")
     print(" ".join("%.3f/%.3f" % (x, y) for x, y in zip(res["ate_hip"], res["ate_twin"])))
