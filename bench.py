@@ -348,6 +348,10 @@ def main():
                                     "frac_of_peak_per_gpu": round(all_bytes / elapsed / 1e9 / HBM_PEAK_GBS, 6),
                                     "algorithmic_bytes_per_frame": round(all_bytes / max(cnt["frames"], 1), 1)},
             "kernel_ms": {f: round(fam_t[f][0], 3) for f in fam_t},
+            # unit counts since process start (pre-roll and warm-up included): what a PMC pass over the whole
+            # process divides its per-kernel totals by (tools/pmc_traffic.sh)
+            "units_whole_process": {k: c1[k] for k in ("frames", "keyframes", "ba_calls", "gftt_calls", "pyr_left", "pyr_right",
+                                                       "track_pts", "right_pts", "tri_pts", "pose_edges") if k in c1},
             "host_ms_per_step": {"in_step": round(cnt["ns_step"] / 1e6 / K / G, 3),
                                  "in_abi_calls": round(cnt["ns_kernel_calls"] / 1e6 / K / G, 3),
                                  "h2d_enqueue": round(hostns[0] / 1e6 / K / G, 3), "d2h_enqueue": round(hostns[1] / 1e6 / K / G, 3),

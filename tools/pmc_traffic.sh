@@ -24,8 +24,28 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         out[ctr + "_bench"] = json.loads(open("gpurun_out/pmc_%s_bench.json" % ctr).read().strip().splitlines()[-1])["config"]
     except Exception as e:
         out[ctr + "_bench"] = str(e)
+# per unit of work: a PMC pass sees the whole process, so divide by the unit counts of the whole process
+# that bench.py reports (units_whole_process); KB -> bytes (x1024, the counter's documented unit)
+try:
+    u = json.loads(open("gpurun_out/pmc_FETCH_SIZE_bench.json").read().strip().splitlines()[-1])["units_whole_process"]
+    fam = {"local_ba": (["k_local_ba_t<0>", "k_ba_build"], "job", u["ba_calls"]),
+           "lk": (["k_lk"], "point", u["track_pts"] + u["right_pts"]),
+           "pose_only": (["k_pose_only<1>", "k_pose_only<0>"], "job", u["frames"]),
+           "pyramid": (["k_pyr_fused<false>", "k_pyr_fused<true>"], "image", u["pyr_left"] + u["pyr_right"]),
+           "gftt": (["k_gftt_eig3<false>", "k_gftt_select2"], "image", u["gftt_calls"]),
+           "triangulate": (["k_triangulate"], "point", u["tri_pts"])}
+    per = {}
+    for f, (ks, unit, n) in fam.items():
+        fb = sum(out["FETCH_SIZE"].get(k, {}).get("total_KB", 0.0) for k in ks) * 1024 / max(n, 1)
+        wb = sum(out["WRITE_SIZE"].get(k, {}).get("total_KB", 0.0) for k in ks) * 1024 / max(n, 1)
+        per[f] = {"unit": unit, "units_in_run": n, "kernels": ks, "fetch_bytes": round(fb), "write_bytes": round(wb), "bytes": round(fb + wb)}
+    out["per_unit"] = per
+    out["units_whole_process"] = u
+except Exception as e:
+    out["per_unit"] = "unavailable: %r" % (e,)
 json.dump(out, open("gpurun_out/pmc_traffic_raw.json", "w"), indent=1)
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     print(ctr, {k: v["KB_per_launch"] for k, v in out[ctr].items()})
+print("per unit", out["per_unit"])
 PY
 rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE

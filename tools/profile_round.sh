@@ -19,4 +19,5 @@ timeout 300 python tools/kbench.py tput > $O/kbench_tput.txt 2>&1 < /dev/null
 timeout 900 python tools/ate_distribution.py 384 320 --analytic-too > $O/ate_distribution.txt 2> $O/ate_distribution.err < /dev/null
 timeout 900 bash tools/pmc_traffic.sh > $O/pmc_traffic.log 2>&1 < /dev/null
 cp gpurun_out/pmc_traffic_raw.json $O/ 2>/dev/null
+timeout 600 bash tools/lat.sh > $O/latency_small_S.txt 2>&1 < /dev/null
 tail -c 400 $O/bench_default.json; echo; head -12 $O/kernel_stats.csv | cut -c1-120; head -8 $O/ate_distribution.txt; tail -3 $O/pmc_traffic.log | cut -c1-600
