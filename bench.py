@@ -61,7 +61,7 @@ def measured_traffic(fam, cnt, launches):
     if not t or not t.get("bytes"):
         return None
     units = {"local_ba": cnt["ba_calls"], "lk": cnt["track_pts"] + cnt["right_pts"], "pose_only": cnt["frames"],
-             "gftt": cnt["gftt_calls"]}.get(fam)
+             "gftt": cnt["gftt_calls"], "pyramid": cnt["pyr_left"] + cnt["pyr_right"], "triangulate": cnt["tri_pts"]}.get(fam)
     if not units or not launches:
         return None
     return t["bytes"] * units / launches
