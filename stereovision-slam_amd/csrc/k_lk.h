@@ -147,7 +147,15 @@ __device__ __forceinline__ float lk_sum_to_f32(long long s, float scale)
     return (float)t * __uint_as_float(kb);
 }
 
-__global__ void __launch_bounds__(64 * LK_WAVES_PER_BLOCK)
+#ifndef LK_OCC_TEST
+#define LK_OCC_TEST 0       // development: 1 = force 8 waves per SIMD, 2 = pad LDS down to 4 waves per SIMD
+#endif
+#if LK_OCC_TEST == 1
+#define LK_OCC_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
+#else
+#define LK_OCC_ATTR
+#endif
+__global__ void __launch_bounds__(64 * LK_WAVES_PER_BLOCK) LK_OCC_ATTR
 k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, float2 *next_xy,
      uint8_t *status, float *err, LkParams prm)
 {
@@ -155,6 +163,11 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
     __shared__ uint32_t sD_all[LK_WAVES_PER_BLOCK][144];
     __shared__ uint32_t sJ_all[LK_WAVES_PER_BLOCK][LK_REG * LK_REG / 4 + 8];
 
+#if LK_OCC_TEST == 2
+    __shared__ uint32_t sPad[8192];
+    sPad[threadIdx.x] = threadIdx.x;
+    if (prm.max_count < 0) status[0] = (uint8_t)sPad[(threadIdx.x * 37) & 8191];
+#endif
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const LkJob jb = jobs[blockIdx.y];
     const int pi = blockIdx.x * LK_WAVES_PER_BLOCK + wave;
