@@ -76,14 +76,19 @@ struct LkW { uint32_t top, bot; };   // (w00 | w01 << 16), (w10 | w11 << 16); w1
 
 __device__ __forceinline__ LkW lk_weights(float a, float b)
 {
-    // cvRound == round-half-even == rintf
-    const int w00 = (int)rintf((1.f - a) * (1.f - b) * (float)(1 << LK_W_BITS));
-    const int w01 = (int)rintf(a * (1.f - b) * (float)(1 << LK_W_BITS));
-    const int w10 = (int)rintf((1.f - a) * b * (float)(1 << LK_W_BITS));
-    const int w11 = (1 << LK_W_BITS) - w00 - w01 - w10;
+    // OpenCV: w = cvRound(x * (1 << W_BITS)) with x = (1-a)(1-b), a(1-b), (1-a)b and cvRound == round-half-even.
+    // Scaling by 2^14 commutes with every f32 rounding here (no under- or overflow), so the scale goes onto a
+    // first: A = 2^14 a (exact), 2^14 - A == fl(2^14 (1 - a)) == 2^14 fl(1 - a).  Round-half-even to an integer
+    // in [0, 2^14] is one f32 add of 1.5 * 2^23: the integer sits in the low mantissa bits of the sum, and the
+    // low 16 bits of the magic constant are zero, so the Q14 halves are packed straight from the float bits.
+    const float S = (float)(1 << LK_W_BITS), M = 12582912.f;                  // M = 0x4B400000
+    const float A = a * S, An = S - A, bn = 1.f - b;
+    const uint32_t b00 = __float_as_uint(An * bn + M), b01 = __float_as_uint(A * bn + M), b10 = __float_as_uint(An * b + M);
+    // w11 = 2^14 - w00 - w01 - w10 (may be -1, kept signed in its 16-bit half)
+    const uint32_t w11 = ((1u << LK_W_BITS) + 3u * 0x4B400000u) - (b00 + b01 + b10);
     LkW w;
-    w.top = ((uint32_t)w00 & 0xffffu) | ((uint32_t)w01 << 16);
-    w.bot = ((uint32_t)w10 & 0xffffu) | ((uint32_t)w11 << 16);
+    w.top = __builtin_amdgcn_perm(b01, b00, 0x05040100u);
+    w.bot = __builtin_amdgcn_perm(w11, b10, 0x05040100u);
     return w;
 }
 
@@ -147,6 +152,22 @@ __device__ __forceinline__ float lk_sum_to_f32(long long s, float scale)
     return (float)t * __uint_as_float(kb);
 }
 
+// Wave totals of two int32 lane values whose sums of absolute values fit int32: the first butterfly step
+// sends each lane's "other" value to its xor-1 neighbour, so the remaining three DPP steps carry both sums at
+// once (sum a in the lanes with bit0 ^ bit2 == 0, sum b in the others; that predicate is invariant under
+// xor 2, half-mirror and mirror and flips under xor 1).  5 + 8 VALU instead of 8 + 8 plus a 64-bit scalar tail.
+__device__ __forceinline__ void lk_wave_sum2_i32(int a, int b, bool second, int &sa, int &sb)
+{
+    int v = (second ? b : a) + dpp_i32<SVS_DPP_XOR1>(second ? a : b);
+    v += dpp_i32<SVS_DPP_XOR2>(v);
+    v += dpp_i32<SVS_DPP_HALF_MIRROR>(v);
+    v += dpp_i32<SVS_DPP_MIRROR>(v);
+    sa = (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) +
+         (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
+    sb = (__builtin_amdgcn_readlane(v, 1) + __builtin_amdgcn_readlane(v, 17)) +
+         (__builtin_amdgcn_readlane(v, 33) + __builtin_amdgcn_readlane(v, 49));
+}
+
 #ifndef LK_OCC_TEST
 #define LK_OCC_TEST 0       // development: 1 = force 8 waves per SIMD, 2 = pad LDS down to 4 waves per SIMD
 #endif
@@ -197,6 +218,10 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
     // Scharr work split: lanes 0..47 -> row lane/4, columns 3*(lane%4) .. +2
     const int sr = lane >> 2, sc = (lane & 3) * 3;
     const float FLT_SCALE = 1.f / (float)(1 << 20);
+    const bool second = ((lane ^ (lane >> 2)) & 1) != 0;       // lk_wave_sum2_i32
+    // f32 brackets of the f64 termination test dx^2 + dy^2 <= eps2: the f32 evaluation is within 2^-22
+    // relative of the f64 one, so outside (e_lo, e_hi) it decides; inside, the f64 test runs
+    const float e_lo = (float)(prm.eps2 * (1.0 - 2e-6)), e_hi = (float)(prm.eps2 * (1.0 + 2e-6));
 
     int max_level = prm.max_level;
     if (max_level > g.nlevels - 1) max_level = g.nlevels - 1;
@@ -300,6 +325,11 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
             continue;
         }
         D = 1.f / D;
+        // |d| <= 8160 (Q5 difference of two u8 interpolations): if 8160 * sum|Ix| and 8160 * sum|Iy| stay below
+        // 2^31 the b sums and all their partial sums fit int32 (always, short of adversarial patches)
+        int sAx, sAy;
+        lk_wave_sum2_i32((ix0 < 0 ? -ix0 : ix0) + (ix1 < 0 ? -ix1 : ix1), (iy0 < 0 ? -iy0 : iy0) + (iy1 < 0 ? -iy1 : iy1), second, sAx, sAy);
+        const bool narrow = sAx <= 263000 && sAy <= 263000;
         const int acc00 = (1 << (LK_W_BITS - 5 - 1)) - (iv0 << (LK_W_BITS - 5)), acc01 = (1 << (LK_W_BITS - 5 - 1)) - (iv1 << (LK_W_BITS - 5));
         nx -= 5.f; ny -= 5.f;
         float pdx = 0.f, pdy = 0.f;
@@ -324,14 +354,21 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
             // |d| < 2^14, |Ix|,|Iy| < 2^13: 24-bit multiplies, 16-lane row sums fit int32
             const int pb1 = __mul24(d0, ix0) + __mul24(d1, ix1);
             const int pb2 = __mul24(d0, iy0) + __mul24(d1, iy1);
-            const long long sb1 = wave_sum_i32_wide(pb1);
-            const long long sb2 = wave_sum_i32_wide(pb2);
-            const float b1 = lk_sum_to_f32(sb1, FLT_SCALE), b2 = lk_sum_to_f32(sb2, FLT_SCALE);
+            float b1, b2;
+            if (narrow) {
+                int s1, s2;
+                lk_wave_sum2_i32(pb1, pb2, second, s1, s2);
+                b1 = (float)s1 * FLT_SCALE; b2 = (float)s2 * FLT_SCALE;
+            } else {
+                b1 = lk_sum_to_f32(wave_sum_i32_wide(pb1), FLT_SCALE); b2 = lk_sum_to_f32(wave_sum_i32_wide(pb2), FLT_SCALE);
+            }
             const float dx = (A12 * b2 - A22 * b1) * D;
             const float dy = (A12 * b1 - A11 * b2) * D;
             nx += dx; ny += dy;
             nextp.x = nx + 5.f; nextp.y = ny + 5.f;
-            if ((double)dx * (double)dx + (double)dy * (double)dy <= prm.eps2) break;
+            const float dd2 = dx * dx + dy * dy;
+            if (dd2 < e_lo) break;
+            if (dd2 <= e_hi && (double)dx * (double)dx + (double)dy * (double)dy <= prm.eps2) break;
             // (double)|v| < 0.01  <=>  |v| <= 0.01f  (0.01f is the largest float below 0.01)
             if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
                 nextp.x -= dx * 0.5f; nextp.y -= dy * 0.5f;
