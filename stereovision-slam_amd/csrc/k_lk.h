@@ -36,6 +36,10 @@ struct LkParams {
     double eps2;
     double min_eig_thr;
     int use_initial_flow;
+    // smallest float x with (double)(x / (2 * 121)) >= min_eig_thr (the quotient is monotone in x), so the
+    // min-eigenvalue test is one compare; eig_use_div = 1 keeps the division (threshold search did not settle)
+    float eig_num_thr;
+    int eig_use_div;
 };
 
 #define LK_WIN 11
@@ -114,28 +118,44 @@ __device__ __forceinline__ int lk_sample_diff(const uint32_t *base32, int a, int
     return lk_dot2(t, w.top, lk_dot2(b, w.bot, acc0)) >> (LK_W_BITS - 5);
 }
 
-__device__ __forceinline__ void lk_stage_J(uint32_t *sJ, const uint8_t *J0, int pitch, int w, int h,
-                                           int cx, int cy, int lane, int &rx0, int &ry0)
+// The 32x32 J search region around (cx, cy), one dword per lane and row octet: loads issued here ...
+struct LkJRegs { uint32_t v[4]; };
+__device__ __forceinline__ LkJRegs lk_stage_J_issue(const uint8_t *J0, int pitch, int w, int h,
+                                                    int cx, int cy, int lane, int &rx0, int &ry0)
 {
     rx0 = __builtin_amdgcn_readfirstlane((cx - 10) & ~3);
     ry0 = __builtin_amdgcn_readfirstlane(cy - 10);
     const int r = lane >> 3, c4 = lane & 7;
+    LkJRegs o;
     if (rx0 >= -SVS_BORDER && rx0 + LK_REG <= w + SVS_BORDER && ry0 >= -SVS_BORDER && ry0 + LK_REG <= h + SVS_BORDER) {
         const uint8_t *p = J0 + (ptrdiff_t)(ry0 + r) * pitch + (rx0 + c4 * 4);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            sJ[lane + 64 * k] = *reinterpret_cast<const uint32_t *>(p + (ptrdiff_t)(8 * k) * pitch);
+            o.v[k] = *reinterpret_cast<const uint32_t *>(p + (ptrdiff_t)(8 * k) * pitch);
     } else {
         const int gxmax = (w + SVS_BORDER - 4) & ~3;
         const int gx = max(-SVS_BORDER, min(rx0 + c4 * 4, gxmax));
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int gy = max(-SVS_BORDER, min(ry0 + r + 8 * k, h + SVS_BORDER - 1));
-            sJ[lane + 64 * k] = *reinterpret_cast<const uint32_t *>(J0 + (ptrdiff_t)gy * pitch + gx);
+            o.v[k] = *reinterpret_cast<const uint32_t *>(J0 + (ptrdiff_t)gy * pitch + gx);
         }
     }
+    return o;
+}
+// ... and written to LDS here, so that the latency of the loads hides behind whatever sits in between
+__device__ __forceinline__ void lk_stage_J_commit(uint32_t *sJ, const LkJRegs &o, int lane)
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sJ[lane + 64 * k] = o.v[k];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void lk_stage_J(uint32_t *sJ, const uint8_t *J0, int pitch, int w, int h,
+                                           int cx, int cy, int lane, int &rx0, int &ry0)
+{
+    const LkJRegs o = lk_stage_J_issue(J0, pitch, w, h, cx, cy, lane, rx0, ry0);
+    lk_stage_J_commit(sJ, o, lane);
 }
 
 // (float)s * scale for a wave-uniform 64-bit sum, |s| < 2^32 (121 x 8160 x 4080), scale a power of
@@ -168,6 +188,22 @@ __device__ __forceinline__ void lk_wave_sum2_i32(int a, int b, bool second, int 
          (__builtin_amdgcn_readlane(v, 33) + __builtin_amdgcn_readlane(v, 49));
 }
 
+// Four wave totals at once: after the xor-1 step a lane carries two of the four sums, after the xor-2 step
+// one (a: p = q = 0, b: q only, c: p only, d: both; p = bit0 ^ bit2 flips under xor 1 only, q = bit1 ^ bit2
+// under xor 2 only, both are invariant under half-mirror and mirror).  5 DPP adds instead of 16.
+__device__ __forceinline__ void lk_wave_sum4_i32(int a, int b, int c, int d, bool p, bool q, int &sa, int &sb, int &sc, int &sd)
+{
+    const int v0 = (p ? c : a) + dpp_i32<SVS_DPP_XOR1>(p ? a : c);
+    const int v1 = (p ? d : b) + dpp_i32<SVS_DPP_XOR1>(p ? b : d);
+    int v = (q ? v1 : v0) + dpp_i32<SVS_DPP_XOR2>(q ? v0 : v1);
+    v += dpp_i32<SVS_DPP_HALF_MIRROR>(v);
+    v += dpp_i32<SVS_DPP_MIRROR>(v);
+    sa = (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) + (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
+    sb = (__builtin_amdgcn_readlane(v, 2) + __builtin_amdgcn_readlane(v, 18)) + (__builtin_amdgcn_readlane(v, 34) + __builtin_amdgcn_readlane(v, 50));
+    sc = (__builtin_amdgcn_readlane(v, 1) + __builtin_amdgcn_readlane(v, 17)) + (__builtin_amdgcn_readlane(v, 33) + __builtin_amdgcn_readlane(v, 49));
+    sd = (__builtin_amdgcn_readlane(v, 3) + __builtin_amdgcn_readlane(v, 19)) + (__builtin_amdgcn_readlane(v, 35) + __builtin_amdgcn_readlane(v, 51));
+}
+
 #ifndef LK_OCC_TEST
 #define LK_OCC_TEST 0       // development: 1 = force 8 waves per SIMD, 2 = pad LDS down to 4 waves per SIMD
 #endif
@@ -180,7 +216,7 @@ __global__ void __launch_bounds__(64 * LK_WAVES_PER_BLOCK) LK_OCC_ATTR
 k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, float2 *next_xy,
      uint8_t *status, float *err, LkParams prm)
 {
-    __shared__ uint32_t sI_all[LK_WAVES_PER_BLOCK][14 * LK_IROW / 4 + 2];
+    __shared__ uint32_t sI_all[LK_WAVES_PER_BLOCK][16 * LK_IROW / 4 + 2];     // 14 rows used, 16 staged
     __shared__ uint32_t sD_all[LK_WAVES_PER_BLOCK][144];
     __shared__ uint32_t sJ_all[LK_WAVES_PER_BLOCK][LK_REG * LK_REG / 4 + 8];
 
@@ -218,7 +254,8 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
     // Scharr work split: lanes 0..47 -> row lane/4, columns 3*(lane%4) .. +2
     const int sr = lane >> 2, sc = (lane & 3) * 3;
     const float FLT_SCALE = 1.f / (float)(1 << 20);
-    const bool second = ((lane ^ (lane >> 2)) & 1) != 0;       // lk_wave_sum2_i32
+    const bool second = ((lane ^ (lane >> 2)) & 1) != 0;       // lk_wave_sum2_i32 / lk_wave_sum4_i32 (p)
+    const bool second_q = (((lane >> 1) ^ (lane >> 2)) & 1) != 0;
     // f32 brackets of the f64 termination test dx^2 + dy^2 <= eps2: the f32 evaluation is within 2^-22
     // relative of the f64 one, so outside (e_lo, e_hi) it decides; inside, the f64 test runs
     const float e_lo = (float)(prm.eps2 * (1.0 - 2e-6)), e_hi = (float)(prm.eps2 * (1.0 + 2e-6));
@@ -230,7 +267,7 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
         const int w = g.w[level], h = g.h[level], pitch = g.pitch[level];
         const uint8_t *I0 = lvl_origin(slotI, g, level);
         const uint8_t *J0 = lvl_origin(slotJ, g, level);
-        const float lscale = 1.f / (float)(1 << level);
+        const float lscale = __uint_as_float((uint32_t)(127 - level) << 23);     // 2^-level
         float px = prevp.x * lscale, py = prevp.y * lscale;
         float nx, ny;
         if (level == max_level) {
@@ -241,7 +278,8 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
 
         px -= 5.f; py -= 5.f;
         const int ipx = __builtin_amdgcn_readfirstlane(lk_floor_i(px)), ipy = __builtin_amdgcn_readfirstlane(lk_floor_i(py));
-        if (ipx < -LK_WIN || ipx >= w || ipy < -LK_WIN || ipy >= h) {
+        const uint32_t wext = (uint32_t)(w + LK_WIN), hext = (uint32_t)(h + LK_WIN);     // -11 <= v < len as one unsigned compare
+        if ((uint32_t)(ipx + LK_WIN) >= wext || (uint32_t)(ipy + LK_WIN) >= hext) {
             if (level == 0) { st = false; errv = 0.f; }
             continue;
         }
@@ -250,13 +288,19 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
         // 1. stage I neighbourhood: rows ipy-1..ipy+12, 20 bytes from the aligned column xs <= ipx-1
         const int xs = (ipx - 1) & ~3, a0 = (ipx - 1) & 3;   // patch byte (r, c) lives at r*LK_IROW + a0 + c
         __builtin_amdgcn_wave_barrier();
+        // every lane loads (16 rows x 4 dwords, then the fifth dword of row lane % 16: rows 14, 15 and the
+        // duplicates are never read) — no exec masking; the J region of this level's start position follows
+        // at once so that both load latencies overlap
+        nx -= 5.f; ny -= 5.f;
+        int rx0, ry0;
+        LkJRegs jr;
         {
             const uint8_t *Ib = I0 + (ptrdiff_t)(ipy - 1) * pitch + xs;
-            uint32_t v0 = 0, v1 = 0;
-            if (lane < 56) v0 = *reinterpret_cast<const uint32_t *>(Ib + (ptrdiff_t)(lane >> 2) * pitch + (lane & 3) * 4);
-            if (lane < 14) v1 = *reinterpret_cast<const uint32_t *>(Ib + (ptrdiff_t)lane * pitch + 16);
-            if (lane < 56) sI32[(lane >> 2) * (LK_IROW / 4) + (lane & 3)] = v0;
-            if (lane < 14) sI32[lane * (LK_IROW / 4) + 4] = v1;
+            const uint32_t v0 = *reinterpret_cast<const uint32_t *>(Ib + (ptrdiff_t)(lane >> 2) * pitch + (lane & 3) * 4);
+            const uint32_t v1 = *reinterpret_cast<const uint32_t *>(Ib + (ptrdiff_t)(lane & 15) * pitch + 16);
+            jr = lk_stage_J_issue(J0, pitch, w, h, lk_floor_i(nx), lk_floor_i(ny), lane, rx0, ry0);
+            sI32[(lane >> 2) * (LK_IROW / 4) + (lane & 3)] = v0;
+            sI32[(lane & 15) * (LK_IROW / 4) + 4] = v1;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -313,37 +357,36 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
                           lk_dot2(__builtin_amdgcn_perm(d11, d10, 0x07060302u), iw.bot, 1 << (LK_W_BITS - 1))) >> LK_W_BITS;
             if (!has1) { ix1 = 0; iy1 = 0; }
         }
-        const int sA11 = wave_sum_i32(__mul24(ix0, ix0) + __mul24(ix1, ix1));
-        const int sA12 = wave_sum_i32(__mul24(ix0, iy0) + __mul24(ix1, iy1));
-        const int sA22 = wave_sum_i32(__mul24(iy0, iy0) + __mul24(iy1, iy1));
+        // A sums (exact: 121 x 4080^2 < 2^31) and sum(|Ix| + |Iy|) for the width of the b sums below
+        int sA11, sA12, sA22, sAbs;
+        lk_wave_sum4_i32(__mul24(ix0, ix0) + __mul24(ix1, ix1), __mul24(ix0, iy0) + __mul24(ix1, iy1), __mul24(iy0, iy0) + __mul24(iy1, iy1),
+                         ((ix0 < 0 ? -ix0 : ix0) + (ix1 < 0 ? -ix1 : ix1)) + ((iy0 < 0 ? -iy0 : iy0) + (iy1 < 0 ? -iy1 : iy1)),
+                         second, second_q, sA11, sA12, sA22, sAbs);
         const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         const float dd = A11 - A22;
-        const float minEig = (A22 + A11 - sqrtf(dd * dd + 4.f * A12 * A12)) / (float)(2 * LK_WIN * LK_WIN);
-        if ((double)minEig < prm.min_eig_thr || D < 1.1920928955078125e-07f) {
+        const float eigNum = A22 + A11 - sqrtf(dd * dd + 4.f * A12 * A12);
+        const bool eigSmall = prm.eig_use_div ? (double)(eigNum / (float)(2 * LK_WIN * LK_WIN)) < prm.min_eig_thr : eigNum < prm.eig_num_thr;
+        if (eigSmall || D < 1.1920928955078125e-07f) {
             if (level == 0) st = false;
             continue;
         }
         D = 1.f / D;
-        // |d| <= 8160 (Q5 difference of two u8 interpolations): if 8160 * sum|Ix| and 8160 * sum|Iy| stay below
-        // 2^31 the b sums and all their partial sums fit int32 (always, short of adversarial patches)
-        int sAx, sAy;
-        lk_wave_sum2_i32((ix0 < 0 ? -ix0 : ix0) + (ix1 < 0 ? -ix1 : ix1), (iy0 < 0 ? -iy0 : iy0) + (iy1 < 0 ? -iy1 : iy1), second, sAx, sAy);
-        const bool narrow = sAx <= 263000 && sAy <= 263000;
+        // |d| <= 8160 (Q5 difference of two u8 interpolations): if 8160 * sum(|Ix| + |Iy|) stays below 2^31 the
+        // b sums and all their partial sums fit int32 (always, short of adversarial patches)
+        const bool narrow = sAbs <= 263000;
         const int acc00 = (1 << (LK_W_BITS - 5 - 1)) - (iv0 << (LK_W_BITS - 5)), acc01 = (1 << (LK_W_BITS - 5 - 1)) - (iv1 << (LK_W_BITS - 5));
-        nx -= 5.f; ny -= 5.f;
         float pdx = 0.f, pdy = 0.f;
-        int rx0, ry0;
-        lk_stage_J(sJ, J0, pitch, w, h, lk_floor_i(nx), lk_floor_i(ny), lane, rx0, ry0);
+        lk_stage_J_commit(sJ, jr, lane);
 
         for (int j = 0; j < prm.max_count; ++j) {
             const int inx = __builtin_amdgcn_readfirstlane(lk_floor_i(nx)), iny = __builtin_amdgcn_readfirstlane(lk_floor_i(ny));
-            if (inx < -LK_WIN || inx >= w || iny < -LK_WIN || iny >= h) {
+            if ((uint32_t)(inx + LK_WIN) >= wext || (uint32_t)(iny + LK_WIN) >= hext) {
                 if (level == 0) st = false;
                 break;
             }
             int ox = inx - rx0, oy = iny - ry0;
-            if (ox < 0 || ox > LK_REG - 12 || oy < 0 || oy > LK_REG - 12) {
+            if ((uint32_t)ox > LK_REG - 12 || (uint32_t)oy > LK_REG - 12) {
                 lk_stage_J(sJ, J0, pitch, w, h, inx, iny, lane, rx0, ry0);
                 ox = inx - rx0; oy = iny - ry0;
             }

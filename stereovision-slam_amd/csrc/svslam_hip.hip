@@ -602,6 +602,16 @@ static LkParams make_lk_params(const svslam_lk_params *p)
     k.eps2 = eps * eps;
     k.min_eig_thr = p ? p->min_eig_thr : 1e-4;
     k.use_initial_flow = p ? p->use_initial_flow : 1;
+    // k_lk tests the min eigenvalue as numerator < x* instead of (double)(numerator / 242.f) < thr: x* is the
+    // smallest float whose quotient reaches the threshold (float division is monotone), found by stepping
+    const float den = (float)(2 * LK_WIN * LK_WIN);
+    float x = (float)(k.min_eig_thr * (double)den);
+    int steps = 0;
+    bool ok = std::isfinite(x) && k.min_eig_thr > 1e-30;
+    while (ok && (double)(x / den) >= k.min_eig_thr) { x = std::nextafterf(x, -INFINITY); if (++steps > 64) ok = false; }
+    while (ok && (double)(x / den) < k.min_eig_thr) { x = std::nextafterf(x, INFINITY); if (++steps > 128) ok = false; }
+    k.eig_num_thr = x;
+    k.eig_use_div = ok ? 0 : 1;
     return k;
 }
 
