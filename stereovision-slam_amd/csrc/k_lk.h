@@ -56,7 +56,11 @@ typedef short lk_s2 __attribute__((ext_vector_type(2)));
 // a.lo*b.lo + a.hi*b.hi + c on signed 16-bit halves (v_dot2_i32_i16): one bilinear tap pair
 __device__ __forceinline__ int lk_dot2(uint32_t a, uint32_t b, int c)
 {
-    return __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_s2, a), __builtin_bit_cast(lk_s2, b), c, false);
+    // the three-source form: the compiler's choice (v_dot2c, accumulator == destination) costs a v_mov per tap
+    // pair whenever the accumulator is a loop-invariant constant
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
 // Bytes (a, a+1) of an LDS byte array, any a, widened to two u16 halves: one aligned
 // ds_read2_b32 + one v_perm_b32 with the per-lane selector lk_pair_sel(a).
@@ -118,9 +122,22 @@ __device__ __forceinline__ int lk_sample_diff(const uint32_t *base32, int a, int
     return lk_dot2(t, w.top, lk_dot2(b, w.bot, acc0)) >> (LK_W_BITS - 5);
 }
 
+// The same with the tap's LDS BYTE ADDRESS given (array base + byte offset folded into one per-lane constant
+// by the caller): aligned dword address and byte selector both come from that one value.
+typedef const __attribute__((address_space(3))) uint32_t *lk_lds_u32;
+__device__ __forceinline__ int lk_sample_diff_at(uint32_t addr, LkW w, int acc0)
+{
+    const uint32_t sel = LK_PAIR_SEL0 + (addr & 3u) * 0x00010001u;
+    lk_lds_u32 q = (lk_lds_u32)(uintptr_t)(addr & ~3u);
+    const uint32_t t = __builtin_amdgcn_perm(q[1], q[0], sel), b = __builtin_amdgcn_perm(q[LK_REG / 4 + 1], q[LK_REG / 4], sel);
+    return lk_dot2(t, w.top, lk_dot2(b, w.bot, acc0)) >> (LK_W_BITS - 5);
+}
+
 // The 32x32 J search region around (cx, cy), one dword per lane and row octet: loads issued here ...
 struct LkJRegs { uint32_t v[4]; };
-__device__ __forceinline__ LkJRegs lk_stage_J_issue(const uint8_t *J0, int pitch, int w, int h,
+// J0 = slot base, lofs = byte offset of the level's pixel (0, 0) inside the slot: all per-lane address
+// arithmetic stays in 32 bits (uniform 64-bit base + unsigned 32-bit lane offset = the saddr form of global_load)
+__device__ __forceinline__ LkJRegs lk_stage_J_issue(const uint8_t *J0, uint32_t lofs, int pitch, int w, int h,
                                                     int cx, int cy, int lane, int &rx0, int &ry0)
 {
     rx0 = __builtin_amdgcn_readfirstlane((cx - 10) & ~3);
@@ -128,17 +145,17 @@ __device__ __forceinline__ LkJRegs lk_stage_J_issue(const uint8_t *J0, int pitch
     const int r = lane >> 3, c4 = lane & 7;
     LkJRegs o;
     if (rx0 >= -SVS_BORDER && rx0 + LK_REG <= w + SVS_BORDER && ry0 >= -SVS_BORDER && ry0 + LK_REG <= h + SVS_BORDER) {
-        const uint8_t *p = J0 + (ptrdiff_t)(ry0 + r) * pitch + (rx0 + c4 * 4);
+        const uint32_t p = lofs + (uint32_t)((ry0 + r) * pitch + (rx0 + c4 * 4));
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            o.v[k] = *reinterpret_cast<const uint32_t *>(p + (ptrdiff_t)(8 * k) * pitch);
+            o.v[k] = *reinterpret_cast<const uint32_t *>(J0 + (p + (uint32_t)(8 * k * pitch)));
     } else {
         const int gxmax = (w + SVS_BORDER - 4) & ~3;
         const int gx = max(-SVS_BORDER, min(rx0 + c4 * 4, gxmax));
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int gy = max(-SVS_BORDER, min(ry0 + r + 8 * k, h + SVS_BORDER - 1));
-            o.v[k] = *reinterpret_cast<const uint32_t *>(J0 + (ptrdiff_t)gy * pitch + gx);
+            o.v[k] = *reinterpret_cast<const uint32_t *>(J0 + (lofs + (uint32_t)(gy * pitch + gx)));
         }
     }
     return o;
@@ -151,10 +168,10 @@ __device__ __forceinline__ void lk_stage_J_commit(uint32_t *sJ, const LkJRegs &o
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
-__device__ __forceinline__ void lk_stage_J(uint32_t *sJ, const uint8_t *J0, int pitch, int w, int h,
+__device__ __forceinline__ void lk_stage_J(uint32_t *sJ, const uint8_t *J0, uint32_t lofs, int pitch, int w, int h,
                                            int cx, int cy, int lane, int &rx0, int &ry0)
 {
-    const LkJRegs o = lk_stage_J_issue(J0, pitch, w, h, cx, cy, lane, rx0, ry0);
+    const LkJRegs o = lk_stage_J_issue(J0, lofs, pitch, w, h, cx, cy, lane, rx0, ry0);
     lk_stage_J_commit(sJ, o, lane);
 }
 
@@ -251,6 +268,9 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
     const int oI0 = (wy0 + 1) * LK_IROW + wx0 + 1, oI1 = (wy1 + 1) * LK_IROW + wx1 + 1;
     const int oD0 = wy0 * 12 + wx0, oD1 = wy1 * 12 + wx1;
     const int oJ0 = wy0 * LK_REG + wx0, oJ1 = wy1 * LK_REG + wx1;
+    // LDS byte addresses of this lane's two window pixels at search-region offset 0
+    const uint32_t aJ0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)sJ + (uint32_t)oJ0,
+                   aJ1 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)sJ + (uint32_t)oJ1;
     // Scharr work split: lanes 0..47 -> row lane/4, columns 3*(lane%4) .. +2
     const int sr = lane >> 2, sc = (lane & 3) * 3;
     const float FLT_SCALE = 1.f / (float)(1 << 20);
@@ -265,8 +285,8 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
 
     for (int level = max_level; level >= 0; --level) {
         const int w = g.w[level], h = g.h[level], pitch = g.pitch[level];
-        const uint8_t *I0 = lvl_origin(slotI, g, level);
-        const uint8_t *J0 = lvl_origin(slotJ, g, level);
+        // pixel (0, 0) of the level as a 32-bit offset into the slot (both slots share the geometry)
+        const uint32_t lofs = (uint32_t)g.ofs[level] + (uint32_t)(SVS_BORDER * pitch + SVS_BORDER);
         const float lscale = __uint_as_float((uint32_t)(127 - level) << 23);     // 2^-level
         float px = prevp.x * lscale, py = prevp.y * lscale;
         float nx, ny;
@@ -295,10 +315,10 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
         int rx0, ry0;
         LkJRegs jr;
         {
-            const uint8_t *Ib = I0 + (ptrdiff_t)(ipy - 1) * pitch + xs;
-            const uint32_t v0 = *reinterpret_cast<const uint32_t *>(Ib + (ptrdiff_t)(lane >> 2) * pitch + (lane & 3) * 4);
-            const uint32_t v1 = *reinterpret_cast<const uint32_t *>(Ib + (ptrdiff_t)(lane & 15) * pitch + 16);
-            jr = lk_stage_J_issue(J0, pitch, w, h, lk_floor_i(nx), lk_floor_i(ny), lane, rx0, ry0);
+            const uint32_t ib = lofs + (uint32_t)((ipy - 1) * pitch + xs);     // >= 0: the stored border covers rows >= -16
+            const uint32_t v0 = *reinterpret_cast<const uint32_t *>(slotI + (ib + (uint32_t)((lane >> 2) * pitch + (lane & 3) * 4)));
+            const uint32_t v1 = *reinterpret_cast<const uint32_t *>(slotI + (ib + (uint32_t)((lane & 15) * pitch + 16)));
+            jr = lk_stage_J_issue(slotJ, lofs, pitch, w, h, lk_floor_i(nx), lk_floor_i(ny), lane, rx0, ry0);
             sI32[(lane >> 2) * (LK_IROW / 4) + (lane & 3)] = v0;
             sI32[(lane & 15) * (LK_IROW / 4) + 4] = v1;
         }
@@ -325,15 +345,14 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
                     t1[k] = c - a;
                 }
             }
-            const int gy = ipy + sr;
-            const bool rowin = gy >= 0 && gy < h;
+            const bool rowin = (uint32_t)(ipy + sr) < (uint32_t)h;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                int dx = t0[k + 2] - t0[k];
-                int dy = (t1[k + 2] + t1[k]) * 3 + t1[k + 1] * 10;
-                const int gx = ipx + sc + k;
-                if (!(rowin && gx >= 0 && gx < w)) { dx = 0; dy = 0; }
-                sD[sr * 12 + sc + k] = ((uint32_t)dx & 0xffffu) | ((uint32_t)dy << 16);
+                const int dx = t0[k + 2] - t0[k];
+                const int dy = (t1[k + 2] + t1[k]) * 3 + t1[k + 1] * 10;
+                // zero outside the image: a select on the packed pair, no divergent branch
+                const uint32_t inb = 0u - (uint32_t)(rowin & ((uint32_t)(ipx + sc + k) < (uint32_t)w));
+                sD[sr * 12 + sc + k] = (((uint32_t)dx & 0xffffu) | ((uint32_t)dy << 16)) & inb;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -357,11 +376,10 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
                           lk_dot2(__builtin_amdgcn_perm(d11, d10, 0x07060302u), iw.bot, 1 << (LK_W_BITS - 1))) >> LK_W_BITS;
             if (!has1) { ix1 = 0; iy1 = 0; }
         }
-        // A sums (exact: 121 x 4080^2 < 2^31) and sum(|Ix| + |Iy|) for the width of the b sums below
-        int sA11, sA12, sA22, sAbs;
-        lk_wave_sum4_i32(__mul24(ix0, ix0) + __mul24(ix1, ix1), __mul24(ix0, iy0) + __mul24(ix1, iy1), __mul24(iy0, iy0) + __mul24(iy1, iy1),
-                         ((ix0 < 0 ? -ix0 : ix0) + (ix1 < 0 ? -ix1 : ix1)) + ((iy0 < 0 ? -iy0 : iy0) + (iy1 < 0 ? -iy1 : iy1)),
-                         second, second_q, sA11, sA12, sA22, sAbs);
+        // A sums (exact: 121 x 4080^2 < 2^31); the fourth lane of the butterfly is idle
+        int sA11, sA12, sA22, sIdle;
+        lk_wave_sum4_i32(__mul24(ix0, ix0) + __mul24(ix1, ix1), __mul24(ix0, iy0) + __mul24(ix1, iy1), __mul24(iy0, iy0) + __mul24(iy1, iy1), 0,
+                         second, second_q, sA11, sA12, sA22, sIdle);
         const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         const float dd = A11 - A22;
@@ -372,9 +390,10 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
             continue;
         }
         D = 1.f / D;
-        // |d| <= 8160 (Q5 difference of two u8 interpolations): if 8160 * sum(|Ix| + |Iy|) stays below 2^31 the
-        // b sums and all their partial sums fit int32 (always, short of adversarial patches)
-        const bool narrow = sAbs <= 263000;
+        // |d| <= 8160 (Q5 difference of two u8 interpolations), so |b| and all its partial sums stay below
+        // 8160 * sum|Ix| <= 8160 * 11 * sqrt(sum Ix^2) (Cauchy-Schwarz over the 121 pixels): with sum Ix^2 and
+        // sum Iy^2 <= 5.7e8 that is < 2^31 and the b sums fit int32 (always, short of adversarial patches)
+        const bool narrow = sA11 <= 570000000 && sA22 <= 570000000;
         const int acc00 = (1 << (LK_W_BITS - 5 - 1)) - (iv0 << (LK_W_BITS - 5)), acc01 = (1 << (LK_W_BITS - 5 - 1)) - (iv1 << (LK_W_BITS - 5));
         float pdx = 0.f, pdy = 0.f;
         lk_stage_J_commit(sJ, jr, lane);
@@ -387,13 +406,13 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
             }
             int ox = inx - rx0, oy = iny - ry0;
             if ((uint32_t)ox > LK_REG - 12 || (uint32_t)oy > LK_REG - 12) {
-                lk_stage_J(sJ, J0, pitch, w, h, inx, iny, lane, rx0, ry0);
+                lk_stage_J(sJ, slotJ, lofs, pitch, w, h, inx, iny, lane, rx0, ry0);
                 ox = inx - rx0; oy = iny - ry0;
             }
             const LkW jw = lk_weights(nx - (float)inx, ny - (float)iny);
-            const int jo = oy * LK_REG + ox;
-            const int d0 = lk_sample_diff(sJ, jo + oJ0, LK_REG, jw, acc00);
-            const int d1 = lk_sample_diff(sJ, jo + oJ1, LK_REG, jw, acc01);
+            const uint32_t jo = (uint32_t)(oy * LK_REG + ox);
+            const int d0 = lk_sample_diff_at(aJ0 + jo, jw, acc00);
+            const int d1 = lk_sample_diff_at(aJ1 + jo, jw, acc01);
             // |d| < 2^14, |Ix|,|Iy| < 2^13: 24-bit multiplies, 16-lane row sums fit int32
             const int pb1 = __mul24(d0, ix0) + __mul24(d1, ix1);
             const int pb2 = __mul24(d0, iy0) + __mul24(d1, iy1);
@@ -430,7 +449,7 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
             }
             int ox = inx - rx0, oy = iny - ry0;
             if (ox < 0 || ox > LK_REG - 12 || oy < 0 || oy > LK_REG - 12) {
-                lk_stage_J(sJ, J0, pitch, w, h, inx, iny, lane, rx0, ry0);
+                lk_stage_J(sJ, slotJ, lofs, pitch, w, h, inx, iny, lane, rx0, ry0);
                 ox = inx - rx0; oy = iny - ry0;
             }
             const LkW jw = lk_weights(fx - (float)inx, fy - (float)iny);
