@@ -50,6 +50,7 @@
 #define BA_MAX_NP 192
 #define BA_PIT_CAP 2048          // block-pair items of a tile staged in LDS (more are read from global)
 #define BA_TILE_MAX 480             // landmarks and (pose, landmark) blocks per LDS tile of the Schur sweep
+#define BB_MAXKEYS 33               // keys of the landmark renumbering sort (k_ba_build.h keeps [key][thread] counters in LDS)
 
 struct BaJob { int kf_ofs, nkf, lm_ofs, nlm, obs_ofs, nobs, iters_done, reserved; };
 struct BaCams { double cam[2][4]; double ext[2][7]; };
@@ -68,6 +69,9 @@ struct BaDev {               // device-side job descriptor (built on the host)
     int rec_ofs;             // offset (records) of this job's 2*nobs records: landmark-major, then pose-major
     int lay_nblk, lay_na, lay_ntile;   // counts the aux LAYOUT was reserved for: the actual ones (host build) or
                                        // their upper bounds (device build, k_ba_build.h)
+    int nmv;                 // landmarks [0, nmv) (internal numbering) go through the LDS tiles; the single-view
+                             // landmarks behind them are grouped by pose (sv_start) and folded in by the row pass
+    int reserved;
 };
 
 struct BaWork {              // per-job HBM scratch, strided by the context limits
@@ -99,10 +103,10 @@ static inline void ba_work_free(BaWork &w) { if (w.all) (void)hipFree(w.all); w.
 // ---------------------------------------------------------------- host-side structure
 // aux layout per job (ints), offsets from ba_aux_layout():
 //   lm_estart[nlm+1] lm_edges[nobs] kf_estart[nkf+1] lm_orig[nlm]
-//   lm_bstart[nlm+1] blk_kf[nblk] blk_lm[nblk] kf_pidx[nkf] act_kf[nkf]
+//   lm_bstart[nlm+1] blk_kf[nblk] blk_lm[nblk] kf_pidx[nkf] act_kf[nkf] sv_start[nkf+1]
 //   tile_lm[ntile+1]  pcs[ntile*npairs+1]  pitem[ncontrib] (y | w << 10 | landmark << 20, tile-local)
 struct BaAuxLayout {
-    size_t lm_estart, lm_edges, kf_estart, lm_orig, lm_bstart, blk_kf, blk_lm, kf_pidx, act_kf;
+    size_t lm_estart, lm_edges, kf_estart, lm_orig, lm_bstart, blk_kf, blk_lm, kf_pidx, act_kf, sv_start;
     size_t tile_lm, pcs, pitem, total;
 };
 __host__ __device__ inline BaAuxLayout ba_aux_layout(int nkf, int nlm, int nobs, int nblk, int na, int ncontrib, int ntile)
@@ -118,6 +122,7 @@ __host__ __device__ inline BaAuxLayout ba_aux_layout(int nkf, int nlm, int nobs,
     L.blk_lm = o; o += nblk;
     L.kf_pidx = o; o += nkf;
     L.act_kf = o; o += nkf;
+    L.sv_start = o; o += (size_t)nkf + 1;
     L.tile_lm = o; o += (size_t)ntile + 1;
     L.pcs = o; o += (size_t)ntile * ((size_t)na * (na + 1) / 2) + 1;
     L.pitem = o; o += ncontrib;
@@ -129,9 +134,9 @@ __host__ __device__ inline int ba_pair_index(int a, int b, int na) { return a * 
 
 struct BaHostStruct {        // scratch reused across jobs
     std::vector<int> lm_estart, lm_edges, kf_estart, lm_orig, lm_new, srt, ostart, lm_bstart, blk_kf, blk_lm, kf_pidx,
-        act_kf, tile_lm, pcs, pitem, fill, bpa;
+        act_kf, tile_lm, pcs, pitem, fill, bpa, lkf, sv_start;
     std::vector<BaRec> recs;     // [0,nobs) landmark-major (= lm_edges order), [nobs,2nobs) pose-major
-    int nblk = 0, na = 0, ncontrib = 0, ntile = 0;
+    int nblk = 0, na = 0, ncontrib = 0, ntile = 0, nmv = 0;
 
     // Returns false if an edge index is out of range.  Two passes over the edges when they
     // arrive landmark-major with keyframes ascending inside a landmark (the order the host
@@ -158,26 +163,42 @@ struct BaHostStruct {        // scratch reused across jobs
             });
         // Landmarks are renumbered by descending block count (stable), so the lanes of a wave in
         // the thread-per-landmark passes walk equally many blocks: most landmarks of a local
-        // window are seen from one keyframe only, a few from all of them.
+        // window are seen from one keyframe only, a few from all of them.  The single-view ones are
+        // further grouped by their keyframe (sv_start: landmark range per keyframe), so that their
+        // Schur contributions — which touch nothing but S(a, a) and bs(a) — can be summed by rows of lanes
+        // dealt to poses, without LDS tiles; [0, nmv) are the landmarks with two or more blocks.  Landmarks
+        // without edges come last.  (Too many keys for the device build's LDS counters: no grouping,
+        // nmv = nlm, every landmark goes through the tiles.)
         ostart.assign((size_t)nlm + 1, 0);          // edge ranges in caller numbering (srt order)
         lm_new.assign(nlm, 0);                       // first: blocks per landmark
+        lkf.assign(nlm, 0);                          // keyframe of a landmark's (last) block
         {
             int prev_lm = -1, prev_kf = -1;
             for (int i = 0; i < nobs; ++i) {
                 const int e = srt[i], k = okf[e], l = olm[e];
                 ostart[l + 1]++;
-                if (l != prev_lm || k != prev_kf) { lm_new[l]++; prev_lm = l; prev_kf = k; }
+                if (l != prev_lm || k != prev_kf) { lm_new[l]++; lkf[l] = k; prev_lm = l; prev_kf = k; }
             }
         }
         for (int i = 0; i < nlm; ++i) ostart[i + 1] += ostart[i];
+        sv_start.assign((size_t)nkf + 1, nlm);
         {
             int maxc = 0;
             for (int l = 0; l < nlm; ++l) maxc = std::max(maxc, lm_new[l]);
-            fill.assign((size_t)maxc + 2, 0);        // counting sort, descending count
-            for (int l = 0; l < nlm; ++l) fill[(size_t)(maxc - lm_new[l]) + 1]++;
-            for (int c = 0; c <= maxc; ++c) fill[(size_t)c + 1] += fill[c];
+            const bool grouped = maxc >= 1 && maxc + nkf <= BB_MAXKEYS;
+            const int nkeys = grouped ? maxc + nkf : maxc + 1;
+            auto key = [&](int l) {
+                const int c = lm_new[l];
+                if (!grouped) return maxc - c;
+                return c >= 2 ? maxc - c : c == 1 ? maxc - 1 + lkf[l] : maxc - 1 + nkf;
+            };
+            fill.assign((size_t)nkeys + 1, 0);        // counting sort, stable
+            for (int l = 0; l < nlm; ++l) fill[(size_t)key(l) + 1]++;
+            for (int c = 0; c < nkeys; ++c) fill[(size_t)c + 1] += fill[c];
+            if (grouped) for (int k = 0; k <= nkf; ++k) sv_start[k] = fill[(size_t)maxc - 1 + k];
+            nmv = grouped ? sv_start[0] : nlm;
             lm_orig.resize(nlm);
-            for (int l = 0; l < nlm; ++l) { const int nid = fill[(size_t)(maxc - lm_new[l])]++; lm_orig[nid] = l; }
+            for (int l = 0; l < nlm; ++l) { const int nid = fill[(size_t)key(l)]++; lm_orig[nid] = l; }
         }
         // pass 1 (landmark-major, new numbering): edge ranges, blocks, records (keyframe still raw)
         lm_edges.resize(nobs);
@@ -240,12 +261,12 @@ struct BaHostStruct {        // scratch reused across jobs
         tile_lm.clear(); tile_lm.push_back(0);
         {
             int nl_t = 0, nb_t = 0;
-            for (int l = 0; l < nlm; ++l) {
+            for (int l = 0; l < nmv; ++l) {
                 const int k = lm_bstart[l + 1] - lm_bstart[l];
                 if (nl_t + 1 > tile_cap || nb_t + k > tile_cap) { tile_lm.push_back(l); nl_t = 0; nb_t = 0; }
                 ++nl_t; nb_t += k;
             }
-            tile_lm.push_back(nlm);
+            if (nmv > 0) tile_lm.push_back(nmv);
         }
         ntile = (int)tile_lm.size() - 1;
         const int npairs = na * (na + 1) / 2;
@@ -296,12 +317,12 @@ struct BaHostStruct {        // scratch reused across jobs
         cp(L.kf_estart, kf_estart, (size_t)j.nkf + 1); cp(L.lm_orig, lm_orig, j.nlm);
         cp(L.lm_bstart, lm_bstart, (size_t)j.nlm + 1);
         cp(L.blk_kf, blk_kf, nblk); cp(L.blk_lm, blk_lm, nblk);
-        cp(L.kf_pidx, kf_pidx, j.nkf); cp(L.act_kf, act_kf, j.nkf);
+        cp(L.kf_pidx, kf_pidx, j.nkf); cp(L.act_kf, act_kf, j.nkf); cp(L.sv_start, sv_start, (size_t)j.nkf + 1);
         cp(L.tile_lm, tile_lm, (size_t)ntile + 1);
         cp(L.pcs, pcs, (size_t)ntile * ((size_t)na * (na + 1) / 2) + 1); cp(L.pitem, pitem, ncontrib);
         d.kf_ofs = j.kf_ofs; d.nkf = j.nkf; d.lm_ofs = j.lm_ofs; d.nlm = j.nlm; d.obs_ofs = j.obs_ofs; d.nobs = j.nobs;
         d.nblk = nblk; d.na = na; d.ncontrib = ncontrib; d.ntile = ntile; d.iters_done = 0; d.rec_ofs = 0;
-        d.lay_nblk = nblk; d.lay_na = na; d.lay_ntile = ntile;
+        d.lay_nblk = nblk; d.lay_na = na; d.lay_ntile = ntile; d.nmv = nmv; d.reserved = 0;
     }
 };
 
@@ -414,6 +435,29 @@ __device__ __forceinline__ void ba_linearize(const double *PT, const double *CT,
             L.jl[3 * r + c] = M[3 * r] * PT[c] + M[3 * r + 1] * PT[3 + c] + M[3 * r + 2] * PT[6 + c];
 }
 
+// Recursive-halving butterfly over the 16 lanes of a DPP row (k_geom.h:po_bfly): 32 values per lane in, the
+// row totals of values 2 code, 2 code + 1 out in v[0], v[1] (code = 8 s0 + 4 s1 + 2 s2 + s3; 30 adds, not 32 x 4)
+template <int CTRL, int HALF>
+__device__ __forceinline__ void ba_bfly(double *v, bool sel)
+{
+#pragma unroll
+    for (int i = 0; i < HALF; ++i) {
+        const double lo = v[i], hi = v[i + HALF];
+        const double keep = sel ? hi : lo, send = sel ? lo : hi;
+        v[i] = keep + dpp_f64<CTRL>(send);
+    }
+}
+__device__ __forceinline__ int ba_row_sum32(double *v, int lane)
+{
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+    const bool s0 = b0 != b2, s1 = b1 != b2, s2 = b2 != b3, s3 = b3;
+    ba_bfly<SVS_DPP_XOR1, 16>(v, s0);
+    ba_bfly<SVS_DPP_XOR2, 8>(v, s1);
+    ba_bfly<SVS_DPP_HALF_MIRROR, 4>(v, s2);
+    ba_bfly<SVS_DPP_MIRROR, 2>(v, s3);
+    return (s0 ? 8 : 0) + (s1 ? 4 : 0) + (s2 ? 2 : 0) + (s3 ? 1 : 0);
+}
+
 // One Schur task of a tile: S(a, b) rows 2 rg, 2 rg + 1 (and the same rows of bs when a == b) lose
 // sum_items Y W_b^T with Y = W_a (Hll + lambda I)^-1, the items striding over the LANES (8 or 16)
 // lanes of a DPP row.  (Wider groups for the diagonal pairs — 32 / 64 lanes with row_bcast
@@ -523,8 +567,8 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
     double *red = bp + np;
     double *PTab = red + BA_WAVES;
     double *CTab = PTab + BA_PT * na;
-    double *part = CTab + 2 * BA_CT;               // [BA_ROWS][27] pose-pass partial sums
-    double *Wt = part + 27 * BA_ROWS;              // [tile_cap][18] blocks of the current tile
+    double *part = CTab + 2 * BA_CT;               // [BA_ROWS][32] row partial sums (pose pass, single-view pass: 27 used)
+    double *Wt = part + 32 * BA_ROWS;              // [tile_cap][18] blocks of the current tile
     double *Dl = Wt + 18 * tile_cap;               // [tile_cap][6]  (Hll + lambda I)^-1, symmetric
     double *Bl = Dl + 6 * tile_cap;                // [tile_cap][3]  bl
     int *Pcs = reinterpret_cast<int *>(Bl + 3 * tile_cap);   // [npairs + 1] item ranges of the current tile
@@ -544,7 +588,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
     const int *kf_estart = aux + AL.kf_estart;
     const int *lm_bstart = aux + AL.lm_bstart;
     const int *blk_kf = aux + AL.blk_kf, *blk_lm = aux + AL.blk_lm;
-    const int *kf_pidx = aux + AL.kf_pidx, *act_kf = aux + AL.act_kf;
+    const int *kf_pidx = aux + AL.kf_pidx, *act_kf = aux + AL.act_kf, *sv_start = aux + AL.sv_start;
     const int *tile_lm = aux + AL.tile_lm, *pcs = aux + AL.pcs, *pitem = aux + AL.pitem;
 
     const size_t J = job;
@@ -650,13 +694,13 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
             for (int t = 0; t < 27; ++t) acc[t] = row_sum_f64(acc[t]);
             if (rl == 0) {
 #pragma unroll
-                for (int t = 0; t < 27; ++t) part[row * 27 + t] = acc[t];
+                for (int t = 0; t < 27; ++t) part[row * 32 + t] = acc[t];
             }
             __syncthreads();
             for (int z = tid; z < 27 * na; z += BA_THREADS) {
                 const int a2 = z / 27, t = z - a2 * 27;
                 double v = 0;
-                for (int sb = 0; sb < rpp; ++sb) v += part[(sb * na + a2) * 27 + t];
+                for (int sb = 0; sb < rpp; ++sb) v += part[(sb * na + a2) * 32 + t];
                 if (t < 21) {
                     int r = 0, rem = t;
                     while (rem >= 6 - r) { rem -= 6 - r; ++r; }
@@ -709,8 +753,79 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
             }
             __syncthreads();
             BA_PROF(2);
-            // ---- tile sweep: linearise the tile's landmarks into LDS, then fold the tile into S / bs
             double chi_part = 0;
+            // ---- single-view landmarks (most of a local window): one block each, so all they change is S(a, a)
+            // and bs(a) of their pose.  No LDS tile: a lane linearises its landmark (one or two edges), forms W,
+            // (Hll + lambda I)^-1 and Y = W Dinv in registers and adds Y W^T (21 sums) and Y bl (6) to its own
+            // accumulators; the rows are dealt over the poses like the pose pass, row totals by the butterfly,
+            // the rows of a pose added in row order.
+            if (lin && jd.nmv < nlm) {
+                const int row = tid >> 4, rl = tid & 15;
+                const int rpp = BA_ROWS / na, a = row % na, sub = row / na;
+                double acc[32];
+#pragma unroll
+                for (int t = 0; t < 32; ++t) acc[t] = 0;
+                if (sub < rpp) {
+                    const int k = act_kf[a];
+                    const double *PT = PTab + BA_PT * a;
+                    for (int j = sv_start[k] + sub * 16 + rl; j < sv_start[k + 1]; j += 16 * rpp) {
+                        const double X[3] = { pts[3 * (size_t)j], pts[3 * (size_t)j + 1], pts[3 * (size_t)j + 2] };
+                        double h[6] = { 0, 0, 0, 0, 0, 0 }, b3[3] = { 0, 0, 0 }, ww[18];
+#pragma unroll
+                        for (int t = 0; t < 18; ++t) ww[t] = 0;
+                        for (int i = lm_estart[j]; i < lm_estart[j + 1]; ++i) {
+                            const BaRec rc = recL[i];
+                            const int kc = (unsigned)rc.lmkc >> 24;
+                            BaLin L;
+                            ba_linearize(PT, CTab + BA_CT * (kc & 1), X, rc.u, rc.v, delta, L);
+                            if (!have_chi) { err[2 * i] = L.ex; err[2 * i + 1] = L.ey; chi_part += L.rho; }
+                            const double wl0 = L.w * L.jl[0], wl1 = L.w * L.jl[1], wl2 = L.w * L.jl[2],
+                                         wl3 = L.w * L.jl[3], wl4 = L.w * L.jl[4], wl5 = L.w * L.jl[5];
+#pragma unroll
+                            for (int r = 0; r < 6; ++r) {
+                                const double p0 = L.jp[r], p1 = L.jp[6 + r];
+                                ww[r * 3 + 0] += p0 * wl0 + p1 * wl3;
+                                ww[r * 3 + 1] += p0 * wl1 + p1 * wl4;
+                                ww[r * 3 + 2] += p0 * wl2 + p1 * wl5;
+                            }
+                            b3[0] -= wl0 * L.ex + wl3 * L.ey; b3[1] -= wl1 * L.ex + wl4 * L.ey; b3[2] -= wl2 * L.ex + wl5 * L.ey;
+                            h[0] += wl0 * L.jl[0] + wl3 * L.jl[3]; h[1] += wl0 * L.jl[1] + wl3 * L.jl[4]; h[2] += wl0 * L.jl[2] + wl3 * L.jl[5];
+                            h[3] += wl1 * L.jl[1] + wl4 * L.jl[4]; h[4] += wl1 * L.jl[2] + wl4 * L.jl[5]; h[5] += wl2 * L.jl[2] + wl5 * L.jl[5];
+                        }
+                        double D[9] = { h[0] + lambda, h[1], h[2], h[1], h[3] + lambda, h[4], h[2], h[4], h[5] + lambda }, Di[9];
+                        d_inv3(D, Di);
+                        int t = 0;
+#pragma unroll
+                        for (int r = 0; r < 6; ++r) {
+                            const double x0 = ww[r * 3], x1 = ww[r * 3 + 1], x2 = ww[r * 3 + 2];
+                            const double y0 = x0 * Di[0] + x1 * Di[1] + x2 * Di[2], y1 = x0 * Di[1] + x1 * Di[4] + x2 * Di[5],
+                                         y2 = x0 * Di[2] + x1 * Di[5] + x2 * Di[8];
+#pragma unroll
+                            for (int cc = r; cc < 6; ++cc) { acc[t] += y0 * ww[cc * 3] + y1 * ww[cc * 3 + 1] + y2 * ww[cc * 3 + 2]; ++t; }
+                            acc[21 + r] += y0 * b3[0] + y1 * b3[1] + y2 * b3[2];
+                        }
+                    }
+                }
+                const int code = ba_row_sum32(acc, lane);
+                reinterpret_cast<double2 *>(part + 32 * row)[code] = make_double2(acc[0], acc[1]);
+                __syncthreads();
+                for (int z = tid; z < 27 * na; z += BA_THREADS) {
+                    const int a2 = z / 27, t = z - a2 * 27;
+                    double v = 0;
+                    for (int sb = 0; sb < rpp; ++sb) v += part[(sb * na + a2) * 32 + t];
+                    if (t < 21) {
+                        int r = 0, rem = t;
+                        while (rem >= 6 - r) { rem -= 6 - r; ++r; }
+                        const int cc = r + rem;
+                        S[(size_t)(6 * a2 + r) * ld + 6 * a2 + cc] -= v;
+                        if (cc != r) S[(size_t)(6 * a2 + cc) * ld + 6 * a2 + r] -= v;
+                    } else bs[6 * a2 + (t - 21)] -= v;
+                }
+                __syncthreads();
+            }
+            BA_PROF(0);
+            // ---- tile sweep (landmarks seen from two or more poses): linearise the tile's landmarks into LDS,
+            // then fold the tile into S / bs
             for (int tl = 0; lin && tl < ntile; ++tl) {
                 const int l0 = tile_lm[tl], l1 = tile_lm[tl + 1], bt0 = lm_bstart[l0];
                 // the tile's pair ranges and items go to LDS too: issued here, stored after the
@@ -787,6 +902,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                         if (c0 == c1) continue;
                         ba_schur_task<16>(a, a, rg, c0, c1, tid & 15, it0, Pit, pitem, Wt, Dl, Bl, S, bs, ld);
                     }
+                    if (prof) { __syncthreads(); BA_PROF(10); }         // development: diagonal / off-diagonal split
                     for (int tk = tid >> 3; tk < 3 * npairs; tk += BA_THREADS / 8) {
                         const int pr = tk / 3, rg = tk - 3 * pr;
                         const int c0 = Pcs[pr], c1 = Pcs[pr + 1];
@@ -1026,7 +1142,7 @@ static inline size_t ba_lds_fixed_bytes(int max_kf)
 {
     size_t np = 6 * (size_t)max_kf;
     return ((np + 1) * (np + 1) + 3 * np + 36 * (size_t)max_kf + BA_WAVES + BA_PT * (size_t)max_kf + 2 * BA_CT +
-            27 * BA_ROWS) * sizeof(double) +
+            32 * BA_ROWS) * sizeof(double) +
            ((BA_MAX_NP / 6) * (BA_MAX_NP / 6 + 1) / 2 + 1 + BA_PIT_CAP) * sizeof(int) + 64;
 }
 // landmarks / blocks per LDS tile: what the 160 KB leave after the reduced system, at most BA_TILE_MAX

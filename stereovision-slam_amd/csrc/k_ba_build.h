@@ -17,7 +17,7 @@
 #pragma clang fp contract(off)
 
 #define BB_THREADS 256
-#define BB_MAXKEYS 33            // block counts 0..32 / keyframes 0..31
+// BB_MAXKEYS (k_ba.h): block counts 0..32 / keyframes 0..31; the grouped landmark sort needs max count + nkf keys
 
 // upper bound of the number of LDS tiles of a problem (greedy packing with two capacities)
 __host__ __device__ inline int ba_tile_bound(int nlm, int nobs, int nkf, int tile_cap)
@@ -78,13 +78,14 @@ k_ba_build(BaDev *jobs, const int *obs_kf, const int *obs_lm, const uint8_t *obs
     BaRec *recL = recs_all + jd.rec_ofs, *recP = recL + nobs;
     int *aux = aux_all + jd.aux_ofs;
     if (nobs <= 0 || nlm <= 0 || nkf <= 0) {
-        if (tid == 0) { jd.nblk = 0; jd.na = 0; jd.ncontrib = 0; jd.ntile = 0; }
+        if (tid == 0) { jd.nblk = 0; jd.na = 0; jd.ncontrib = 0; jd.ntile = 0; jd.nmv = 0; }
         return;
     }
     const BaAuxLayout AL = ba_aux_layout(nkf, nlm, nobs, jd.lay_nblk, jd.lay_na, 0, jd.lay_ntile);
     int *g_lm_estart = aux + AL.lm_estart, *g_lm_edges = aux + AL.lm_edges, *g_kf_estart = aux + AL.kf_estart;
     int *g_lm_orig = aux + AL.lm_orig, *g_lm_bstart = aux + AL.lm_bstart, *g_blk_kf = aux + AL.blk_kf, *g_blk_lm = aux + AL.blk_lm;
     int *g_kf_pidx = aux + AL.kf_pidx, *g_act_kf = aux + AL.act_kf, *g_tile_lm = aux + AL.tile_lm, *g_pcs = aux + AL.pcs;
+    int *g_sv_start = aux + AL.sv_start;
     int *g_pitem = aux + AL.pitem;
 
     // LDS carve
@@ -162,21 +163,38 @@ k_ba_build(BaDev *jobs, const int *obs_kf, const int *obs_lm, const uint8_t *obs
     __syncthreads();
     const int maxc = small[0], na = small[1];
     const int npairs = na * (na + 1) / 2;
-    // ---- 3. landmarks renumbered by descending block count, stable: flattened [key][thread] counting sort
-    const int nkeys = maxc + 1;
+    // ---- 3. landmarks renumbered by descending block count, the single-view ones grouped by their keyframe, the
+    //         ones without edges last (BaHostStruct::build has the same key), stable: flattened [key][thread]
+    //         counting sort.  sv_start[k] = first landmark of keyframe k's single-view group; nmv = sv_start[0].
+    const bool grouped = maxc >= 1 && maxc + nkf <= BB_MAXKEYS;
+    const int nkeys = grouped ? maxc + nkf : maxc + 1;
     const int lper = (nlm + BB_THREADS - 1) / BB_THREADS;
     {
         const int l0 = min(tid * lper, nlm), l1 = min(l0 + lper, nlm);
-        for (int key = 0; key < nkeys; ++key) flat[key * BB_THREADS + tid] = 0;
-        for (int l = l0; l < l1; ++l) flat[(maxc - cnt[l]) * BB_THREADS + tid]++;
+        auto key = [&](int l) -> int {
+            const int c = cnt[l];
+            if (!grouped) return maxc - c;
+            if (c >= 2) return maxc - c;
+            if (c == 0) return maxc - 1 + nkf;
+            return maxc - 1 + (int)((edge(ostart[l]) >> 16) & 0xffu);
+        };
+        for (int k2 = 0; k2 < nkeys; ++k2) flat[k2 * BB_THREADS + tid] = 0;
+        for (int l = l0; l < l1; ++l) flat[key(l) * BB_THREADS + tid]++;
         __syncthreads();
         bb_exscan(flat, nkeys * BB_THREADS, tmp, tid);
+        if (tid <= nkf) {
+            const int v = grouped ? flat[(maxc - 1 + tid) * BB_THREADS] : nlm;     // start of the bucket = its first thread's offset
+            g_sv_start[tid] = v;
+            if (tid == 0) small[4] = v;
+        }
+        __syncthreads();                      // thread 0's column is about to be advanced
         for (int l = l0; l < l1; ++l) {
-            const int pos = flat[(maxc - cnt[l]) * BB_THREADS + tid]++;
+            const int pos = flat[key(l) * BB_THREADS + tid]++;
             lm_orig[pos] = l;
         }
     }
     __syncthreads();
+    const int nmv = small[4];
     // ---- 4. edge and block ranges in the new numbering
     for (int jn = tid; jn < nlm; jn += BB_THREADS) {
         const int l = lm_orig[jn];
@@ -237,9 +255,9 @@ k_ba_build(BaDev *jobs, const int *obs_kf, const int *obs_lm, const uint8_t *obs
     if (tid == 0) {
         int nt = 0, st = 0;
         g_tile_lm[0] = 0;
-        while (st < nlm) {
+        while (st < nmv) {
             const int lim = lm_bs[st] + tile_cap;
-            int lo = st + 1, hi = min(st + tile_cap, nlm);        // the tile ends in (st, hi]; lm_bs[lo] - lm_bs[st] <= cap holds for lo = st + 1
+            int lo = st + 1, hi = min(st + tile_cap, nmv);        // the tile ends in (st, hi]; lm_bs[lo] - lm_bs[st] <= cap holds for lo = st + 1
             while (lo < hi) {
                 const int mid = (lo + hi + 1) >> 1;
                 if (lm_bs[mid] <= lim) lo = mid; else hi = mid - 1;
@@ -297,6 +315,6 @@ k_ba_build(BaDev *jobs, const int *obs_kf, const int *obs_lm, const uint8_t *obs
     }
     if (tid == 0) {
         g_pcs[nlist] = small[3];
-        jd.nblk = nblk; jd.na = na; jd.ncontrib = small[3]; jd.ntile = ntile;
+        jd.nblk = nblk; jd.na = na; jd.ncontrib = small[3]; jd.ntile = ntile; jd.nmv = nmv;
     }
 }

@@ -42,7 +42,7 @@ def ba(nj=1, nkf=10, nlm=700, reps=3):
         names = ["edge+J", "lm+pose", "dinv/Y/Sinit", "schur", "chol", "backsub", "errors"]
         tot = sum(prof[:7])
         print("  rep %d: %.3f ms/launch; trials %d; phase us (100MHz ticks/100): " % (r, ms / max(n, 1), prof[11]) +
-              ", ".join("%s %.1f" % (nm, prof[i] / 100.0) for i, nm in enumerate(names)) + "  sum %.1f  [chol factor part %.1f; tile pass %.1f, tile schur %.1f]" % ((tot + prof[8] + prof[9]) / 100.0, prof[7] / 100.0, prof[8] / 100.0, prof[9] / 100.0))
+              ", ".join("%s %.1f" % (nm, prof[i] / 100.0) for i, nm in enumerate(names)) + "  sum %.1f  [chol factor part %.1f; tile pass %.1f, tile schur diag %.1f + offdiag %.1f]" % ((tot + prof[8] + prof[9] + prof[10]) / 100.0, prof[7] / 100.0, prof[8] / 100.0, prof[10] / 100.0, prof[9] / 100.0))
     c.close()
 
 
@@ -135,6 +135,8 @@ if __name__ == "__main__":
         lkbench(); sys.exit(0)
     if what == "gftt":
         gfttbench(); sys.exit(0)
+    if what == "ba1":        # the captured pipeline problem: alone and 256 at a time, with the phase profile
+        ba(1, 0, 0, reps=2); ba(256, 0, 0, reps=2); sys.exit(0)
     if what == "tput":       # chip-time per family at bench scale
         for nj in (1, 64, 256, 512):
             ba(nj, 0, 0, reps=2)
