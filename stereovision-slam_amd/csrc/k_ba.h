@@ -103,10 +103,10 @@ static inline void ba_work_free(BaWork &w) { if (w.all) (void)hipFree(w.all); w.
 // ---------------------------------------------------------------- host-side structure
 // aux layout per job (ints), offsets from ba_aux_layout():
 //   lm_estart[nlm+1] lm_edges[nobs] kf_estart[nkf+1] lm_orig[nlm]
-//   lm_bstart[nlm+1] blk_kf[nblk] blk_lm[nblk] kf_pidx[nkf] act_kf[nkf] sv_start[nkf+1]
+//   lm_bstart[nlm+1] blk_kf[nblk] blk_lm[nblk] blk_es[nblk+1] kf_pidx[nkf] act_kf[nkf] sv_start[nkf+1]
 //   tile_lm[ntile+1]  pcs[ntile*npairs+1]  pitem[ncontrib] (y | w << 10 | landmark << 20, tile-local)
 struct BaAuxLayout {
-    size_t lm_estart, lm_edges, kf_estart, lm_orig, lm_bstart, blk_kf, blk_lm, kf_pidx, act_kf, sv_start;
+    size_t lm_estart, lm_edges, kf_estart, lm_orig, lm_bstart, blk_kf, blk_lm, blk_es, kf_pidx, act_kf, sv_start;
     size_t tile_lm, pcs, pitem, total;
 };
 __host__ __device__ inline BaAuxLayout ba_aux_layout(int nkf, int nlm, int nobs, int nblk, int na, int ncontrib, int ntile)
@@ -120,6 +120,7 @@ __host__ __device__ inline BaAuxLayout ba_aux_layout(int nkf, int nlm, int nobs,
     L.lm_bstart = o; o += (size_t)nlm + 1;
     L.blk_kf = o; o += nblk;
     L.blk_lm = o; o += nblk;
+    L.blk_es = o; o += (size_t)nblk + 1;
     L.kf_pidx = o; o += nkf;
     L.act_kf = o; o += nkf;
     L.sv_start = o; o += (size_t)nkf + 1;
@@ -134,7 +135,7 @@ __host__ __device__ inline int ba_pair_index(int a, int b, int na) { return a * 
 
 struct BaHostStruct {        // scratch reused across jobs
     std::vector<int> lm_estart, lm_edges, kf_estart, lm_orig, lm_new, srt, ostart, lm_bstart, blk_kf, blk_lm, kf_pidx,
-        act_kf, tile_lm, pcs, pitem, fill, bpa, lkf, sv_start;
+        act_kf, tile_lm, pcs, pitem, fill, bpa, lkf, sv_start, blk_es;
     std::vector<BaRec> recs;     // [0,nobs) landmark-major (= lm_edges order), [nobs,2nobs) pose-major
     int nblk = 0, na = 0, ncontrib = 0, ntile = 0, nmv = 0;
 
@@ -205,13 +206,13 @@ struct BaHostStruct {        // scratch reused across jobs
         lm_estart.assign((size_t)nlm + 1, 0);
         lm_bstart.assign((size_t)nlm + 1, 0);
         kf_estart.assign((size_t)nkf + 1, 0);
-        blk_kf.resize(nobs); blk_lm.resize(nobs);     // upper bound, trimmed below
+        blk_kf.resize(nobs); blk_lm.resize(nobs); blk_es.resize((size_t)nobs + 1);     // upper bound, trimmed below
         recs.resize(2 * (size_t)nobs);
         {
             int i = 0, nb = 0;
             BaRec *__restrict rl = recs.data();
             int *__restrict le = lm_edges.data(), *__restrict ke = kf_estart.data();
-            int *__restrict bk = blk_kf.data(), *__restrict bm = blk_lm.data();
+            int *__restrict bk = blk_kf.data(), *__restrict bm = blk_lm.data(), *__restrict be = blk_es.data();
             int *__restrict les = lm_estart.data(), *__restrict lbs = lm_bstart.data();
             const int *__restrict lo = lm_orig.data(), *__restrict os = ostart.data(), *__restrict sr = srt.data();
             for (int jn = 0; jn < nlm; ++jn) {
@@ -221,7 +222,7 @@ struct BaHostStruct {        // scratch reused across jobs
                     const int e = sr[q], k = okf[e];
                     le[i] = e;
                     ke[k + 1]++;
-                    if (k != prev_kf) { bk[nb] = k; bm[nb] = jn; ++nb; prev_kf = k; }
+                    if (k != prev_kf) { bk[nb] = k; bm[nb] = jn; be[nb] = i; ++nb; prev_kf = k; }
                     BaRec r;
                     r.u = ouv[2 * e]; r.v = ouv[2 * e + 1];
                     r.lmkc = (k << 1) | (ori[e] ? 1 : 0);      // completed in pass 2
@@ -232,8 +233,9 @@ struct BaHostStruct {        // scratch reused across jobs
                 lbs[jn + 1] = nb;
             }
             nblk = nb;
+            be[nb] = nobs;
         }
-        blk_kf.resize(nblk); blk_lm.resize(nblk);
+        blk_kf.resize(nblk); blk_lm.resize(nblk); blk_es.resize((size_t)nblk + 1);
         for (int i = 0; i < nkf; ++i) kf_estart[i + 1] += kf_estart[i];
         kf_pidx.assign(nkf, -1); act_kf.assign(nkf, -1);
         na = 0;
@@ -316,7 +318,7 @@ struct BaHostStruct {        // scratch reused across jobs
         cp(L.lm_estart, lm_estart, (size_t)j.nlm + 1); cp(L.lm_edges, lm_edges, j.nobs);
         cp(L.kf_estart, kf_estart, (size_t)j.nkf + 1); cp(L.lm_orig, lm_orig, j.nlm);
         cp(L.lm_bstart, lm_bstart, (size_t)j.nlm + 1);
-        cp(L.blk_kf, blk_kf, nblk); cp(L.blk_lm, blk_lm, nblk);
+        cp(L.blk_kf, blk_kf, nblk); cp(L.blk_lm, blk_lm, nblk); cp(L.blk_es, blk_es, (size_t)nblk + 1);
         cp(L.kf_pidx, kf_pidx, j.nkf); cp(L.act_kf, act_kf, j.nkf); cp(L.sv_start, sv_start, (size_t)j.nkf + 1);
         cp(L.tile_lm, tile_lm, (size_t)ntile + 1);
         cp(L.pcs, pcs, (size_t)ntile * ((size_t)na * (na + 1) / 2) + 1); cp(L.pitem, pitem, ncontrib);
@@ -587,7 +589,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
     const int *lm_estart = aux + AL.lm_estart, *lm_edges = aux + AL.lm_edges;
     const int *kf_estart = aux + AL.kf_estart;
     const int *lm_bstart = aux + AL.lm_bstart;
-    const int *blk_kf = aux + AL.blk_kf, *blk_lm = aux + AL.blk_lm;
+    const int *blk_kf = aux + AL.blk_kf, *blk_lm = aux + AL.blk_lm, *blk_es = aux + AL.blk_es;
     const int *kf_pidx = aux + AL.kf_pidx, *act_kf = aux + AL.act_kf, *sv_start = aux + AL.sv_start;
     const int *tile_lm = aux + AL.tile_lm, *pcs = aux + AL.pcs, *pitem = aux + AL.pitem;
 
@@ -839,49 +841,68 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                     pre[q] = c < it1 ? pitem[c] : 0;
                 }
                 const int pcs_mine = tid <= npairs ? pcs[tl * npairs + tid] : 0;   // npairs + 1 <= BA_THREADS
-                for (int lj = tid; lj < l1 - l0; lj += BA_THREADS) {
-                    const int j = l0 + lj;
-                    double h[6] = { 0, 0, 0, 0, 0, 0 }, b3[3] = { 0, 0, 0 };
+                // thread per BLOCK: its one or two edge records are independent loads, every thread of the workgroup
+                // has work (a tile of multi-view landmarks is ~200 landmarks of ~2.5 blocks; one thread per landmark
+                // walked five dependent record loads with most of the workgroup idle).  W_block -> LDS; the block's
+                // share of Hll and bl goes through LDS too (the Dl / Bl area, indexed by block for the moment) ...
+                const int nbt = lm_bstart[l1] - bt0;
+                for (int bq = tid; bq < nbt; bq += BA_THREADS) {
+                    const int b = bt0 + bq, j = blk_lm[b];
+                    const int e0 = blk_es[b], e1 = blk_es[b + 1];
                     const double X[3] = { pts[3 * (size_t)j], pts[3 * (size_t)j + 1], pts[3 * (size_t)j + 2] };
-                    const int eend = lm_estart[j + 1];
-                    int i = lm_estart[j];
-                    while (i < eend) {
-                        BaRec rc = recL[i];
-                        const int blk = rc.blk;
-                        double wacc[18];
+                    double h[6] = { 0, 0, 0, 0, 0, 0 }, b3[3] = { 0, 0, 0 }, wacc[18];
 #pragma unroll
-                        for (int t = 0; t < 18; ++t) wacc[t] = 0;
-                        for (;;) {
-                            const int kc = (unsigned)rc.lmkc >> 24;
-                            BaLin L;
-                            ba_linearize(PTab + BA_PT * (kc >> 1), CTab + BA_CT * (kc & 1), X, rc.u, rc.v, delta, L);
-                            if (!have_chi) { err[2 * i] = L.ex; err[2 * i + 1] = L.ey; chi_part += L.rho; }
-                            const double wl0 = L.w * L.jl[0], wl1 = L.w * L.jl[1], wl2 = L.w * L.jl[2],
-                                         wl3 = L.w * L.jl[3], wl4 = L.w * L.jl[4], wl5 = L.w * L.jl[5];
+                    for (int t = 0; t < 18; ++t) wacc[t] = 0;
+                    for (int i = e0; i < e1; ++i) {
+                        const BaRec rc = recL[i];
+                        const int kc = (unsigned)rc.lmkc >> 24;
+                        BaLin L;
+                        ba_linearize(PTab + BA_PT * (kc >> 1), CTab + BA_CT * (kc & 1), X, rc.u, rc.v, delta, L);
+                        if (!have_chi) { err[2 * i] = L.ex; err[2 * i + 1] = L.ey; chi_part += L.rho; }
+                        const double wl0 = L.w * L.jl[0], wl1 = L.w * L.jl[1], wl2 = L.w * L.jl[2],
+                                     wl3 = L.w * L.jl[3], wl4 = L.w * L.jl[4], wl5 = L.w * L.jl[5];
 #pragma unroll
-                            for (int a = 0; a < 6; ++a) {
-                                const double p0 = L.jp[a], p1 = L.jp[6 + a];
-                                wacc[a * 3 + 0] += p0 * wl0 + p1 * wl3;
-                                wacc[a * 3 + 1] += p0 * wl1 + p1 * wl4;
-                                wacc[a * 3 + 2] += p0 * wl2 + p1 * wl5;
-                            }
-                            b3[0] -= wl0 * L.ex + wl3 * L.ey; b3[1] -= wl1 * L.ex + wl4 * L.ey; b3[2] -= wl2 * L.ex + wl5 * L.ey;
-                            h[0] += wl0 * L.jl[0] + wl3 * L.jl[3]; h[1] += wl0 * L.jl[1] + wl3 * L.jl[4]; h[2] += wl0 * L.jl[2] + wl3 * L.jl[5];
-                            h[3] += wl1 * L.jl[1] + wl4 * L.jl[4]; h[4] += wl1 * L.jl[2] + wl4 * L.jl[5]; h[5] += wl2 * L.jl[2] + wl5 * L.jl[5];
-                            ++i;
-                            if (i >= eend) break;
-                            rc = recL[i];
-                            if (rc.blk != blk) break;
+                        for (int a = 0; a < 6; ++a) {
+                            const double p0 = L.jp[a], p1 = L.jp[6 + a];
+                            wacc[a * 3 + 0] += p0 * wl0 + p1 * wl3;
+                            wacc[a * 3 + 1] += p0 * wl1 + p1 * wl4;
+                            wacc[a * 3 + 2] += p0 * wl2 + p1 * wl5;
                         }
-                        double *wd = Wt + 18 * (blk - bt0);
-#pragma unroll
-                        for (int t = 0; t < 18; ++t) wd[t] = wacc[t];
+                        b3[0] -= wl0 * L.ex + wl3 * L.ey; b3[1] -= wl1 * L.ex + wl4 * L.ey; b3[2] -= wl2 * L.ex + wl5 * L.ey;
+                        h[0] += wl0 * L.jl[0] + wl3 * L.jl[3]; h[1] += wl0 * L.jl[1] + wl3 * L.jl[4]; h[2] += wl0 * L.jl[2] + wl3 * L.jl[5];
+                        h[3] += wl1 * L.jl[1] + wl4 * L.jl[4]; h[4] += wl1 * L.jl[2] + wl4 * L.jl[5]; h[5] += wl2 * L.jl[2] + wl5 * L.jl[5];
                     }
-                    double D[9] = { h[0] + lambda, h[1], h[2], h[1], h[3] + lambda, h[4], h[2], h[4], h[5] + lambda }, Di[9];
-                    d_inv3(D, Di);
-                    double *dd = Dl + 6 * lj;
-                    dd[0] = Di[0]; dd[1] = Di[1]; dd[2] = Di[2]; dd[3] = Di[4]; dd[4] = Di[5]; dd[5] = Di[8];
-                    Bl[3 * lj] = b3[0]; Bl[3 * lj + 1] = b3[1]; Bl[3 * lj + 2] = b3[2];
+                    double *wd = Wt + 18 * bq;
+#pragma unroll
+                    for (int t = 0; t < 18; ++t) wd[t] = wacc[t];
+                    double *dd = Dl + 6 * bq;
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) dd[t] = h[t];
+                    Bl[3 * bq] = b3[0]; Bl[3 * bq + 1] = b3[1]; Bl[3 * bq + 2] = b3[2];
+                }
+                __syncthreads();
+                // ... where the landmark's thread adds its blocks' shares in block order (read, barrier, then
+                // overwrite: a landmark's own slot is one of the block slots), inverts Hll + lambda I and leaves
+                // Dinv and bl per landmark
+                for (int lj0 = 0; lj0 < l1 - l0; lj0 += BA_THREADS) {
+                    const int lj = lj0 + tid;
+                    double h[6] = { 0, 0, 0, 0, 0, 0 }, b3[3] = { 0, 0, 0 };
+                    if (lj < l1 - l0) {
+                        const int j = l0 + lj;
+                        for (int b = lm_bstart[j] - bt0; b < lm_bstart[j + 1] - bt0; ++b) {
+#pragma unroll
+                            for (int t = 0; t < 6; ++t) h[t] += Dl[6 * b + t];
+                            b3[0] += Bl[3 * b]; b3[1] += Bl[3 * b + 1]; b3[2] += Bl[3 * b + 2];
+                        }
+                    }
+                    __syncthreads();
+                    if (lj < l1 - l0) {
+                        double D[9] = { h[0] + lambda, h[1], h[2], h[1], h[3] + lambda, h[4], h[2], h[4], h[5] + lambda }, Di[9];
+                        d_inv3(D, Di);
+                        double *dd = Dl + 6 * lj;
+                        dd[0] = Di[0]; dd[1] = Di[1]; dd[2] = Di[2]; dd[3] = Di[4]; dd[4] = Di[5]; dd[5] = Di[8];
+                        Bl[3 * lj] = b3[0]; Bl[3 * lj + 1] = b3[1]; Bl[3 * lj + 2] = b3[2];
+                    }
                 }
 #pragma unroll
                 for (int q = 0; q < BA_PIT_CAP / BA_THREADS; ++q) Pit[tid + q * BA_THREADS] = pre[q];
@@ -902,6 +923,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                         if (c0 == c1) continue;
                         ba_schur_task<16>(a, a, rg, c0, c1, tid & 15, it0, Pit, pitem, Wt, Dl, Bl, S, bs, ld);
                     }
+                    if (prof) { __syncthreads(); BA_PROF(10); }         // development: diagonal / off-diagonal split
                     if (prof) { __syncthreads(); BA_PROF(10); }         // development: diagonal / off-diagonal split
                     for (int tk = tid >> 3; tk < 3 * npairs; tk += BA_THREADS / 8) {
                         const int pr = tk / 3, rg = tk - 3 * pr;

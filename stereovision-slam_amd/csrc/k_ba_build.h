@@ -85,7 +85,7 @@ k_ba_build(BaDev *jobs, const int *obs_kf, const int *obs_lm, const uint8_t *obs
     int *g_lm_estart = aux + AL.lm_estart, *g_lm_edges = aux + AL.lm_edges, *g_kf_estart = aux + AL.kf_estart;
     int *g_lm_orig = aux + AL.lm_orig, *g_lm_bstart = aux + AL.lm_bstart, *g_blk_kf = aux + AL.blk_kf, *g_blk_lm = aux + AL.blk_lm;
     int *g_kf_pidx = aux + AL.kf_pidx, *g_act_kf = aux + AL.act_kf, *g_tile_lm = aux + AL.tile_lm, *g_pcs = aux + AL.pcs;
-    int *g_sv_start = aux + AL.sv_start;
+    int *g_sv_start = aux + AL.sv_start, *g_blk_es = aux + AL.blk_es;
     int *g_pitem = aux + AL.pitem;
 
     // LDS carve
@@ -207,6 +207,7 @@ k_ba_build(BaDev *jobs, const int *obs_kf, const int *obs_lm, const uint8_t *obs
     bb_exscan(lm_es, nlm + 1, tmp, tid);
     const int nblk = bb_exscan(lm_bs, nlm + 1, tmp, tid);
     for (int jn = tid; jn <= nlm; jn += BB_THREADS) { g_lm_estart[jn] = lm_es[jn]; g_lm_bstart[jn] = lm_bs[jn]; }
+    if (tid == 0) g_blk_es[nblk] = nobs;
     // ---- 5. landmark-major records, blocks, pose masks (thread per landmark; lanes of a wave walk
     //         similar edge counts because of the renumbering)
     for (int jn = tid; jn < nlm; jn += BB_THREADS) {
@@ -216,7 +217,7 @@ k_ba_build(BaDev *jobs, const int *obs_kf, const int *obs_lm, const uint8_t *obs
         for (int q = ostart[l]; q < ostart[l + 1]; ++q, ++i) {
             const unsigned int ev = edge(q);
             const int e = srt[q], k = (int)((ev >> 16) & 0xffu);
-            if (k != prev_kf) { ++b; g_blk_kf[b] = k; g_blk_lm[b] = jn; prev_kf = k; mask |= 1u << pidx[k]; }
+            if (k != prev_kf) { ++b; g_blk_kf[b] = k; g_blk_lm[b] = jn; g_blk_es[b] = i; prev_kf = k; mask |= 1u << pidx[k]; }
             g_lm_edges[i] = e;
             const float2 uv = ouv[e];
             BaRec r;
