@@ -64,7 +64,7 @@ static inline size_t bb_lds_bytes(int max_nlm, int max_nobs = 0)
 }
 
 __global__ void __launch_bounds__(BB_THREADS)
-k_ba_build(BaDev *jobs, const int *obs_kf, const int *obs_lm, const uint8_t *obs_right, const float2 *obs_uv,
+k_ba_build(BaDev *jobs, const unsigned int *obs_packed, const float2 *obs_uv,
            const int *srt_all, BaRec *recs_all, int *aux_all, int tile_cap, int max_nlm, int *err_flag, int all_active,
            int edge_cache)
 {
@@ -72,8 +72,11 @@ k_ba_build(BaDev *jobs, const int *obs_kf, const int *obs_lm, const uint8_t *obs
     BaDev &jd = jobs[blockIdx.x];
     const int tid = threadIdx.x;
     const int nkf = jd.nkf, nlm = jd.nlm, nobs = jd.nobs;
-    const int *okf = obs_kf + jd.obs_ofs, *olm = obs_lm + jd.obs_ofs, *srt = srt_all + jd.obs_ofs;
-    const uint8_t *ori = obs_right + jd.obs_ofs;
+    // edges in caller order, one packed word each (landmark | keyframe << 16 | camera << 24, written by the host
+    // while it validates them); srt = their (landmark, keyframe) order, not even read when that is the identity
+    const unsigned int *opk = obs_packed + jd.obs_ofs;
+    const int *srt = srt_all + jd.obs_ofs;
+    const bool ident = jd.reserved != 0;
     const float2 *ouv = obs_uv + jd.obs_ofs;
     BaRec *recL = recs_all + jd.rec_ofs, *recP = recL + nobs;
     int *aux = aux_all + jd.aux_ofs;
@@ -107,18 +110,17 @@ k_ba_build(BaDev *jobs, const int *obs_kf, const int *obs_lm, const uint8_t *obs
         for (int i0 = tid; i0 < nobs; i0 += 4 * BB_THREADS) {
             int e4[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int i = i0 + u * BB_THREADS; e4[u] = i < nobs ? srt[i] : 0; }
+            for (int u = 0; u < 4; ++u) { const int i = i0 + u * BB_THREADS; e4[u] = i < nobs ? (ident ? i : srt[i]) : 0; }
             unsigned int v4[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v4[u] = (unsigned int)olm[e4[u]] | ((unsigned int)okf[e4[u]] << 16) | ((ori[e4[u]] ? 1u : 0u) << 24);
+            for (int u = 0; u < 4; ++u) v4[u] = opk[e4[u]];
 #pragma unroll
             for (int u = 0; u < 4; ++u) { const int i = i0 + u * BB_THREADS; if (i < nobs) ed[i] = v4[u]; }
         }
     }
     auto edge = [&](int i) -> unsigned int {
         if (edge_cache) return ed[i];
-        const int e = srt[i];
-        return (unsigned int)olm[e] | ((unsigned int)okf[e] << 16) | ((ori[e] ? 1u : 0u) << 24);
+        return opk[ident ? i : srt[i]];
     };
 
     for (int l = tid; l <= nlm; l += BB_THREADS) { cnt[l] = 0; }
@@ -216,7 +218,7 @@ k_ba_build(BaDev *jobs, const int *obs_kf, const int *obs_lm, const uint8_t *obs
         unsigned int mask = 0;
         for (int q = ostart[l]; q < ostart[l + 1]; ++q, ++i) {
             const unsigned int ev = edge(q);
-            const int e = srt[q], k = (int)((ev >> 16) & 0xffu);
+            const int e = ident ? q : srt[q], k = (int)((ev >> 16) & 0xffu);
             if (k != prev_kf) { ++b; g_blk_kf[b] = k; g_blk_lm[b] = jn; g_blk_es[b] = i; prev_kf = k; mask |= 1u << pidx[k]; }
             g_lm_edges[i] = e;
             const float2 uv = ouv[e];

@@ -388,7 +388,8 @@ int svslam_create(const svslam_limits *lim, svslam_ctx **out)
         const char *wm = std::getenv("SVSLAM_WAIT");        // spin | poll (default)
         c->wait_poll = !(wm && std::strcmp(wm, "spin") == 0);
         c->timing_split = std::getenv("SVSLAM_TIMING_SPLIT") != nullptr;
-        c->ba_host_build = std::getenv("SVSLAM_BA_HOST_BUILD") != nullptr;
+        // the device build takes the edge indices packed into one word (landmark < 2^16, keyframe < 2^8)
+        c->ba_host_build = std::getenv("SVSLAM_BA_HOST_BUILD") != nullptr || lim->max_lm >= 65536 || lim->max_kf >= 256;
     }
     HIPCHK(c, pool_stream(c->device, &c->stream));
     HIPCHK(c, hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
@@ -406,8 +407,8 @@ int svslam_create(const svslam_limits *lim, svslam_ctx **out)
     const size_t J = lim->max_jobs, N = lim->max_pts;
     size_t per_job_pts = N * (8 + 8 + 1 + 4 + 24 + 8 + 1 + 1 + 8) + 1024;
     size_t per_job_ba = (size_t)lim->max_kf * 56 + (size_t)lim->max_lm * 24 +
-                        (size_t)lim->max_obs * (21 + 8 + 32 + 12 + 2 * (size_t)(lim->max_kf + 1) + 8) + (size_t)lim->max_lm * 16 + 8192;
-    // (per edge: raw 21 B, chi2 8 B, two records 32 B, edge + block lists 12 B, pair items <= 2 (K + 1) B)
+                        (size_t)lim->max_obs * (21 + 8 + 32 + 16 + 2 * (size_t)(lim->max_kf + 1) + 8) + (size_t)lim->max_lm * 16 + 8192;
+    // (per edge: raw <= 21 B, chi2 8 B, two records 32 B, edge + block lists 16 B, pair items <= 2 (K + 1) B)
     per_job_ba += 4 * (size_t)(ba_tile_bound(lim->max_lm, lim->max_obs, lim->max_kf, std::max(ba_tile_cap(lim->max_kf), 64)) + 2) *
                   ((size_t)lim->max_kf * (lim->max_kf + 1) / 2 + 1);          // per-tile pair ranges at their upper bound
     size_t per_job = std::max(per_job_pts, per_job_ba) + (size_t)lim->max_corners * 8 + 4096;
@@ -841,10 +842,10 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
     // arena: cams | jobs | poses | points | [raw edges + order (device build)] | chi2 + flag (out) |
     //        records | aux  (records and aux are device-only when the device builds the structure)
     size_t ocams = c->ar.take(sizeof(BaCams));
-    size_t okf_o = 0, olm_o = 0, ori_o = 0, ouv_o = 0, osrt_o = 0;
+    size_t opk_o = 0, ouv_o = 0, osrt_o = 0;
     if (!c->ba_host_build) {
-        okf_o = c->ar.take(sizeof(int) * TO); olm_o = c->ar.take(sizeof(int) * TO); osrt_o = c->ar.take(sizeof(int) * TO);
-        ouv_o = c->ar.take(sizeof(float) * 2 * TO); ori_o = c->ar.take(TO);
+        opk_o = c->ar.take(sizeof(unsigned int) * TO); osrt_o = c->ar.take(sizeof(int) * TO);
+        ouv_o = c->ar.take(sizeof(float) * 2 * TO);
     }
     size_t ojobs = c->ar.take(sizeof(BaDev) * njobs);          // read back from here ...
     size_t oposes = c->ar.take(sizeof(double) * 7 * std::max(total_kf, 1));
@@ -894,24 +895,37 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
         aux_total = bump.load();
         (void)c->ar.take(sizeof(int) * aux_total);
     } else {
-        // The device builds the structure (k_ba_build).  The host validates the indices and tells the
-        // device the (landmark, keyframe) order of the edges: the identity for the order the backend
-        // gathers them in (src/backend.cpp:83-160), a stable sort otherwise.
+        // The device builds the structure (k_ba_build).  One pass of the pool over the problems validates the
+        // edge indices, packs them (landmark | keyframe << 16 | camera << 24: 4 bytes per edge instead of 9),
+        // notes whether they arrive in (landmark, keyframe) order — the order the backend gathers them in
+        // (src/backend.cpp:83-160); a stable sort otherwise — and copies the problem's measurements, poses and
+        // positions into the staging arena: every input byte is touched once, by the thread that has it in cache.
         std::vector<int> bad((size_t)njobs, 0);
         int *srt = hp<int>(c, osrt_o);
+        unsigned int *pk = hp<unsigned int>(c, opk_o);
+        float *auv = hp<float>(c, ouv_o);
+        double *aposes = hp<double>(c, oposes), *apts = hp<double>(c, opts);
         auto check_one = [&](int i) {
             const svslam_ba_job &j = jobs[i];
             const int *kf = obs_kf + j.obs_ofs, *lm = obs_lm + j.obs_ofs;
-            int *sr = srt + j.obs_ofs;
+            const uint8_t *rt = obs_is_right + j.obs_ofs;
+            unsigned int *pj = pk + j.obs_ofs;
             bool sorted = true;
             for (int e = 0; e < j.nobs; ++e) {
                 const int k = kf[e], l = lm[e];
                 if (k < 0 || k >= j.nkf || l < 0 || l >= j.nlm) { bad[(size_t)i] = 1; return; }
                 if (e && !((lm[e - 1] < l) || (lm[e - 1] == l && kf[e - 1] <= k))) sorted = false;
-                sr[e] = e;
+                pj[e] = (unsigned int)l | ((unsigned int)k << 16) | ((rt[e] ? 1u : 0u) << 24);
             }
-            if (!sorted)
+            if (!sorted) {
+                int *sr = srt + j.obs_ofs;
+                for (int e = 0; e < j.nobs; ++e) sr[e] = e;
                 std::stable_sort(sr, sr + j.nobs, [&](int a, int b) { return lm[a] != lm[b] ? lm[a] < lm[b] : kf[a] < kf[b]; });
+            }
+            if (j.nobs) memcpy(auv + 2 * (size_t)j.obs_ofs, obs_uv + 2 * (size_t)j.obs_ofs, sizeof(float) * 2 * j.nobs);
+            if (j.nkf) memcpy(aposes + 7 * (size_t)j.kf_ofs, poses + 7 * (size_t)j.kf_ofs, sizeof(double) * 7 * j.nkf);
+            if (j.nlm) memcpy(apts + 3 * (size_t)j.lm_ofs, pts + 3 * (size_t)j.lm_ofs, sizeof(double) * 3 * j.nlm);
+            dj[i].reserved = sorted ? 1 : 0;
         };
         if (c->pool && njobs > 1) c->pool->parallel_for(njobs, check_one);
         else for (int i = 0; i < njobs; ++i) check_one(i);
@@ -921,7 +935,7 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
             const svslam_ba_job &j = jobs[i];
             BaDev &d = dj[i];
             d.kf_ofs = j.kf_ofs; d.nkf = j.nkf; d.lm_ofs = j.lm_ofs; d.nlm = j.nlm; d.obs_ofs = j.obs_ofs; d.nobs = j.nobs;
-            d.nblk = d.na = d.ncontrib = d.ntile = 0; d.iters_done = 0;
+            d.nblk = d.na = d.ncontrib = d.ntile = 0; d.iters_done = 0; d.nmv = 0;
             d.rec_ofs = 2 * j.obs_ofs;
             d.lay_nblk = j.nobs; d.lay_na = j.nkf; d.lay_ntile = ba_tile_bound(j.nlm, j.nobs, j.nkf, tile_cap);
             d.aux_ofs = (int)at;
@@ -931,15 +945,11 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
         aux_total = at;
         (void)c->ar.take(sizeof(int) * aux_total);
         if (c->ar.off > c->ar.cap) return fail(c, "local_ba: staging arena too small for the problem structure (%zu > %zu bytes)", c->ar.off, c->ar.cap);
-        if (total_obs > 0) {
-            memcpy(hp<void>(c, okf_o), obs_kf, sizeof(int) * total_obs);
-            memcpy(hp<void>(c, olm_o), obs_lm, sizeof(int) * total_obs);
-            memcpy(hp<void>(c, ouv_o), obs_uv, sizeof(float) * 2 * total_obs);
-            memcpy(hp<void>(c, ori_o), obs_is_right, (size_t)total_obs);
-        }
     }
-    if (total_kf > 0) memcpy(hp<void>(c, oposes), poses, sizeof(double) * 7 * total_kf);
-    if (total_lm > 0) memcpy(hp<void>(c, opts), pts, sizeof(double) * 3 * total_lm);
+    if (c->ba_host_build) {
+        if (total_kf > 0) memcpy(hp<void>(c, oposes), poses, sizeof(double) * 7 * total_kf);
+        if (total_lm > 0) memcpy(hp<void>(c, opts), pts, sizeof(double) * 3 * total_lm);
+    }
     c->host_ns[4] += now_ns() - t_prep0;
     if (h2d(c, 0, in_end)) return -1;
     if (h2d(c, oflag, oflag + sizeof(int) * 4)) return -1;
@@ -947,9 +957,9 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
     tm_begin(c, c->timing_split ? FAM_DBG2 : FAM_BA, njobs);
     if (!c->ba_host_build) {
         hipLaunchKernelGGL(k_ba_build, dim3(njobs), dim3(BB_THREADS), bb_lds_bytes(max_nlm, max_nobs), c->stream, dp<BaDev>(c, ojobs),
-                           dp<int>(c, okf_o), dp<int>(c, olm_o), dp<uint8_t>(c, ori_o), dp<float2>(c, ouv_o), dp<int>(c, osrt_o),
+                           dp<unsigned int>(c, opk_o), dp<float2>(c, ouv_o), dp<int>(c, osrt_o),
                            dp<BaRec>(c, orecs), dp<int>(c, oaux), tile_cap, max_nlm, dp<int>(c, oflag), 0,
-                           bb_edge_cache_fits(max_nlm, max_nobs) && c->lim.max_lm < 65536 ? 1 : 0);
+                           bb_edge_cache_fits(max_nlm, max_nobs) ? 1 : 0);
         if (c->timing_split) { tm_end(c); tm_begin(c, FAM_DBG3, njobs); }
     }
     hipLaunchKernelGGL(k_local_ba_t<0>, dim3(njobs), dim3(BA_THREADS), ba_lds_bytes(c->lim.max_kf), c->stream,
@@ -1015,8 +1025,8 @@ int svslam_sba_open(svslam_ctx *c, const double cam_l[4], const double ext_l[7],
     const int tile_cap = ba_tile_cap(c->lim.max_kf);
     const size_t TO = (size_t)nobs;
     size_t ocams = c->ar.take(sizeof(BaCams));
-    size_t okf_o = c->ar.take(sizeof(int) * TO), olm_o = c->ar.take(sizeof(int) * TO), osrt_o = c->ar.take(sizeof(int) * TO);
-    size_t ouv_o = c->ar.take(sizeof(float) * 2 * TO), ori_o = c->ar.take(TO);
+    size_t opk_o = c->ar.take(sizeof(unsigned int) * TO), osrt_o = c->ar.take(sizeof(int) * TO);
+    size_t ouv_o = c->ar.take(sizeof(float) * 2 * TO);
     size_t ojobs = c->ar.take(sizeof(BaDev));
     size_t oposes = c->ar.take(sizeof(double) * 7 * nkf);
     size_t opts = c->ar.take(sizeof(double) * 3 * nlm);
@@ -1030,32 +1040,33 @@ int svslam_sba_open(svslam_ctx *c, const double cam_l[4], const double ext_l[7],
     memcpy(cams->cam[0], cam_l, 32); memcpy(cams->cam[1], cam_r, 32);
     memcpy(cams->ext[0], ext_l, 56); memcpy(cams->ext[1], ext_r, 56);
     int *srt = hp<int>(c, osrt_o);
+    unsigned int *pk = hp<unsigned int>(c, opk_o);
     bool sorted = true;
     for (int e = 0; e < nobs; ++e) {
         const int k = obs_kf[e], l = obs_lm[e];
         if (k < 0 || k >= nkf || l < 0 || l >= nlm) return fail(c, "sba_open: edge %d index out of range", e);
         if (e && !((obs_lm[e - 1] < l) || (obs_lm[e - 1] == l && obs_kf[e - 1] <= k))) sorted = false;
         srt[e] = e;
+        pk[e] = (unsigned int)l | ((unsigned int)k << 16) | ((obs_is_right[e] ? 1u : 0u) << 24);
     }
     if (!sorted) std::stable_sort(srt, srt + nobs, [&](int a, int b) { return obs_lm[a] != obs_lm[b] ? obs_lm[a] < obs_lm[b] : obs_kf[a] < obs_kf[b]; });
     BaDev &d = *hp<BaDev>(c, ojobs);
     d.kf_ofs = 0; d.nkf = nkf; d.lm_ofs = 0; d.nlm = nlm; d.obs_ofs = 0; d.nobs = nobs;
-    d.nblk = d.na = d.ncontrib = d.ntile = 0; d.iters_done = 0; d.rec_ofs = 0;
+    d.nblk = d.na = d.ncontrib = d.ntile = 0; d.iters_done = 0; d.rec_ofs = 0; d.nmv = 0; d.reserved = sorted ? 1 : 0;
     d.lay_nblk = nobs; d.lay_na = nkf; d.lay_ntile = ba_tile_bound(nlm, nobs, nkf, tile_cap);
     d.aux_ofs = 0;
     (void)c->ar.take(sizeof(int) * (ba_aux_layout(nkf, nlm, nobs, d.lay_nblk, d.lay_na, 0, d.lay_ntile).total + ba_pitem_bound(nobs, nkf)));
     if (c->ar.off > c->ar.cap) return fail(c, "sba_open: staging arena too small");
-    memcpy(hp<void>(c, okf_o), obs_kf, sizeof(int) * TO); memcpy(hp<void>(c, olm_o), obs_lm, sizeof(int) * TO);
-    memcpy(hp<void>(c, ouv_o), obs_uv, sizeof(float) * 2 * TO); memcpy(hp<void>(c, ori_o), obs_is_right, TO);
+    memcpy(hp<void>(c, ouv_o), obs_uv, sizeof(float) * 2 * TO);
     memcpy(hp<void>(c, oposes), poses, sizeof(double) * 7 * nkf);
     memcpy(hp<void>(c, opts), pts, sizeof(double) * 3 * nlm);
     hp<int>(c, oflag)[0] = 0;
     if (h2d(c, 0, in_end)) return -1;
     if (h2d(c, oflag, oflag + sizeof(int) * 4)) return -1;
-    hipLaunchKernelGGL(k_ba_build, dim3(1), dim3(BB_THREADS), bb_lds_bytes(nlm, nobs), c->stream, dp<BaDev>(c, ojobs), dp<int>(c, okf_o),
-                       dp<int>(c, olm_o), dp<uint8_t>(c, ori_o), dp<float2>(c, ouv_o), dp<int>(c, osrt_o), dp<BaRec>(c, orecs),
+    hipLaunchKernelGGL(k_ba_build, dim3(1), dim3(BB_THREADS), bb_lds_bytes(nlm, nobs), c->stream, dp<BaDev>(c, ojobs), dp<unsigned int>(c, opk_o),
+                       dp<float2>(c, ouv_o), dp<int>(c, osrt_o), dp<BaRec>(c, orecs),
                        dp<int>(c, oaux), tile_cap, nlm, dp<int>(c, oflag), 1 /* every keyframe active on every rank */,
-                       bb_edge_cache_fits(nlm, nobs) && c->lim.max_lm < 65536 ? 1 : 0);
+                       bb_edge_cache_fits(nlm, nobs) ? 1 : 0);
     HIPCHK(c, hipGetLastError());
     if (d2h_sync(c, oflag, oflag + sizeof(int) * 4)) return -1;
     if (hp<int>(c, oflag)[0]) return fail(c, "sba_open: the structure build overflowed a capacity");
