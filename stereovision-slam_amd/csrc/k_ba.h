@@ -569,7 +569,8 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
     double *red = bp + np;
     double *PTab = red + BA_WAVES;
     double *CTab = PTab + BA_PT * na;
-    double *part = CTab + 2 * BA_CT;               // [BA_ROWS][32] row partial sums (pose pass, single-view pass: 27 used)
+    double *PTab2 = CTab + 2 * BA_CT;              // pose table of the trial state (errors of the trial, see the back-substitution)
+    double *part = PTab2 + BA_PT * na;             // [BA_ROWS][32] row partial sums (pose pass, single-view pass: 27 used)
     double *Wt = part + 32 * BA_ROWS;              // [tile_cap][18] blocks of the current tile
     double *Dl = Wt + 18 * tile_cap;               // [tile_cap][6]  (Hll + lambda I)^-1, symmetric
     double *Bl = Dl + 6 * tile_cap;                // [tile_cap][3]  bl
@@ -614,21 +615,24 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
         CT[9] = cams.ext[tid][4]; CT[10] = cams.ext[tid][5]; CT[11] = cams.ext[tid][6];
         CT[12] = cams.cam[tid][0]; CT[13] = cams.cam[tid][1]; CT[14] = cams.cam[tid][2]; CT[15] = cams.cam[tid][3];
     }
-    auto pose_table = [&]() {
+    auto pose_table_into = [&](double *tab) {
         __syncthreads();
         if (tid < na) {
             const double *T = poses + 7 * act_kf[tid];
-            double *PT = PTab + BA_PT * tid;
+            double *PT = tab + BA_PT * tid;
             d_quat_to_R(T, PT);
             PT[9] = T[4]; PT[10] = T[5]; PT[11] = T[6];
         }
         __syncthreads();
     };
+    auto pose_table = [&]() { pose_table_into(PTab); };
 
     // errors at the current state: thread per edge in landmark-major order (coalesced records,
     // near-coalesced landmark reads, poses from the LDS table)
+    // (evaluated through the SECOND pose table: the first keeps the linearisation point of the iteration, which is
+    // also where the successor of a rejected trial has to linearise)
     auto error_pass = [&]() -> double {
-        pose_table();
+        pose_table_into(PTab2);
         double chi = 0;
         for (int i = tid; i < nobs; i += BA_THREADS) {
             const BaRec rc = recL[i];
@@ -636,7 +640,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
             const double *Xp = pts + 3 * (size_t)(rc.lmkc & BA_LM_MASK);
             const double X[3] = { Xp[0], Xp[1], Xp[2] };
             BaProj o;
-            ba_project(PTab + BA_PT * (kc >> 1), CTab + BA_CT * (kc & 1), X, rc.u, rc.v, o);
+            ba_project(PTab2 + BA_PT * (kc >> 1), CTab + BA_CT * (kc & 1), X, rc.u, rc.v, o);
             err[2 * i] = o.ex; err[2 * i + 1] = o.ey;
             double r0, r1;
             d_huber(o.ex * o.ex + o.ey * o.ey, delta, r0, r1);
@@ -744,13 +748,13 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
             if (lin) {
             for (int i = tid; i < 7 * nkf; i += BA_THREADS) poses_b[i] = poses[i];
             for (int i = tid; i < 3 * nlm; i += BA_THREADS) pts_b[i] = pts[i];
-            for (int i = tid; i < np * np; i += BA_THREADS) {
-                int r = i / np, c = i - r * np;
-                double v = 0;
-                if (r / 6 == c / 6) v = Hpp[36 * (r / 6) + (r % 6) * 6 + (c % 6)];
-                if (r == c && MODE == 0) v += lambda;          // shared map: added once, to the reduced system
-                S[(size_t)r * ld + c] = v;
-            }
+            for (int r = wv; r < np; r += BA_WAVES)
+                for (int c = lane; c < np; c += 64) {
+                    double v = 0;
+                    if (r / 6 == c / 6) v = Hpp[36 * (r / 6) + (r % 6) * 6 + (c % 6)];
+                    if (r == c && MODE == 0) v += lambda;          // shared map: added once, to the reduced system
+                    S[(size_t)r * ld + c] = v;
+                }
             for (int i = tid; i < np; i += BA_THREADS) bs[i] = bp[i];
             }
             __syncthreads();
@@ -1044,23 +1048,40 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                 double *invd = xp;
                 if (prof && tid == 0) { long long t_ = wall_clock64(); prof[7] += t_ - tprev; }
                 if (ok) {
-                    // rhs holds y; back-substitution L^T x = y with the stored inverse pivots
-                    double ivk[2];
-                    ivk[0] = (lane < np) ? invd[lane] : 0.0;
-                    ivk[1] = (lane + 64 < np) ? invd[lane + 64] : 0.0;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    for (int i = lane; i < np; i += 64) xp[i] = rhs[i] ;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    for (int k = np - 1; k >= 0; --k) {
-                        const double ik = readlane_f64(ivk[k >> 6], k & 63);
-                        const double xk = xp[k] * ik;
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        for (int i = lane; i <= k; i += 64) {
-                            if (i == k) xp[i] = xk;
-                            else xp[i] -= S[(size_t)k * ld + i] * xk;
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    // rhs holds y; back-substitution L^T x = y with the stored inverse pivots.  x lives in registers
+                    // (lane i: x_i, x_{i+64}, x_{i+128}), the pivot comes over v_readlane, row k of L is requested one
+                    // step ahead: the serial chain per unknown is readlane -> multiply -> FMA, no LDS round trip.
+                    double ivk[3], xr[3], srow[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const int i = lane + 64 * c;
+                        ivk[c] = i < np ? invd[i] : 0.0;
+                        xr[c] = i < np ? rhs[i] : 0.0;
+                        srow[c] = i < np ? S[(size_t)(np - 1) * ld + i] : 0.0;
                     }
+                    for (int k = np - 1; k >= 0; --k) {
+                        const int kc = k >> 6, kl = k & 63;
+                        double cur[3], nxt[3];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            cur[c] = srow[c];
+                            const int i = lane + 64 * c;
+                            nxt[c] = (k > 0 && i < k) ? S[(size_t)(k - 1) * ld + i] : 0.0;
+                        }
+                        const double xsel = kc == 0 ? xr[0] : kc == 1 ? xr[1] : xr[2];
+                        const double isel = kc == 0 ? ivk[0] : kc == 1 ? ivk[1] : ivk[2];
+                        const double xk = readlane_f64(xsel, kl) * readlane_f64(isel, kl);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const int i = lane + 64 * c;
+                            if (i < k) xr[c] -= cur[c] * xk;
+                            else if (i == k) xr[c] = xk;
+                            srow[c] = nxt[c];
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { const int i = lane + 64 * c; if (i < np) xp[i] = xr[c]; }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 }
                 if (lane == 0) iflag[0] = ok;
             }
@@ -1101,7 +1122,6 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                         scale_part += x * (lambda * x + b3[a]);
                     }
                 }
-                __syncthreads();     // every landmark used the old poses / table before they move
                 for (int a = tid; a < na; a += BA_THREADS) {
                     const int k = act_kf[a];
                     double dT[7], Tn[7], x6[6];
@@ -1163,7 +1183,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
 static inline size_t ba_lds_fixed_bytes(int max_kf)
 {
     size_t np = 6 * (size_t)max_kf;
-    return ((np + 1) * (np + 1) + 3 * np + 36 * (size_t)max_kf + BA_WAVES + BA_PT * (size_t)max_kf + 2 * BA_CT +
+    return ((np + 1) * (np + 1) + 3 * np + 36 * (size_t)max_kf + BA_WAVES + 2 * BA_PT * (size_t)max_kf + 2 * BA_CT +
             32 * BA_ROWS) * sizeof(double) +
            ((BA_MAX_NP / 6) * (BA_MAX_NP / 6 + 1) / 2 + 1 + BA_PIT_CAP) * sizeof(int) + 64;
 }
