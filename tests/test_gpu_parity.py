@@ -483,3 +483,35 @@ def test_local_ba_structure_built_on_device_equals_host_build(svs, monkeypatch):
     for i in range(0, 8, 2):
         assert np.array_equal(rd[i][0], rd[i + 1][0]) and np.array_equal(rd[i][1], rd[i + 1][1])
     cd.close(); ch.close()
+
+
+@pytest.mark.gpu
+def test_local_ba_wide_window_without_single_view_grouping(svs, orc, monkeypatch):
+    """20 keyframes with landmarks seen from all of them: block-count keys + keyframe keys exceed the sort's key
+    space, so the structure falls back to the ungrouped numbering (every landmark through the LDS tiles, no
+    single-view row pass).  Device build == host build bit for bit, both == the oracle at the usual tolerances;
+    a 16-keyframe problem next to it stays on the grouped path."""
+    rng = np.random.default_rng(77)
+    jobs = []
+    for (nkf, nlm, keep) in ((20, 300, 0.6), (16, 400, 0.12)):
+        p = cm.make_ba_problem(rng, nkf, nlm)
+        m = rng.random(len(p["okf"])) < keep
+        m |= p["olm"] < 3                                   # a few landmarks keep all their observations
+        o = np.lexsort((p["okf"][m], p["olm"][m]))
+        jobs.append((p["poses0"], p["pts0"], p["okf"][m][o], p["olm"][m][o], p["ori"][m][o], p["ouv"][m][o]))
+    nblk0 = len(np.unique(jobs[0][3].astype(np.int64) * 64 + jobs[0][2]))
+    assert np.bincount(jobs[0][3][::1]).max() >= 2 * 14 and nblk0 > 0      # wide enough for the fallback (max count + nkf > 33)
+    kw = dict(max_slots=1, max_jobs=2, max_kf=20, max_lm=512, max_obs=16384)
+    cd = svs.Context(cm.W, cm.H, **kw)
+    monkeypatch.setenv("SVSLAM_BA_HOST_BUILD", "1")
+    ch = svs.Context(cm.W, cm.H, **kw)
+    monkeypatch.delenv("SVSLAM_BA_HOST_BUILD")
+    rd = cd.local_ba(jobs, cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R)
+    rh = ch.local_ba(jobs, cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R)
+    for (pd, xd, c2d, itd), (ph, xh, c2h, ith), job in zip(rd, rh, jobs):
+        assert itd == ith and np.array_equal(pd, ph) and np.array_equal(xd, xh) and np.array_equal(c2d, c2h)
+        pa, xa, ca, ia = orc.local_ba(cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R, *job, jac_mode=0)
+        assert itd == ia
+        assert np.allclose(pd[:, 4:], pa[:, 4:], atol=1e-6) and np.allclose(pd[:, :4], pa[:, :4], atol=1e-7)
+        assert np.allclose(xd, xa, rtol=1e-6, atol=1e-6)
+    cd.close(); ch.close()
