@@ -99,10 +99,11 @@ def thread_cpu_seconds():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("SVS_BENCH_STREAMS", "6144")),
-                    help="independent stereo streams per GPU, advanced in lockstep")
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("SVS_BENCH_STREAMS", "0")),
+                    help="independent stereo streams per GPU, advanced in lockstep (0 = the largest of 12288 / 8192 / "
+                         "6144 whose frame buffers fit the GPU's memory for this --warmup + --steps)")
     ap.add_argument("--groups", type=int, default=int(os.environ.get("SVS_BENCH_GROUPS", "0")),
                     help="host threads per GPU, each driving streams/groups streams through its own "
                          "svslam context (own HIP stream): one group's BA overlaps the others' tracking")
@@ -147,19 +148,26 @@ def main():
     # always outside the timed region: keep it under ~190 GB.
     SW, SH = (1241, 376) if args.full_res else (W, H)     # stored frame size
     FB = Wm + K
-    cap = int(190e9 // (2 * SW * SH * FB))
+    budget = 225e9                                   # of the MI355X's 288 GB; the pyramids and work buffers need ~1 MB per stream
+    if torch.cuda.is_available():
+        budget = min(budget, 0.8 * torch.cuda.mem_get_info(local_rank)[0])
+    cap = int(budget // (2 * SW * SH * FB + (1 << 20)))
+    if S <= 0:
+        # more streams per launch fill the chip better (measured: 6144 / 8192 / 12288 streams = 1.00 / 1.04 / 1.08),
+        # the frame ring of warmup + steps frames per stream decides what fits
+        S = next((c for c in (12288, 8192, 6144) if c <= cap), cap)
     if S > cap:
         S = max(512, cap // 512 * 512) if cap >= 512 else max(1, cap)
     # host layout from the cores this rank may actually use (cgroup quota / ranks on the node):
-    # about two threads per core (half of them are waiting on the GPU at any time), at most 8
-    # groups (>= 512 streams each at the default size) x at most 4 bookkeeping threads
+    # about two threads per core (half of them are waiting on the GPU at any time), at most 12
+    # groups x at most 4 bookkeeping threads
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     cores = max(1, effective_cpus() // max(1, local_world))
     pinned = set() if args.no_pin else sdist.pin_to_device_numa(local_rank, min_cpus=cores)
-    G = args.groups if args.groups > 0 else min(8, cores)
+    # (about 1024 streams per group: 8 groups up to 8192 streams, 12 beyond; tools/sweep.sh)
+    G = args.groups if args.groups > 0 else min(12 if S >= 12288 else 8, cores)
     G = max(1, min(G, S))
-    while S % G:
-        G -= 1
+    S -= S % G                                       # whole groups (8192 streams in 12 groups: 12 x 682)
     if args.host_threads <= 0:
         args.host_threads = max(1, min(4, (2 * cores + G - 1) // G))
     Sg = S // G
