@@ -12,6 +12,7 @@ f=$(find $O/rp -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$f" ] && 
 timeout 300 python tools/trace_busy.py $O/rp > $O/trace_busy.txt 2>&1 < /dev/null
 rm -rf $O/rp
 timeout 600 python bench.py --full-res --steps 60 --no-cpu-baseline > $O/bench_full_res.json 2> $O/bench_full_res.err < /dev/null
+timeout 600 python bench.py --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_100_10.json 2> $O/bench_100_10.err < /dev/null
 timeout 120 python tools/kbench.py gftt > $O/kbench_gftt.txt 2>&1 < /dev/null
 SVSLAM_TIMING_SPLIT=1 timeout 120 python tools/kbench.py gftt > $O/kbench_gftt_split.txt 2>&1 < /dev/null
 timeout 200 python tools/kbench.py lk > $O/kbench_lk.txt 2>&1 < /dev/null
