@@ -156,6 +156,10 @@ def main():
         # more streams per launch fill the chip better (measured: 6144 / 8192 / 12288 streams = 1.00 / 1.04 / 1.08),
         # the frame ring of warmup + steps frames per stream decides what fits
         S = next((c for c in (12288, 8192, 6144) if c <= cap), cap)
+        # a rank that may use only a few cores (N ranks sharing one CPU quota) cannot feed that many streams:
+        # ~27 us of host CPU per frame; keep its memory footprint in proportion
+        lw = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        S = min(S, 1024 * max(1, effective_cpus() // max(1, lw)))
     if S > cap:
         S = max(512, cap // 512 * 512) if cap >= 512 else max(1, cap)
     # host layout from the cores this rank may actually use (cgroup quota / ranks on the node):
