@@ -76,7 +76,7 @@ def lkbench(nj=512, npts=150):
     c = svs.Context(cm.W, cm.H, max_slots=3, max_jobs=nj, max_pts=max(len(pts), 8), max_kf=0, max_lm=0, max_obs=0)
     c.pyramid([0, 1, 2], [l0, r0, l1])
     for name, dst in (("temporal", 2), ("stereo", 1)):
-        for mc in (1, 2, 4, 30):
+        for mc in ((int(os.environ["LKBENCH_MC"]),) if "LKBENCH_MC" in os.environ else (1, 2, 4, 30)):
             prm = svs.LkParams(3, mc, 0.01, 1e-4, 1)
             c.lk([(0, dst, pts, pts)] * nj, prm)
             c.timing_reset() if hasattr(c, "timing_reset") else None
