@@ -372,6 +372,7 @@ def main():
                                  "pinned_to_gpu_numa_cpus": len(pinned),
                                  "minor_page_faults_per_step": round((ru1.ru_minflt - ru0.ru_minflt) / K, 1),
                                  "rss_growth_bytes_per_frame": round((rss1 - rss0) / max(S * K, 1), 1),
+                                 "rss_gb": round(rss1 / 1e9, 2),
                                  "cpus_busy_by_thread_name": cpu_by_thread,
                              "capacity_events": {"corners_dropped": cnt.get("corners_dropped", 0), "ba_skipped": cnt.get("ba_skipped", 0)}},
         }
