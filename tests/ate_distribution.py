@@ -9,7 +9,7 @@ DISTRIBUTION of the trajectory error, not about single runs.  This tool measures
 ATE (RMSE after rigid alignment) against the renderer's ground truth for both paths, the paired
 difference, and a bootstrap confidence interval of the relative difference of the means.
 
-  python tools/ate_distribution.py [n_streams] [n_frames] > profiles/r2_ate_distribution.txt
+  python tests/ate_distribution.py [n_streams] [n_frames] > profiles/r2_ate_distribution.txt
 
 Used by tests/test_gpu_ate_distribution.py (-m gpu).  The twin is test infrastructure."""
 import importlib
@@ -20,7 +20,7 @@ import threading
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p_ in (ROOT, os.path.join(ROOT, "tests")):
+for p_ in (ROOT, os.path.join(ROOT, "tests")):  # (this file lives in tests/: it drives the CPU twin, test infrastructure)
     if p_ not in sys.path:
         sys.path.insert(0, p_)
 

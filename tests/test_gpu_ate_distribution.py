@@ -3,7 +3,7 @@ path are chaotic in each other once an outlier bit flips, so the crit
 where it is meaningful — on the DISTRIBUTION of the trajectory error over many seeded streams:
 HIP pipeline vs the reference-faithful CPU twin (numeric BA Jacobians), paired by stream, with a
 bootstrap confidence interval.  Committed table of a larger run: profiles/r2_ate_distribution.txt
-(tools/ate_distribution.py)."""
+(tests/ate_distribution.py)."""
 import os
 import sys
 
@@ -12,8 +12,6 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
 def test_ate_distribution_hip_vs_reference_faithful_twin():

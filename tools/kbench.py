@@ -46,14 +46,27 @@ def ba(nj=1, nkf=10, nlm=700, reps=3):
     c.close()
 
 
+def _inputs(npts, min_dist, stereo=False):
+    """corners of the left image (and their stereo matches / landmarks) from the HIP kernels themselves: the tools
+    do not touch the oracle"""
+    l0, r0 = svs.synth_pair(3, 0)
+    c = svs.Context(cm.W, cm.H, max_slots=2, max_jobs=2, max_pts=max(npts, 8), max_corners=max(npts, 8), max_kf=0, max_lm=0, max_obs=0)
+    c.pyramid([0, 1], [l0, r0])
+    pts = c.gftt([(0, None)], max_corners=npts, min_dist=min_dist)[0]
+    out = (pts,)
+    if stereo:
+        q, st, _ = c.lk([(0, 1, pts, pts)])[0]
+        xyz, ok = c.triangulate([(pts, q, None, 0.0)], cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R)[0]
+        out = (pts, q, st, xyz, ok)
+    c.close()
+    return out
+
+
 def frontend(nj=1, npts=230):
     l0, r0 = svs.synth_pair(3, 0); l1, _ = svs.synth_pair(3, 1)
-    import oracle_lib as orc
-    pts = orc.gftt(l0, max_corners=npts, min_dist=8.0)
+    pts, q, st, xyz, ok = _inputs(npts, 8.0, stereo=True)
     c = svs.Context(cm.W, cm.H, max_slots=3 * nj, max_jobs=3 * nj, max_kf=0, max_lm=0, max_obs=0)
     c.pyramid(list(range(3 * nj)), [l0, r0, l1] * nj)
-    q, st, _ = orc.lk(l0, r0, pts, pts)
-    xyz, ok = orc.triangulate(cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R, pts, q)
     m = (st > 0) & (ok > 0)
     c.timing(True)
     for r in range(3):
@@ -71,8 +84,7 @@ def frontend(nj=1, npts=230):
 def lkbench(nj=512, npts=150):
     """LK throughput at bench scale: nj jobs x npts points, temporal and stereo pairs, by iteration cap."""
     l0, r0 = svs.synth_pair(3, 0); l1, _ = svs.synth_pair(3, 1)
-    import oracle_lib as orc
-    pts = orc.gftt(l0, max_corners=npts, min_dist=20.0)
+    pts, = _inputs(npts, 20.0)
     c = svs.Context(cm.W, cm.H, max_slots=3, max_jobs=nj, max_pts=max(len(pts), 8), max_kf=0, max_lm=0, max_obs=0)
     c.pyramid([0, 1, 2], [l0, r0, l1])
     for name, dst in (("temporal", 2), ("stereo", 1)):
@@ -93,8 +105,7 @@ def lkbench(nj=512, npts=150):
 def gfttbench(nj=512):
     """GFTT and pyramid throughput at bench scale: nj images per launch, no mask / 80 / 230 mask squares"""
     l0, r0 = svs.synth_pair(3, 0)
-    import oracle_lib as orc
-    pts = orc.gftt(l0, max_corners=230, min_dist=8.0)
+    pts, = _inputs(230, 8.0)
     c = svs.Context(cm.W, cm.H, max_slots=nj, max_jobs=nj, max_pts=256, max_kf=0, max_lm=0, max_obs=0)
     c.pyramid(list(range(nj)), [l0 if i % 2 == 0 else r0 for i in range(nj)])
     for nr in (0, 80, 230):

@@ -17,7 +17,7 @@ timeout 120 python tools/kbench.py gftt > $O/kbench_gftt.txt 2>&1 < /dev/null
 SVSLAM_TIMING_SPLIT=1 timeout 120 python tools/kbench.py gftt > $O/kbench_gftt_split.txt 2>&1 < /dev/null
 timeout 200 python tools/kbench.py lk > $O/kbench_lk.txt 2>&1 < /dev/null
 timeout 300 python tools/kbench.py tput > $O/kbench_tput.txt 2>&1 < /dev/null
-timeout 900 python tools/ate_distribution.py 384 320 --analytic-too > $O/ate_distribution.txt 2> $O/ate_distribution.err < /dev/null
+timeout 900 python tests/ate_distribution.py 384 320 --analytic-too > $O/ate_distribution.txt 2> $O/ate_distribution.err < /dev/null
 timeout 900 bash tools/pmc_traffic.sh > $O/pmc_traffic.log 2>&1 < /dev/null
 cp gpurun_out/pmc_traffic_raw.json $O/ 2>/dev/null
 timeout 600 bash tools/lat.sh > $O/latency_small_S.txt 2>&1 < /dev/null
