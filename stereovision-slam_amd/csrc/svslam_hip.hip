@@ -78,6 +78,7 @@ struct svslam_ctx {
     // host-side wall time (ns): 0 h2d enqueue, 1 d2h enqueue, 2 stream wait, 3 launches, 4 staging memcpy/prep
     long long host_ns[8] = { 0 };
     bool wait_poll = true;
+    bool wait_block = false;    // SVSLAM_WAIT=block: the completion event sleeps in the driver (hipEventBlockingSync)
     bool low_latency = false;   // svslam_set_low_latency: 4-wave pose-only blocks
     bool timing_split = false;  // SVSLAM_TIMING_SPLIT: per-kernel events of the multi-kernel families (families 6..9)
     bool ba_host_build = false; // SVSLAM_BA_HOST_BUILD: problem structure on the host (the checker of k_ba_build), A/B
@@ -198,8 +199,10 @@ hipError_t wait_stream(svslam_ctx *c)
         if (dt < 10000) continue;
         // back off with the age of the wait: a 100 us kernel is polled every ~20 us, a
         // multi-millisecond BA batch every ~150 us (overshoot stays below ~1/8 of the wait)
+        static const long long nap_min = []{ const char *e = std::getenv("SVSLAM_POLL_MIN_US"); return e ? atoll(e) * 1000 : 20000LL; }();
+        static const long long nap_max = []{ const char *e = std::getenv("SVSLAM_POLL_MAX_US"); return e ? atoll(e) * 1000 : 150000LL; }();
         long long nap = dt >> 3;
-        nap = nap < 20000 ? 20000 : (nap > 150000 ? 150000 : nap);
+        nap = nap < nap_min ? nap_min : (nap > nap_max ? nap_max : nap);
         struct timespec ts = { 0, (long)nap };
         nanosleep(&ts, nullptr);
     }
@@ -385,14 +388,15 @@ int svslam_create(const svslam_limits *lim, svslam_ctx **out)
     *out = c; // returned even on failure so the caller can read the error
     HIPCHK(c, hipSetDevice(c->device));
     {
-        const char *wm = std::getenv("SVSLAM_WAIT");        // spin | poll (default)
-        c->wait_poll = !(wm && std::strcmp(wm, "spin") == 0);
+        const char *wm = std::getenv("SVSLAM_WAIT");        // spin | block | poll (default)
+        c->wait_poll = !(wm && (std::strcmp(wm, "spin") == 0 || std::strcmp(wm, "block") == 0));
+        c->wait_block = wm && std::strcmp(wm, "block") == 0;
         c->timing_split = std::getenv("SVSLAM_TIMING_SPLIT") != nullptr;
         // the device build takes the edge indices packed into one word (landmark < 2^16, keyframe < 2^8)
         c->ba_host_build = std::getenv("SVSLAM_BA_HOST_BUILD") != nullptr || lim->max_lm >= 65536 || lim->max_kf >= 256;
     }
     HIPCHK(c, pool_stream(c->device, &c->stream));
-    HIPCHK(c, hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->done, hipEventDisableTiming | (c->wait_block ? hipEventBlockingSync : 0)));
     for (int i = 0; i < 16; ++i) HIPCHK(c, hipEventCreate(&c->ev[i]));
     make_geom(c->geom, lim->width, lim->height);
     c->pyr_fused = !std::getenv("SVSLAM_PYR_LEGACY") && pyr_fused_plan(c->geom, 64 * 1024, c->pyr_plan);
