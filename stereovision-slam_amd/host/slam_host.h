@@ -265,19 +265,12 @@ struct Counters {                      // workload accounting for the roofline (
 };
 
 // BA job bookkeeping between gather and scatter (per stream, reused)
-struct BaGather {
+struct BaGather {                // what Backend::Optimize keeps between building the problem and reading it back
     std::vector<Frame *> kfs;
     std::vector<MapPoint *> lms;
     std::vector<ObsRef> edge_feat;
-    std::vector<double> poses, pts;
-    std::vector<int> okf, olm;
-    std::vector<uint8_t> right;
-    std::vector<float> uv;
-    void clear()
-    {
-        kfs.clear(); lms.clear(); edge_feat.clear(); poses.clear(); pts.clear(); okf.clear(); olm.clear();
-        right.clear(); uv.clear();
-    }
+    int nkf_ub = 0, nlm_ub = 0, nobs_ub = 0;     // sizes reserved for this problem in the batch arrays
+    void clear() { kfs.clear(); lms.clear(); edge_feat.clear(); }
 };
 
 struct Stream {
@@ -883,18 +876,14 @@ private:
         ba_ms_ = MS_all;
         std::vector<int> &MS = ba_ms_;
         int n = (int)MS.size();
-        // gather per stream (:39-160), in parallel, into the stream's own buffers
+        // Gather per stream (:39-160), in parallel, STRAIGHT into the batch arrays the provider reads: pass 0
+        // bounds every problem's sizes (and pulls its landmarks into cache), a prefix sum places the problems,
+        // pass 1 fills them.  A problem may use less than its reservation (outlier features, landmarks without a
+        // live observation): the jobs carry offsets, gaps are never read.
         pool_.parallel_for(n, [&](int i) {
             Stream &st = *streams_[MS[i]];
             BaGather &g = st.ba;
-            g.clear();
-            for (Frame *kf : st.map.active_keyframes_) {             // :39-66
-                kf->ba_local = (int)g.kfs.size();
-                g.kfs.push_back(kf);
-                for (int t = 0; t < 7; ++t) g.poses.push_back(kf->pose.v[t]);
-            }
             const std::vector<MapPoint *> &AL = st.map.active_landmarks_;
-            // pass 0: upper bound of the edge count (also pulls the landmarks into cache)
             size_t max_obs = 0;
             for (size_t li = 0; li < AL.size(); ++li) {
                 if (li + 8 < AL.size()) {                            // the landmarks are scattered over the pool
@@ -903,14 +892,39 @@ private:
                 }
                 max_obs += AL[li]->observations.size();
             }
-            g.lms.resize(AL.size()); g.pts.resize(3 * AL.size());
-            g.okf.resize(max_obs); g.olm.resize(max_obs); g.right.resize(max_obs); g.uv.resize(2 * max_obs);
-            g.edge_feat.resize(max_obs);
+            g.nkf_ub = (int)st.map.active_keyframes_.size(); g.nlm_ub = (int)AL.size(); g.nobs_ub = (int)max_obs;
+        });
+        jobs_ba_.resize(n);
+        int ko = 0, lo = 0, oo = 0;
+        for (int i = 0; i < n; ++i) {
+            const BaGather &g = streams_[MS[i]]->ba;
+            svslam_ba_job &j = jobs_ba_[i];
+            j.kf_ofs = ko; j.lm_ofs = lo; j.obs_ofs = oo;
+            j.nkf = j.nlm = j.nobs = 0; j.iters_done = 0; j.reserved = 0;
+            ko += g.nkf_ub; lo += g.nlm_ub; oo += g.nobs_ub;
+        }
+        ba_poses_.resize(7 * (size_t)std::max(ko, 1)); ba_pts_.resize(3 * (size_t)std::max(lo, 1));
+        ba_okf_.resize((size_t)std::max(oo, 1)); ba_olm_.resize((size_t)std::max(oo, 1));
+        ba_right_.resize((size_t)std::max(oo, 1)); ba_uv_.resize(2 * (size_t)std::max(oo, 1));
+        ba_chi2_.resize((size_t)std::max(oo, 1));
+        pool_.parallel_for(n, [&](int i) {
+            Stream &st = *streams_[MS[i]];
+            BaGather &g = st.ba;
+            svslam_ba_job &j = jobs_ba_[i];
+            g.clear();
+            double *__restrict o_poses = &ba_poses_[7 * (size_t)j.kf_ofs];
+            for (Frame *kf : st.map.active_keyframes_) {             // :39-66
+                kf->ba_local = (int)g.kfs.size();
+                std::memcpy(o_poses + 7 * g.kfs.size(), kf->pose.v, 7 * sizeof(double));
+                g.kfs.push_back(kf);
+            }
+            const std::vector<MapPoint *> &AL = st.map.active_landmarks_;
+            g.lms.resize(AL.size()); g.edge_feat.resize((size_t)g.nobs_ub);
             MapPoint **__restrict o_lms = g.lms.data();
-            double *__restrict o_pts = g.pts.data();
-            int *__restrict o_kf = g.okf.data(), *__restrict o_lm = g.olm.data();
-            uint8_t *__restrict o_right = g.right.data();
-            float *__restrict o_uv = g.uv.data();
+            double *__restrict o_pts = &ba_pts_[3 * (size_t)j.lm_ofs];
+            int *__restrict o_kf = &ba_okf_[(size_t)j.obs_ofs], *__restrict o_lm = &ba_olm_[(size_t)j.obs_ofs];
+            uint8_t *__restrict o_right = &ba_right_[(size_t)j.obs_ofs];
+            float *__restrict o_uv = &ba_uv_[2 * (size_t)j.obs_ofs];
             ObsRef *__restrict o_ef = g.edge_feat.data();
             int nl = 0; size_t ne = 0;
             for (size_t li = 0; li < AL.size(); ++li) {              // :83-160
@@ -936,51 +950,24 @@ private:
                     ++ne;
                 }
             }
-            g.lms.resize((size_t)nl); g.pts.resize(3 * (size_t)nl);
-            g.okf.resize(ne); g.olm.resize(ne); g.right.resize(ne); g.uv.resize(2 * ne); g.edge_feat.resize(ne);
+            g.lms.resize((size_t)nl); g.edge_feat.resize(ne);
+            j.nkf = (int)g.kfs.size(); j.nlm = nl; j.nobs = (int)ne;
+            for (size_t e = 0; e < ne; ++e) ba_chi2_[(size_t)j.obs_ofs + e] = 0.0;
             for (Frame *kf : g.kfs) kf->ba_local = -1;
         });
         // a problem beyond the provider's capacity is dropped for this keyframe, alone
         {
             size_t keep = 0;
             for (int i = 0; i < n; ++i) {
-                const BaGather &g = streams_[MS[i]]->ba;
-                const bool fits = (cfg_.max_kf <= 0 || (int)g.kfs.size() <= cfg_.max_kf) &&
-                                  (cfg_.max_lm <= 0 || (int)g.lms.size() <= cfg_.max_lm) &&
-                                  (cfg_.max_obs <= 0 || (int)g.edge_feat.size() <= cfg_.max_obs);
-                if (fits) MS[keep++] = MS[i]; else cnt_.ba_skipped++;
+                const svslam_ba_job &j = jobs_ba_[i];
+                const bool fits = (cfg_.max_kf <= 0 || j.nkf <= cfg_.max_kf) && (cfg_.max_lm <= 0 || j.nlm <= cfg_.max_lm) &&
+                                  (cfg_.max_obs <= 0 || j.nobs <= cfg_.max_obs);
+                if (fits) { MS[keep] = MS[i]; jobs_ba_[keep] = j; ++keep; } else cnt_.ba_skipped++;
             }
-            MS.resize(keep);
+            MS.resize(keep); jobs_ba_.resize(keep);
             n = (int)keep;
             if (n == 0) { st_[6] += now_ns() - t_h6; return; }
         }
-        jobs_ba_.resize(n);
-        int ko = 0, lo = 0, oo = 0;
-        for (int i = 0; i < n; ++i) {
-            BaGather &g = streams_[MS[i]]->ba;
-            svslam_ba_job &j = jobs_ba_[i];
-            j.kf_ofs = ko; j.nkf = (int)g.kfs.size();
-            j.lm_ofs = lo; j.nlm = (int)g.lms.size();
-            j.obs_ofs = oo; j.nobs = (int)g.edge_feat.size();
-            j.iters_done = 0; j.reserved = 0;
-            ko += j.nkf; lo += j.nlm; oo += j.nobs;
-        }
-        ba_poses_.resize(7 * (size_t)std::max(ko, 1)); ba_pts_.resize(3 * (size_t)std::max(lo, 1));
-        ba_okf_.resize((size_t)std::max(oo, 1)); ba_olm_.resize((size_t)std::max(oo, 1));
-        ba_right_.resize((size_t)std::max(oo, 1)); ba_uv_.resize(2 * (size_t)std::max(oo, 1));
-        ba_chi2_.assign((size_t)std::max(oo, 1), 0.0);
-        pool_.parallel_for(n, [&](int i) {
-            const BaGather &g = streams_[MS[i]]->ba;
-            const svslam_ba_job &j = jobs_ba_[i];
-            if (j.nkf) std::memcpy(&ba_poses_[7 * (size_t)j.kf_ofs], g.poses.data(), sizeof(double) * 7 * j.nkf);
-            if (j.nlm) std::memcpy(&ba_pts_[3 * (size_t)j.lm_ofs], g.pts.data(), sizeof(double) * 3 * j.nlm);
-            if (j.nobs) {
-                std::memcpy(&ba_okf_[(size_t)j.obs_ofs], g.okf.data(), sizeof(int) * j.nobs);
-                std::memcpy(&ba_olm_[(size_t)j.obs_ofs], g.olm.data(), sizeof(int) * j.nobs);
-                std::memcpy(&ba_right_[(size_t)j.obs_ofs], g.right.data(), (size_t)j.nobs);
-                std::memcpy(&ba_uv_[2 * (size_t)j.obs_ofs], g.uv.data(), sizeof(float) * 2 * j.nobs);
-            }
-        });
         st_[6] += now_ns() - t_h6;
         if (const char *dump = std::getenv("SVS_DUMP_BA")) DumpBaProblem(dump, 0);   // development hook
         { KTimer kt_(cnt_); check(k_.local_ba_submit(n, jobs_ba_.data(), cam_l_, cfg_.cam_l.pose.v, cam_r_, cfg_.cam_r.pose.v, ko,
