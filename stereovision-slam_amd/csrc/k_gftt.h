@@ -84,18 +84,24 @@ template <int CTRL> __device__ __forceinline__ double dpp_f64x(double v)
 
 template <bool STORE_EIG>
 __global__ void __launch_bounds__(64)
-k_gftt_eig3(const GfttJob *jobs, const uint8_t *pyr, PyrGeom g, GfttWork wk, const float2 *rect_xy, double quality,
+k_gftt_eig3(const GfttJob *jobs, int njobs, const uint8_t *pyr, PyrGeom g, GfttWork wk, const float2 *rect_xy, double quality,
             float *eig_out)
 {
     __shared__ unsigned long long sKeys[GE_CBUF + 64];
-    const int job = blockIdx.z;
-    const GfttJob jb = jobs[job];
     const int w = g.w[0], h = g.h[0], pitch = g.pitch[0];
+    // grid: 8 x strips-per-image x ceil(jobs / 8) workgroups; consecutive ids go to consecutive XCDs, so job j lives
+    // on XCD j % 8 and its strips find each other's halos in that L2
+    const int nsx = (w + GE_COLS - 1) / GE_COLS, nsy = (h + GE_ROWS - 1) / GE_ROWS, per = nsx * nsy;
+    const int slot = blockIdx.x >> 3, round = slot / per, strip = slot - round * per;
+    const int job = round * 8 + (blockIdx.x & 7);
+    if (job >= njobs) return;
+    const int bx = strip % nsx, by = strip / nsx;
+    const GfttJob jb = jobs[job];
     const uint8_t *img = lvl_origin(pyr + (size_t)jb.slot * g.slot_bytes, g, 0);
     unsigned int *ctr = wk.counters + (size_t)job * GF_CNT_STRIDE;
     unsigned long long *gkeys = wk.keys + (size_t)job * wk.cap;
     const int lane = threadIdx.x;
-    const int x0 = blockIdx.x * GE_COLS, y0 = blockIdx.y * GE_ROWS;
+    const int x0 = bx * GE_COLS, y0 = by * GE_ROWS;
     const int gx = x0 - 3 + lane;                               // column of this lane's pixel / covariance / eigenvalue
     const uint8_t *colp = img + min(gx, w + SVS_BORDER - 1);
     const bool col_out = gx < 0 || gx >= w;

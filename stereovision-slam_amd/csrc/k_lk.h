@@ -40,6 +40,10 @@ struct LkParams {
     // min-eigenvalue test is one compare; eig_use_div = 1 keeps the division (threshold search did not settle)
     float eig_num_thr;
     int eig_use_div;
+    // launch geometry (set by launch_lk): the grid is one-dimensional and deals the jobs over the 8 XCDs — the
+    // hardware hands consecutive workgroup ids to consecutive XCDs, so job j runs on XCD j % 8 and all the points
+    // of an image pair share one L2 (with a (points, jobs) grid every XCD fetched every pyramid)
+    int njobs, blocks_per_job;
 };
 
 #define LK_WIN 11
@@ -243,8 +247,11 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
     if (prm.max_count < 0) status[0] = (uint8_t)sPad[(threadIdx.x * 37) & 8191];
 #endif
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const LkJob jb = jobs[blockIdx.y];
-    const int pi = blockIdx.x * LK_WAVES_PER_BLOCK + wave;
+    const int slot = blockIdx.x >> 3, round = slot / prm.blocks_per_job;
+    const int job = round * 8 + (blockIdx.x & 7);
+    if (job >= prm.njobs) return;
+    const LkJob jb = jobs[job];
+    const int pi = (slot - round * prm.blocks_per_job) * LK_WAVES_PER_BLOCK + wave;
     if (pi >= jb.npts) return;
     const int pt = jb.pt_ofs + pi;
     uint32_t *sI32 = sI_all[wave];

@@ -617,7 +617,17 @@ static LkParams make_lk_params(const svslam_lk_params *p)
     while (ok && (double)(x / den) < k.min_eig_thr) { x = std::nextafterf(x, INFINITY); if (++steps > 128) ok = false; }
     k.eig_num_thr = x;
     k.eig_use_div = ok ? 0 : 1;
+    k.njobs = 0; k.blocks_per_job = 1;
     return k;
+}
+
+static void launch_lk(svslam_ctx *c, int njobs, int maxn, const LkJob *jobs, const float2 *prev, float2 *next, uint8_t *stat,
+                      float *err, const svslam_lk_params *p)
+{
+    LkParams k = make_lk_params(p);
+    k.njobs = njobs; k.blocks_per_job = cdiv(maxn, LK_WAVES_PER_BLOCK);
+    hipLaunchKernelGGL(k_lk, dim3(8 * k.blocks_per_job * cdiv(njobs, 8)), dim3(64 * LK_WAVES_PER_BLOCK), 0, c->stream, jobs,
+                       c->d_pyr, c->geom, prev, next, stat, err, k);
 }
 
 int svslam_lk_batch(svslam_ctx *c, int njobs, const svslam_lk_job *jobs, int total_pts,
@@ -649,10 +659,8 @@ int svslam_lk_batch(svslam_ctx *c, int njobs, const svslam_lk_job *jobs, int tot
     if (h2d(c, 0, in_end)) return -1;
     if (maxn > 0) {
         tm_begin(c, FAM_LK, total_pts);
-        dim3 grd(cdiv(maxn, LK_WAVES_PER_BLOCK), njobs);
-        hipLaunchKernelGGL(k_lk, grd, dim3(64 * LK_WAVES_PER_BLOCK), 0, c->stream, dp<LkJob>(c, ojobs), c->d_pyr,
-                           c->geom, dp<float2>(c, oprev), dp<float2>(c, onext), dp<uint8_t>(c, ostat),
-                           dp<float>(c, oerr), make_lk_params(p));
+        launch_lk(c, njobs, maxn, dp<LkJob>(c, ojobs), dp<float2>(c, oprev), dp<float2>(c, onext), dp<uint8_t>(c, ostat),
+                  dp<float>(c, oerr), p);
         tm_end(c);
         HIPCHK(c, hipGetLastError());
     }
@@ -669,8 +677,10 @@ static int launch_gftt(svslam_ctx *c, int njobs, const GfttJob *djobs, const flo
 {
     const int w = c->geom.w[0], h = c->geom.h[0];
     tm_begin(c, c->timing_split ? FAM_DBG0 : FAM_GFTT, njobs);
-    hipLaunchKernelGGL(k_gftt_eig3<false>, dim3(cdiv(w, GE_COLS), cdiv(h, GE_ROWS), njobs), dim3(64), 0, c->stream, djobs,
-                       c->d_pyr, c->geom, c->gw, drects, quality, (float *)nullptr);
+    // one-dimensional grid, jobs dealt over the XCDs (see LkParams): the strips of an image share their halo
+    // columns, rows and the 64-byte lines they straddle through one L2
+    hipLaunchKernelGGL(k_gftt_eig3<false>, dim3(8 * cdiv(w, GE_COLS) * cdiv(h, GE_ROWS) * cdiv(njobs, 8)), dim3(64), 0, c->stream, djobs,
+                       njobs, c->d_pyr, c->geom, c->gw, drects, quality, (float *)nullptr);
     if (c->timing_split) { tm_end(c); tm_begin(c, FAM_DBG1, njobs); }
     hipLaunchKernelGGL(k_gftt_select2, dim3(njobs), dim3(GS_THREADS), 0, c->stream, c->gw, w, h, max_corners, quality,
                        min_dist, dout, dn, max_corners);
@@ -725,8 +735,8 @@ int svslam_gftt_eigmap(svslam_ctx *c, int slot, float *out)
     HIPCHK(c, hipMalloc(&d_eig, sizeof(float) * (size_t)w * h));
     // the production kernel with its eigenvalue store compiled in (the product instantiation differs by
     // exactly that store), so the eig-map parity tests check what ships
-    hipLaunchKernelGGL(k_gftt_eig3<true>, dim3(cdiv(w, GE_COLS), cdiv(h, GE_ROWS), 1), dim3(64), 0, c->stream,
-                       dp<GfttJob>(c, ojobs), c->d_pyr, c->geom, c->gw, (const float2 *)nullptr, 0.01, d_eig);
+    hipLaunchKernelGGL(k_gftt_eig3<true>, dim3(8 * cdiv(w, GE_COLS) * cdiv(h, GE_ROWS)), dim3(64), 0, c->stream,
+                       dp<GfttJob>(c, ojobs), 1, c->d_pyr, c->geom, c->gw, (const float2 *)nullptr, 0.01, d_eig);
     hipError_t e1 = hipGetLastError();
     hipError_t e2 = hipMemsetAsync(c->gw.counters, 0, sizeof(unsigned int) * GF_CNT_STRIDE, c->stream);   // job 0's counters back to zero
     hipError_t e3 = hipStreamSynchronize(c->stream);
@@ -1228,9 +1238,8 @@ int svslam_track_batch(svslam_ctx *c, int njobs, svslam_track_job *jobs, const v
     if (h2d(c, base, in_end)) return -1;
     if (maxn > 0) {
         tm_begin(c, FAM_LK, total_pts);
-        hipLaunchKernelGGL(k_lk, dim3(cdiv(maxn, LK_WAVES_PER_BLOCK), njobs), dim3(64 * LK_WAVES_PER_BLOCK), 0,
-                           c->stream, dp<LkJob>(c, olk), c->d_pyr, c->geom, dp<float2>(c, oprev),
-                           dp<float2>(c, onext), dp<uint8_t>(c, ostat), dp<float>(c, oerr), make_lk_params(p));
+        launch_lk(c, njobs, maxn, dp<LkJob>(c, olk), dp<float2>(c, oprev), dp<float2>(c, onext), dp<uint8_t>(c, ostat),
+                  dp<float>(c, oerr), p);
         tm_end(c);
         // status && in image && has map point -> pose-only edge (src/frontend.cpp:361-371, 443-444)
         hipLaunchKernelGGL(k_track_filter, dim3(njobs), dim3(256), 0, c->stream,
@@ -1324,9 +1333,8 @@ int svslam_rtrack_batch(svslam_ctx *c, int njobs, svslam_rtrack_job *jobs, const
         hipLaunchKernelGGL(k_rt_gather, dim3(cdiv(maxn, 256), njobs), dim3(256), 0, c->stream, dp<RtJob>(c, ort), c->rt,
                            dp<double>(c, ocam), dp<float2>(c, oprev), dp<float2>(c, onext), dp<uint8_t>(c, omp), dp<double>(c, oxyz));
         tm_begin(c, FAM_LK, total_pts);
-        hipLaunchKernelGGL(k_lk, dim3(cdiv(maxn, LK_WAVES_PER_BLOCK), njobs), dim3(64 * LK_WAVES_PER_BLOCK), 0,
-                           c->stream, dp<LkJob>(c, olk), c->d_pyr, c->geom, dp<float2>(c, oprev),
-                           dp<float2>(c, onext), dp<uint8_t>(c, ostat), dp<float>(c, oerr), make_lk_params(p));
+        launch_lk(c, njobs, maxn, dp<LkJob>(c, olk), dp<float2>(c, oprev), dp<float2>(c, onext), dp<uint8_t>(c, ostat),
+                  dp<float>(c, oerr), p);
         tm_end(c);
         hipLaunchKernelGGL(k_track_filter, dim3(njobs), dim3(256), 0, c->stream,
                            reinterpret_cast<const LkJobView *>(dp<LkJob>(c, olk)), dp<float2>(c, onext),

@@ -36,9 +36,12 @@ try:
            "triangulate": (["k_triangulate"], "point", u["tri_pts"])}
     per = {}
     for f, (ks, unit, n) in fam.items():
-        fb = sum(out["FETCH_SIZE"].get(k, {}).get("total_KB", 0.0) for k in ks) * 1024 / max(n, 1)
+        # FETCH_SIZE counts half the bytes on gfx950 for every access width (tools/pmc_calib.sh: 0.500 x for byte,
+        # dword, 8- and 16-byte reads of a 1 GiB buffer; WRITE_SIZE is exact): corrected here, raw value kept
+        fb_raw = sum(out["FETCH_SIZE"].get(k, {}).get("total_KB", 0.0) for k in ks) * 1024 / max(n, 1)
+        fb = 2.0 * fb_raw
         wb = sum(out["WRITE_SIZE"].get(k, {}).get("total_KB", 0.0) for k in ks) * 1024 / max(n, 1)
-        per[f] = {"unit": unit, "units_in_run": n, "kernels": ks, "fetch_bytes": round(fb), "write_bytes": round(wb), "bytes": round(fb + wb)}
+        per[f] = {"unit": unit, "units_in_run": n, "kernels": ks, "fetch_bytes_raw": round(fb_raw), "fetch_bytes": round(fb), "write_bytes": round(wb), "bytes": round(fb + wb)}
     out["per_unit"] = per
     out["units_whole_process"] = u
 except Exception as e:
