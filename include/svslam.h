@@ -241,6 +241,12 @@ int svslam_sba_close(svslam_ctx *ctx, double *poses, double *pts, double *edge_c
  * and clears them.                                                            */
 int svslam_ba_profile(svslam_ctx *ctx, int enable, long long *out12);
 
+/* test hook: the Levenberg-Marquardt trajectory of the last svslam_pose_only_batch / svslam_local_ba_batch call
+ * on this context — one record of 6 doubles per LM trial, rejected trials included: iteration (pose-only:
+ * 16 round + iteration), lambda of the trial, chi2 before, chi2 of the trial state, rho, accepted.  enable = 1
+ * allocates the device buffer (kernels record while it exists), 0 frees it; out != NULL reads job `job`.    */
+int svslam_lm_trace(svslam_ctx *ctx, int enable, int job, double *out, int cap_records, int *n_records);
+
 /* ---- fused per-frame tracking (pyramid + LK + pose-only, one submission) --
  * The whole data-parallel part of Frontend::Track (src/frontend.cpp:645-663)
  * without a host round trip between TrackLastFrame and EstimateCurrentPose:

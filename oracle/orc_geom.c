@@ -381,6 +381,9 @@ static double po_compute_errors(int n, const double cam[4], const double T[7],
     return chi;
 }
 
+/* trace sink of orc_pose_only_trace (NULL otherwise): records as in orc_local_ba_trace, t[0] = 16 round + iteration */
+static double *po_trace; static int po_trace_cap, po_trace_n, po_round;
+
 static void po_optimize(int n, const double cam[4], double T[7], const double *xyz,
                         const float *uv, const uint8_t *active, int robust,
                         int iters, double *err)
@@ -430,6 +433,11 @@ static void po_optimize(int n, const double cam[4], double T[7], const double *x
             for (int a = 0; a < 6; ++a) scale += x[a] * (lambda * x[a] + b[a]);
             scale += 1e-3;
             rho /= scale;
+            if (po_trace && po_trace_n < po_trace_cap) {
+                double *t = po_trace + (size_t)ORC_TRACE_REC * po_trace_n++;
+                t[0] = 16 * po_round + it; t[1] = lambda; t[2] = currentChi; t[3] = tempChi; t[4] = rho;
+                t[5] = (rho > 0 && isfinite(tempChi)) ? 1.0 : 0.0;
+            }
             if (rho > 0 && isfinite(tempChi)) {
                 double alpha = 1. - pow(2 * rho - 1, 3);
                 if (alpha > 2. / 3.) alpha = 2. / 3.;
@@ -458,6 +466,7 @@ int orc_pose_only(int n, const double cam[4], double pose[7], const double *xyz,
     int robust = 1, cnt_outlier = 0;
     for (int r = 0; r < rounds; ++r) {
         memcpy(T, T0, sizeof(T));                       /* :485 */
+        po_round = r;
         for (int i = 0; i < n; ++i) active[i] = outlier[i] ? 0 : 1; /* level 0 */
         po_optimize(n, cam, T, xyz, uv, active, robust, iters, err);
         cnt_outlier = 0;
@@ -472,6 +481,17 @@ int orc_pose_only(int n, const double cam[4], double pose[7], const double *xyz,
     memcpy(pose, T, sizeof(T));
     free(err); free(active);
     return n - cnt_outlier;
+}
+
+int orc_pose_only_trace(int n, const double cam[4], double pose[7], const double *xyz,
+                        const float *uv, uint8_t *outlier, double chi2_th, int rounds,
+                        int iters, double *trace, int trace_cap, int *trace_n)
+{
+    po_trace = trace; po_trace_cap = trace_cap; po_trace_n = 0;
+    int r = orc_pose_only(n, cam, pose, xyz, uv, outlier, chi2_th, rounds, iters);
+    po_trace = NULL;
+    if (trace_n) *trace_n = po_trace_n;
+    return r;
 }
 
 /* ================================================================== */
@@ -585,6 +605,17 @@ static void inv3(const double A[9], double Ai[9])
     Ai[6] = c2 * id; Ai[7] = (A[1] * A[6] - A[0] * A[7]) * id; Ai[8] = (A[0] * A[4] - A[1] * A[3]) * id;
 }
 
+/* LM trajectory hook (test infrastructure): one record of ORC_TRACE_REC doubles per LM trial —
+ * iteration, lambda of the trial, chi2 before, chi2 of the trial state (DBL_MAX: solve failed),
+ * rho, accepted (1/0) — so that a GPU kernel can be compared trial by trial, rejected ones included. */
+int orc_local_ba_trace(const double cam_l[4], const double ext_l[7],
+                 const double cam_r[4], const double ext_r[7], int nkf,
+                 double *poses, int nlm, double *pts, int nobs,
+                 const int *obs_kf, const int *obs_lm,
+                 const uint8_t *obs_is_right, const float *obs_uv,
+                 double huber_delta, int iters, int jac_mode, double *edge_chi2,
+                 double *trace, int trace_cap, int *trace_n);
+
 int orc_local_ba(const double cam_l[4], const double ext_l[7],
                  const double cam_r[4], const double ext_r[7], int nkf,
                  double *poses, int nlm, double *pts, int nobs,
@@ -592,6 +623,20 @@ int orc_local_ba(const double cam_l[4], const double ext_l[7],
                  const uint8_t *obs_is_right, const float *obs_uv,
                  double huber_delta, int iters, int jac_mode, double *edge_chi2)
 {
+    return orc_local_ba_trace(cam_l, ext_l, cam_r, ext_r, nkf, poses, nlm, pts, nobs, obs_kf, obs_lm, obs_is_right,
+                              obs_uv, huber_delta, iters, jac_mode, edge_chi2, NULL, 0, NULL);
+}
+
+int orc_local_ba_trace(const double cam_l[4], const double ext_l[7],
+                 const double cam_r[4], const double ext_r[7], int nkf,
+                 double *poses, int nlm, double *pts, int nobs,
+                 const int *obs_kf, const int *obs_lm,
+                 const uint8_t *obs_is_right, const float *obs_uv,
+                 double huber_delta, int iters, int jac_mode, double *edge_chi2,
+                 double *trace, int trace_cap, int *trace_n)
+{
+    int ntrace = 0;
+    if (trace_n) *trace_n = 0;
     ba_cams cams; cams.cam[0] = cam_l; cams.cam[1] = cam_r; cams.ext[0] = ext_l; cams.ext[1] = ext_r;
     if (nobs <= 0 || nkf <= 0 || nlm <= 0 || 6 * nkf > ORC_MAXN) return 0;
     /* active vertices: those with at least one edge (g2o initializeOptimization) */
@@ -771,6 +816,11 @@ int orc_local_ba(const double cam_l[4], const double ext_l[7],
             }
             scale += 1e-3;
             rho /= scale;
+            if (trace && ntrace < trace_cap) {
+                double *t = trace + (size_t)ORC_TRACE_REC * ntrace++;
+                t[0] = it; t[1] = lambda; t[2] = currentChi; t[3] = tempChi; t[4] = rho;
+                t[5] = (rho > 0 && isfinite(tempChi)) ? 1.0 : 0.0;
+            }
             if (rho > 0 && isfinite(tempChi)) {
                 double alpha = 1. - pow(2 * rho - 1, 3);
                 if (alpha > 2. / 3.) alpha = 2. / 3.;
@@ -793,5 +843,6 @@ int orc_local_ba(const double cam_l[4], const double ext_l[7],
     free(kf_act); free(lm_act); free(kf_idx); free(blk); free(eblk); free(blk_kf); free(blk_lm);
     free(lm_start); free(lm_blocks); free(fill); free(err); free(Hpp); free(S); free(bp); free(bs);
     free(Hll); free(Dinv); free(bl); free(W); free(xp); free(xl); free(poses_b); free(pts_b);
+    if (trace_n) *trace_n = ntrace;
     return it_done;
 }

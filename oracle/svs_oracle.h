@@ -112,6 +112,20 @@ int orc_local_ba(const double cam_l[4], const double ext_l[7],
                  double huber_delta, int iters, int jac_mode,
                  double *edge_chi2);
 
+/* LM trajectory hooks: ORC_TRACE_REC doubles per LM trial (iteration [pose-only: 16 round + iteration],
+ * lambda of the trial, chi2 before, chi2 of the trial state, rho, accepted) */
+#define ORC_TRACE_REC 6
+int orc_local_ba_trace(const double cam_l[4], const double ext_l[7],
+                 const double cam_r[4], const double ext_r[7], int nkf,
+                 double *poses, int nlm, double *pts, int nobs,
+                 const int *obs_kf, const int *obs_lm,
+                 const uint8_t *obs_is_right, const float *obs_uv,
+                 double huber_delta, int iters, int jac_mode, double *edge_chi2,
+                 double *trace, int trace_cap, int *trace_n);
+int orc_pose_only_trace(int n, const double cam[4], double pose[7], const double *xyz,
+                        const float *uv, uint8_t *outlier, double chi2_th, int rounds,
+                        int iters, double *trace, int trace_cap, int *trace_n);
+
 /* test hooks: Jacobians of EdgeProjection (mode 0 analytic, 1 numeric) and of
  * EdgeProjectionPoseOnly::linearizeOplus as the oracle evaluates them */
 void orc_ba_jacobian(const double cam[4], const double ext[7], const double T[7], const double P[3],

@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "svslam_sba_io_doubles", "svslam_sba_open", "svslam_sba_phase", "svslam_sba_close",
     "svslam_dev_alloc", "svslam_dev_free", "svslam_dev_upload", "svslam_dev_download", "svslam_sync",
     "svslam_timing_enable", "svslam_timing_reset", "svslam_timing_get", "svslam_ba_profile",
-    "svslam_set_host_threads", "svslam_debug_host_ns", "svslam_debug_clock_mhz",
+    "svslam_set_host_threads", "svslam_debug_host_ns", "svslam_debug_clock_mhz", "svslam_lm_trace",
 ]
 
 FAMILIES = {"pyramid": 0, "lk": 1, "gftt": 2, "triangulate": 3, "pose_only": 4, "local_ba": 5}
@@ -207,6 +207,15 @@ class Context:
         out = (C.c_longlong * 12)()
         self._chk(self.L.svslam_ba_profile(self.h, 1 if enable else 0, out if read else None), "ba_profile")
         return list(out)
+
+    def lm_trace(self, enable=True, job=None, cap=408):
+        """test hook: record / read the LM trajectory [ntrials, 6] of the last pose-only / local-BA call (svslam_lm_trace)"""
+        if job is None:
+            self._chk(self.L.svslam_lm_trace(self.h, 1 if enable else 0, 0, None, 0, None), "lm_trace")
+            return None
+        out = np.zeros((cap, 6)); n = C.c_int(0)
+        self._chk(self.L.svslam_lm_trace(self.h, 1, job, _p(out), cap, C.byref(n)), "lm_trace")
+        return out[:n.value].copy()
 
     # ---- pyramids --------------------------------------------------------
     def pyramid(self, slots, imgs, device=False, strides=None, decimate_from=None):

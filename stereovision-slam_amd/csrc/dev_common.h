@@ -278,3 +278,20 @@ __device__ __forceinline__ void d_huber(double e2, double delta, double &rho0, d
     else { double sq = sqrt(e2); rho0 = 2 * sq * delta - dsqr; rho1 = delta / sq; }
 }
 #pragma clang fp contract(off)
+
+// LM trajectory test hook (svslam_lm_trace): per job [0] = trials recorded, records of LM_TRACE_REC doubles from
+// [8]: iteration (pose-only: 16 round + iteration), lambda of the trial, chi2 before, chi2 of the trial state,
+// rho, accepted — the layout of the oracle's orc_*_trace.  Written by thread 0 of the job's workgroup.
+#define LM_TRACE_REC 6
+#define LM_TRACE_CAP 408
+#define LM_TRACE_STRIDE (8 + LM_TRACE_REC * LM_TRACE_CAP)
+__device__ __forceinline__ void lm_trace_put(double *trace_all, int job, double it, double lambda, double chi0, double chi1,
+                                             double rho, bool accepted)
+{
+    double *t = trace_all + (size_t)job * LM_TRACE_STRIDE;
+    const int n = (int)t[0];
+    if (n >= LM_TRACE_CAP) return;
+    double *r = t + 8 + LM_TRACE_REC * n;
+    r[0] = it; r[1] = lambda; r[2] = chi0; r[3] = chi1; r[4] = rho; r[5] = accepted ? 1.0 : 0.0;
+    t[0] = (double)(n + 1);
+}

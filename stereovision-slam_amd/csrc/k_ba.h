@@ -542,7 +542,7 @@ __device__ __forceinline__ void ba_schur_task(int a, int b2, int rg, int c0, int
 //   phase 4  reject: restore the backup      phase 5  finalise: per-edge chi2, positions in caller numbering
 // io layout per job (doubles): S[np*np] | bs[np] | bp[np] | hdiag[np] | scalars[8]
 //   scalars: 0 chi2, 1 landmark diagonal max, 2 cholesky ok, 3 scale (landmarks), 4 scale (poses), 5 chi2 of the trial
-struct SbaArgs { int phase, first; double lambda; double *io; };
+struct SbaArgs { int phase, first; double lambda; double *io; double *trace; };   // trace: svslam_lm_trace test hook (MODE 0)
 #define SBA_IO_DOUBLES(np) ((size_t)(np) * (np) + 3 * (size_t)(np) + 8)
 
 template <int MODE>
@@ -1152,6 +1152,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
             rho = currentChi - tempChi;
             scale += 1e-3;
             rho /= scale;
+            if (sba.trace && tid == 0) lm_trace_put(sba.trace, job, it, lambda, currentChi, tempChi, rho, rho > 0 && isfinite(tempChi));
             if (rho > 0 && isfinite(tempChi)) {
                 double t = 2 * rho - 1;
                 double alpha = 1. - t * t * t;

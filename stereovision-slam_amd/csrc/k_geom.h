@@ -235,7 +235,7 @@ __device__ __forceinline__ int po_block_sum_i32(int x, int *buf, int tid)
 template <int WAVES>
 __global__ void __launch_bounds__(64 * WAVES)
 k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *uv,
-            const uint8_t *edge_valid, uint8_t *outlier, double chi2_th, int rounds, int iters)
+            const uint8_t *edge_valid, uint8_t *outlier, double chi2_th, int rounds, int iters, double *trace)
 {
     constexpr int NT = 64 * WAVES, SLOTS = PO_MAX_EDGES / NT;
     __shared__ __attribute__((aligned(16))) double s_red[4 * WAVES * 32];
@@ -366,6 +366,7 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
                     for (int a = 0; a < 6; ++a) scale += x[a] * (lambda * x[a] + b[a]);
                     scale += 1e-3;
                     rho /= scale;
+                    if (trace && tid == 0) lm_trace_put(trace, blockIdx.x, 16 * r + it, lambda, currentChi, tempChi, rho, rho > 0 && isfinite(tempChi));
                     if (rho > 0 && isfinite(tempChi)) {
                         double t = 2 * rho - 1;
                         double alpha = 1. - t * t * t;

@@ -75,6 +75,7 @@ struct svslam_ctx {
     BaWork bw;
     std::unique_ptr<svs::ThreadPool> pool;   // host-side per-problem preparation
     long long *d_ba_prof = nullptr;
+    double *d_lm_trace = nullptr;            // svslam_lm_trace test hook: [max_jobs][LM_TRACE_STRIDE]
     // host-side wall time (ns): 0 h2d enqueue, 1 d2h enqueue, 2 stream wait, 3 launches, 4 staging memcpy/prep
     long long host_ns[8] = { 0 };
     bool wait_poll = true;
@@ -160,10 +161,11 @@ void tm_end(svslam_ctx *c)
 void launch_pose_only(svslam_ctx *c, int njobs, PoseJob *jobs, const double *cam, const double *xyz, const float2 *uv,
                       const uint8_t *valid, uint8_t *outlier, double chi2_th, int rounds, int iters)
 {
+    if (c->d_lm_trace) (void)hipMemsetAsync(c->d_lm_trace, 0, sizeof(double) * LM_TRACE_STRIDE * (size_t)njobs, c->stream);
     if (c->low_latency)
-        hipLaunchKernelGGL(k_pose_only<4>, dim3(njobs), dim3(256), 0, c->stream, jobs, cam, xyz, uv, valid, outlier, chi2_th, rounds, iters);
+        hipLaunchKernelGGL(k_pose_only<4>, dim3(njobs), dim3(256), 0, c->stream, jobs, cam, xyz, uv, valid, outlier, chi2_th, rounds, iters, c->d_lm_trace);
     else
-        hipLaunchKernelGGL(k_pose_only<1>, dim3(njobs), dim3(64), 0, c->stream, jobs, cam, xyz, uv, valid, outlier, chi2_th, rounds, iters);
+        hipLaunchKernelGGL(k_pose_only<1>, dim3(njobs), dim3(64), 0, c->stream, jobs, cam, xyz, uv, valid, outlier, chi2_th, rounds, iters, c->d_lm_trace);
 }
 void tm_collect(svslam_ctx *c)
 {
@@ -265,6 +267,15 @@ int d2h_sync(svslam_ctx *c, size_t from, size_t to)
 template <typename T> T *hp(svslam_ctx *c, size_t off) { return reinterpret_cast<T *>(c->ar.h + off); }
 template <typename T> T *dp(svslam_ctx *c, size_t off) { return reinterpret_cast<T *>(c->ar.d + off); }
 
+// The staging arena (and job 0 of the BA scratch) belongs to a submitted, uncollected local-BA batch or to an
+// open shared-map shard: every other batched call on the context is refused until collect / close.
+int arena_busy(svslam_ctx *c)
+{
+    if (c->ba_pending.active) return fail(c, "a submitted local-BA batch owns this context: call svslam_local_ba_collect first");
+    if (c->sba.open) return fail(c, "an open shared-map BA shard owns this context: call svslam_sba_close first");
+    return 0;
+}
+
 int check_slot(svslam_ctx *c, int s)
 {
     if (s < 0 || s >= c->lim.max_slots) return fail(c, "slot %d out of range [0,%d)", s, c->lim.max_slots);
@@ -319,7 +330,7 @@ int pyramid_common(svslam_ctx *c, int n, const int *slots, const void *const *im
     if (n > c->lim.max_jobs) return fail(c, "pyramid: %d jobs > max_jobs %d", n, c->lim.max_jobs);
     for (int i = 0; i < n; ++i) if (check_slot(c, slots[i])) return -1;
     const int iw = decimate ? src_w : c->geom.w[0], ih = decimate ? src_h : c->geom.h[0];
-    if (c->ba_pending.active) return fail(c, "a submitted local-BA batch owns this context: call svslam_local_ba_collect first");
+    if (arena_busy(c)) return -1;
     c->ar.reset();
     size_t ojobs = c->ar.take(sizeof(PyrJob) * n);
     PyrJob *hj = hp<PyrJob>(c, ojobs);
@@ -493,6 +504,7 @@ void svslam_destroy(svslam_ctx *c)
     (void)hipFree(c->gw.keys); (void)hipFree(c->gw.counters);
     ba_work_free(c->bw);
     if (c->d_ba_prof) (void)hipFree(c->d_ba_prof);
+    if (c->d_lm_trace) (void)hipFree(c->d_lm_trace);
     for (int i = 0; i < 16; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->done) (void)hipEventDestroy(c->done);   // the stream belongs to the pool
     delete c;
@@ -644,7 +656,7 @@ int svslam_lk_batch(svslam_ctx *c, int njobs, const svslam_lk_job *jobs, int tot
             return fail(c, "lk: job %d point range out of bounds", i);
         maxn = std::max(maxn, jobs[i].npts);
     }
-    if (c->ba_pending.active) return fail(c, "a submitted local-BA batch owns this context: call svslam_local_ba_collect first");
+    if (arena_busy(c)) return -1;
     c->ar.reset();
     size_t ojobs = c->ar.take(sizeof(LkJob) * njobs);
     size_t oprev = c->ar.take(sizeof(float) * 2 * total_pts);
@@ -702,7 +714,7 @@ int svslam_gftt_batch(svslam_ctx *c, int njobs, const svslam_gftt_job *jobs, int
         if (jobs[i].nrect < 0 || jobs[i].rect_ofs < 0 || jobs[i].rect_ofs + jobs[i].nrect > total_rects)
             return fail(c, "gftt: job %d rect range out of bounds", i);
     }
-    if (c->ba_pending.active) return fail(c, "a submitted local-BA batch owns this context: call svslam_local_ba_collect first");
+    if (arena_busy(c)) return -1;
     c->ar.reset();
     size_t ojobs = c->ar.take(sizeof(GfttJob) * njobs);
     size_t orect = c->ar.take(sizeof(float) * 2 * std::max(total_rects, 1));
@@ -724,7 +736,7 @@ int svslam_gftt_batch(svslam_ctx *c, int njobs, const svslam_gftt_job *jobs, int
 int svslam_gftt_eigmap(svslam_ctx *c, int slot, float *out)
 {
     if (check_slot(c, slot)) return -1;
-    if (c->ba_pending.active) return fail(c, "a submitted local-BA batch owns this context: call svslam_local_ba_collect first");
+    if (arena_busy(c)) return -1;
     c->ar.reset();
     size_t ojobs = c->ar.take(sizeof(GfttJob));
     GfttJob *j = hp<GfttJob>(c, ojobs);
@@ -761,7 +773,7 @@ int svslam_triangulate_batch(svslam_ctx *c, int njobs, const svslam_tri_job *job
             return fail(c, "triangulate: job %d point range out of bounds", i);
         maxn = std::max(maxn, jobs[i].npts);
     }
-    if (c->ba_pending.active) return fail(c, "a submitted local-BA batch owns this context: call svslam_local_ba_collect first");
+    if (arena_busy(c)) return -1;
     c->ar.reset();
     static_assert(sizeof(TriJob) == sizeof(svslam_tri_job), "job layout");
     size_t ojobs = c->ar.take(sizeof(TriJob) * njobs);
@@ -803,7 +815,7 @@ int svslam_pose_only_batch(svslam_ctx *c, int njobs, svslam_pose_job *jobs, int 
             jobs[i].pt_ofs + jobs[i].npts > total_pts)
             return fail(c, "pose_only: job %d point range out of bounds", i);
     }
-    if (c->ba_pending.active) return fail(c, "a submitted local-BA batch owns this context: call svslam_local_ba_collect first");
+    if (arena_busy(c)) return -1;
     c->ar.reset();
     static_assert(sizeof(PoseJob) == sizeof(svslam_pose_job), "job layout");
     size_t ocam = c->ar.take(32);
@@ -848,7 +860,7 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
                         c->lim.max_kf, j.nlm, c->lim.max_lm, j.nobs, c->lim.max_obs);
     }
     const long long t_prep0 = now_ns();
-    if (c->ba_pending.active) return fail(c, "a submitted local-BA batch owns this context: call svslam_local_ba_collect first");
+    if (arena_busy(c)) return -1;
     c->ar.reset();
     static_assert(sizeof(BaJob) == sizeof(svslam_ba_job), "job layout");
     const size_t TO = (size_t)std::max(total_obs, 1);
@@ -976,10 +988,11 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
                            bb_edge_cache_fits(max_nlm, max_nobs) ? 1 : 0);
         if (c->timing_split) { tm_end(c); tm_begin(c, FAM_DBG3, njobs); }
     }
+    if (c->d_lm_trace) HIPCHK(c, hipMemsetAsync(c->d_lm_trace, 0, sizeof(double) * LM_TRACE_STRIDE * (size_t)njobs, c->stream));
     hipLaunchKernelGGL(k_local_ba_t<0>, dim3(njobs), dim3(BA_THREADS), ba_lds_bytes(c->lim.max_kf), c->stream,
                        dp<BaDev>(c, ojobs), dp<BaCams>(c, ocams), dp<double>(c, oposes), dp<double>(c, opts),
                        dp<BaRec>(c, orecs), dp<int>(c, oaux), c->bw, huber_delta, iters, dp<double>(c, ochi), c->d_ba_prof,
-                       tile_cap, SbaArgs{ 0, 0, 0.0, nullptr });
+                       tile_cap, SbaArgs{ 0, 0, 0.0, nullptr, c->d_lm_trace });
     tm_end(c);
     HIPCHK(c, hipGetLastError());
     c->ba_pending.oflag = oflag;
@@ -1099,7 +1112,7 @@ int svslam_sba_phase(svslam_ctx *c, int phase, double lambda, double *io)
     const size_t nio = SBA_IO_DOUBLES(c->sba.np) * sizeof(double);
     if (phase == 3) { memcpy(hp<void>(c, c->sba.oio), io, nio); if (h2d(c, c->sba.oio, c->sba.oio + nio)) return -1; }
     else HIPCHK(c, hipMemsetAsync(dp<void>(c, c->sba.oio), 0, nio, c->stream));
-    SbaArgs a{ phase, c->sba.launches == 0 ? 1 : 0, lambda, dp<double>(c, c->sba.oio) };
+    SbaArgs a{ phase, c->sba.launches == 0 ? 1 : 0, lambda, dp<double>(c, c->sba.oio), nullptr };
     tm_begin(c, FAM_BA, 1);
     hipLaunchKernelGGL(k_local_ba_t<1>, dim3(1), dim3(BA_THREADS), ba_lds_bytes(c->lim.max_kf), c->stream, dp<BaDev>(c, c->sba.ojobs),
                        dp<BaCams>(c, c->sba.ocams), dp<double>(c, c->sba.oposes), dp<double>(c, c->sba.opts), dp<BaRec>(c, c->sba.orecs),
@@ -1175,6 +1188,28 @@ int svslam_ba_profile(svslam_ctx *c, int enable, long long *out12)
         HIPCHK(c, hipMemset(c->d_ba_prof, 0, sizeof(long long) * BA_PROF_N));
     }
     if (!enable && c->d_ba_prof) { (void)hipFree(c->d_ba_prof); c->d_ba_prof = nullptr; }
+    return 0;
+}
+
+// test hook: the LM trajectory of the last pose-only / local-BA call (every trial, rejected ones included), job by job.
+// enable = 1 allocates the buffer (the kernels then record), 0 frees it; out != NULL copies job `job`'s records
+// (6 doubles each: iteration [pose-only: 16 round + iteration], lambda, chi2 before, chi2 of the trial, rho, accepted).
+int svslam_lm_trace(svslam_ctx *c, int enable, int job, double *out, int cap_records, int *n_records)
+{
+    if (enable && !c->d_lm_trace) {
+        HIPCHK(c, hipMalloc(&c->d_lm_trace, sizeof(double) * LM_TRACE_STRIDE * (size_t)c->lim.max_jobs));
+        HIPCHK(c, hipMemset(c->d_lm_trace, 0, sizeof(double) * LM_TRACE_STRIDE * (size_t)c->lim.max_jobs));
+    }
+    if (out && c->d_lm_trace) {
+        if (job < 0 || job >= c->lim.max_jobs) return fail(c, "lm_trace: job %d out of range", job);
+        std::vector<double> t(LM_TRACE_STRIDE);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpy(t.data(), c->d_lm_trace + (size_t)job * LM_TRACE_STRIDE, sizeof(double) * LM_TRACE_STRIDE, hipMemcpyDeviceToHost));
+        const int n = std::min((int)t[0], cap_records);
+        if (n_records) *n_records = n;
+        if (n > 0) memcpy(out, t.data() + 8, sizeof(double) * LM_TRACE_REC * (size_t)n);
+    } else if (n_records) *n_records = 0;
+    if (!enable && c->d_lm_trace) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_lm_trace); c->d_lm_trace = nullptr; }
     return 0;
 }
 
@@ -1375,7 +1410,7 @@ int svslam_rtrack_upload(svslam_ctx *c, int n, const int *streams, const int *of
         if (counts[i] < 0 || counts[i] > c->lim.max_pts) return fail(c, "rtrack_upload: %d features > max_pts %d", counts[i], c->lim.max_pts);
         total = std::max(total, ofs[i] + counts[i]); maxc = std::max(maxc, counts[i]);
     }
-    if (c->ba_pending.active) return fail(c, "a submitted local-BA batch owns this context: call svslam_local_ba_collect first");
+    if (arena_busy(c)) return -1;
     c->ar.reset();
     const size_t T = (size_t)std::max(total, 1);
     size_t oj = c->ar.take(sizeof(RtUpJob) * n);

@@ -62,17 +62,25 @@ inline bool read_png(const std::vector<uint8_t> &f, Image &img)
     uint32_t w = 0, h = 0;
     int depth = 0, ctype = 0, interlace = 0;
     std::vector<uint8_t> z;
+    bool first = true;
     while (p + 12 <= f.size()) {
         const uint32_t len = be32(&f[p]);
         const char *ty = reinterpret_cast<const char *>(&f[p + 4]);
         if (p + 12 + (size_t)len > f.size()) return false;
         const uint8_t *d = &f[p + 8];
-        if (!std::memcmp(ty, "IHDR", 4)) { w = be32(d); h = be32(d + 4); depth = d[8]; ctype = d[9]; interlace = d[12]; }
+        const bool ihdr = !std::memcmp(ty, "IHDR", 4);
+        if (first != ihdr) return false;                       // IHDR is the first chunk and appears once
+        first = false;
+        if (ihdr) {
+            if (len != 13) return false;
+            w = be32(d); h = be32(d + 4); depth = d[8]; ctype = d[9]; interlace = d[12];
+        }
         else if (!std::memcmp(ty, "IDAT", 4)) z.insert(z.end(), d, d + len);
         else if (!std::memcmp(ty, "IEND", 4)) break;
         p += 12 + (size_t)len;
     }
-    if (!w || !h || depth != 8 || interlace != 0) return false;
+    // a corrupt file yields an empty image (what cv::imread returns), never an oversized allocation
+    if (!w || !h || w > 16384 || h > 16384 || depth != 8 || interlace != 0 || z.empty()) return false;
     const int ch = ctype == 0 ? 1 : ctype == 4 ? 2 : ctype == 2 ? 3 : ctype == 6 ? 4 : 0;
     if (!ch) return false;
     const size_t stride = (size_t)w * ch;
@@ -118,7 +126,8 @@ inline bool read_pgm(const std::vector<uint8_t> &f, Image &img)
         vals[n++] = v;
     }
     ++p;                                         // the single whitespace after maxval
-    if (n < 3 || vals[2] != 255 || p + (size_t)vals[0] * vals[1] > f.size()) return false;
+    if (n < 3 || vals[2] != 255 || vals[0] <= 0 || vals[1] <= 0 || vals[0] > 16384 || vals[1] > 16384 ||
+        p + (size_t)vals[0] * vals[1] > f.size()) return false;
     img.cols = vals[0]; img.rows = vals[1];
     img.data.assign(f.begin() + (long)p, f.begin() + (long)p + (long)vals[0] * vals[1]);
     return true;
@@ -129,7 +138,9 @@ inline Image imread(const std::string &path)     // empty image when the file is
     std::ifstream in(path, std::ios::binary);
     if (!in) return img;
     std::vector<uint8_t> f((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
-    if (!read_png(f, img) && !read_pgm(f, img)) { img = Image(); }
+    try {
+        if (!read_png(f, img) && !read_pgm(f, img)) img = Image();
+    } catch (const std::exception &) { img = Image(); }        // bad_alloc / length_error on a corrupt header
     return img;
 }
 
@@ -147,7 +158,10 @@ public:
             const size_t c = line.find(':');
             if (c == std::string::npos || (!line.empty() && line[0] == '%')) continue;
             auto trim = [](std::string s) { const size_t a = s.find_first_not_of(" \t\r"), b = s.find_last_not_of(" \t\r"); return a == std::string::npos ? std::string() : s.substr(a, b - a + 1); };
-            kv_.emplace_back(trim(line.substr(0, c)), trim(line.substr(c + 1)));
+            std::string val = trim(line.substr(c + 1));
+            if (val.size() >= 2 && (val.front() == '"' || val.front() == '\'') && val.back() == val.front())
+                val = val.substr(1, val.size() - 2);           // cv::FileStorage accepts quoted strings
+            kv_.emplace_back(trim(line.substr(0, c)), val);
         }
         return true;
     }
@@ -256,8 +270,18 @@ class FrontendT {
 public:
     typedef std::shared_ptr<FrontendT> Ptr;
     explicit FrontendT(const FrontendOptions &opt = FrontendOptions()) : opt_(opt) {}
-    void SetMap(Map::Ptr map) { map_ = map; wire_map(); }
-    void SetBackend(std::shared_ptr<Backend> backend) { backend_ = backend; wire_backend(); }
+    ~FrontendT() { unwire(); }                    // the shared Backend / Map handles may outlive the frontend
+    FrontendT(const FrontendT &) = delete;
+    FrontendT &operator=(const FrontendT &) = delete;
+    void SetMap(Map::Ptr map) { if (map_) { map_->keyframes_fn = nullptr; map_->landmarks_fn = nullptr; } map_ = map; wire_map(); }
+    // The pipeline is created at the first AddFrame with local BA compiled in; a backend handle may be attached,
+    // replaced or removed at any time (a frontend without one runs without optimisation, src/frontend.cpp:618-622).
+    void SetBackend(std::shared_ptr<Backend> backend)
+    {
+        if (backend_) { backend_->optimize_now_ = nullptr; backend_->set_enabled_ = nullptr; }
+        backend_ = backend;
+        wire_backend();
+    }
     // the reference's LoopClosure::AddNewKeyFrame / Viewer::UpdateMap call sites (src/frontend.cpp:631-640)
     void SetLoopClosure(std::function<void(const Frame::Ptr &)> on_new_keyframe) { loopclosure_ = std::move(on_new_keyframe); }
     void SetViewer(std::function<void(const Frame::Ptr &)> on_frame) { viewer_ = std::move(on_frame); }
@@ -302,7 +326,7 @@ private:
         cfg.num_features_needed_for_keyframe = opt_.num_features_needed_for_keyframe;
         cfg.max_triangulation_depth = opt_.max_triangulation_depth;
         cfg.num_active_keyframes = opt_.num_active_keyframes; cfg.chi2_th = opt_.chi2_th;
-        cfg.backend_on = backend_ ? 1 : 0;
+        cfg.backend_on = 1;                        // gated by SetBackendEnabled: see SetBackend
         cfg.width = dw; cfg.height = dh; cfg.src_width = w; cfg.src_height = h;
         cfg.resident_track = 0;                    // one stream: the host keeps the feature lists (Backend::UpdateMap from outside)
         cfg.cam_l = *camera_left_; cfg.cam_r = *camera_right_;
@@ -317,9 +341,14 @@ private:
         pipe_.reset(new Pipeline<K>(cfg, *kernels_, 1, 1));
         wire_backend(); wire_map();
     }
+    void unwire()
+    {
+        if (backend_) { backend_->optimize_now_ = nullptr; backend_->set_enabled_ = nullptr; }
+        if (map_) { map_->keyframes_fn = nullptr; map_->landmarks_fn = nullptr; }
+    }
     void wire_backend()
     {
-        if (!backend_) return;
+        if (!backend_) { if (pipe_) pipe_->SetBackendEnabled(false); return; }
         backend_->optimize_now_ = [this]() { if (pipe_) pipe_->OptimizeNow(); };
         backend_->set_enabled_ = [this](bool on) { if (pipe_) pipe_->SetBackendEnabled(on); };
         if (pipe_) pipe_->SetBackendEnabled(backend_->enabled());
@@ -444,7 +473,7 @@ public:
         if ((int)config_.Num("backend_on", 1) != 0) backend_.reset(new Backend());
         frontend_->SetMap(map_);
         frontend_->SetBackend(backend_);
-        frontend_->SetCameras(dataset_->GetCamera((int)config_.Num("left_cam_index", 0)), dataset_->GetCamera((int)config_.Num("right_cam_index", 1)));
+        frontend_->SetCameras(dataset_->GetCamera(0), dataset_->GetCamera(1));   // src/visual_odometry.cpp:73: always cameras 0 / 1; only the image folders follow left/right_cam_index
         if (backend_) { backend_->SetMap(map_); backend_->SetCameras(dataset_->GetCamera(0), dataset_->GetCamera(1)); }
         return true;
     }

@@ -893,6 +893,8 @@ private:
                 max_obs += AL[li]->observations.size();
             }
             g.nkf_ub = (int)st.map.active_keyframes_.size(); g.nlm_ub = (int)AL.size(); g.nobs_ub = (int)max_obs;
+            if (cfg_.max_lm > 0) g.nlm_ub = std::min(g.nlm_ub, cfg_.max_lm + 1);
+            if (cfg_.max_obs > 0) g.nobs_ub = std::min(g.nobs_ub, cfg_.max_obs + 1);
         });
         jobs_ba_.resize(n);
         int ko = 0, lo = 0, oo = 0;
@@ -903,6 +905,8 @@ private:
             j.nkf = j.nlm = j.nobs = 0; j.iters_done = 0; j.reserved = 0;
             ko += g.nkf_ub; lo += g.nlm_ub; oo += g.nobs_ub;
         }
+        // (the bounds are already clamped to capacity + 1 below: a problem that will be dropped as over capacity
+        // reserves no more than a problem that just fits, so it cannot push the batch past the provider's arena)
         ba_poses_.resize(7 * (size_t)std::max(ko, 1)); ba_pts_.resize(3 * (size_t)std::max(lo, 1));
         ba_okf_.resize((size_t)std::max(oo, 1)); ba_olm_.resize((size_t)std::max(oo, 1));
         ba_right_.resize((size_t)std::max(oo, 1)); ba_uv_.resize(2 * (size_t)std::max(oo, 1));
@@ -920,6 +924,7 @@ private:
             }
             const std::vector<MapPoint *> &AL = st.map.active_landmarks_;
             g.lms.resize(AL.size()); g.edge_feat.resize((size_t)g.nobs_ub);
+            const int lm_room = g.nlm_ub; const size_t obs_room = (size_t)g.nobs_ub;   // writes stop at the reservation, counting goes on
             MapPoint **__restrict o_lms = g.lms.data();
             double *__restrict o_pts = &ba_pts_[3 * (size_t)j.lm_ofs];
             int *__restrict o_kf = &ba_okf_[(size_t)j.obs_ofs], *__restrict o_lm = &ba_olm_[(size_t)j.obs_ofs];
@@ -938,21 +943,25 @@ private:
                     if (ft.outlier) continue;
                     if (lm_local < 0) {                              // vertex even if no edge follows (:118-130)
                         lm_local = nl++;
-                        o_lms[lm_local] = mp;
-                        o_pts[3 * lm_local] = mp->pos[0]; o_pts[3 * lm_local + 1] = mp->pos[1]; o_pts[3 * lm_local + 2] = mp->pos[2];
+                        if (lm_local < lm_room) {
+                            o_lms[lm_local] = mp;
+                            o_pts[3 * lm_local] = mp->pos[0]; o_pts[3 * lm_local + 1] = mp->pos[1]; o_pts[3 * lm_local + 2] = mp->pos[2];
+                        }
                     }
                     const int kl = ob.frame->ba_local;
                     if (kl < 0) continue;                            // frame not in the active window (:133)
-                    o_kf[ne] = kl; o_lm[ne] = lm_local;
-                    o_right[ne] = ob.is_left ? 0 : 1;
-                    o_uv[2 * ne] = ft.x; o_uv[2 * ne + 1] = ft.y;
-                    o_ef[ne] = ob;
+                    if (ne < obs_room) {
+                        o_kf[ne] = kl; o_lm[ne] = lm_local;
+                        o_right[ne] = ob.is_left ? 0 : 1;
+                        o_uv[2 * ne] = ft.x; o_uv[2 * ne + 1] = ft.y;
+                        o_ef[ne] = ob;
+                    }
                     ++ne;
                 }
             }
-            g.lms.resize((size_t)nl); g.edge_feat.resize(ne);
-            j.nkf = (int)g.kfs.size(); j.nlm = nl; j.nobs = (int)ne;
-            for (size_t e = 0; e < ne; ++e) ba_chi2_[(size_t)j.obs_ofs + e] = 0.0;
+            g.lms.resize((size_t)std::min(nl, lm_room)); g.edge_feat.resize(std::min(ne, obs_room));
+            j.nkf = (int)g.kfs.size(); j.nlm = nl; j.nobs = (int)ne;      // beyond the reservation = over capacity: dropped below
+            for (size_t e = 0; e < std::min(ne, obs_room); ++e) ba_chi2_[(size_t)j.obs_ofs + e] = 0.0;
             for (Frame *kf : g.kfs) kf->ba_local = -1;
         });
         // a problem beyond the provider's capacity is dropped for this keyframe, alone
@@ -978,11 +987,15 @@ private:
     }
 
     // development hook: writes job i of the batch being submitted when its window is full
-    // (int32 nkf nlm nobs | f64 poses[7 nkf] pts[3 nlm] | i32 okf[nobs] olm[nobs] | u8 right[nobs] | f32 uv[2 nobs])
+    // (int32 nkf nlm nobs | f64 poses[7 nkf] pts[3 nlm] | i32 okf[nobs] olm[nobs] | u8 right[nobs] | f32 uv[2 nobs]).
+    // A '%' in the path makes it a printf pattern for a running number (one file per full-window keyframe:
+    // tests/golden/make_ba_golden.py captures its problems this way), otherwise the file is overwritten.
     void DumpBaProblem(const char *path, int i)
     {
         const svslam_ba_job &j = jobs_ba_[(size_t)i];
         if (j.nkf < cfg_.num_active_keyframes) return;
+        char name[1024];
+        if (std::strchr(path, '%')) { std::snprintf(name, sizeof(name), path, dump_seq_++); path = name; }
         std::ofstream f(path, std::ios::binary | std::ios::trunc);
         const int hdr[3] = { j.nkf, j.nlm, j.nobs };
         f.write(reinterpret_cast<const char *>(hdr), sizeof(hdr));
@@ -1071,6 +1084,7 @@ public:
     std::function<void(int stream, const Frame &)> on_keyframe;
 private:
     bool backend_enabled_ = true;
+    int dump_seq_ = 0;
     std::vector<int> ba_ms_;
     bool ba_inflight_ = false;
     int ba_ko_ = 0, ba_lo_ = 0, ba_oo_ = 0;

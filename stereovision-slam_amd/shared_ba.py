@@ -12,9 +12,11 @@ import math
 import numpy as np
 
 
-def shared_map_ba(engine, rank, nkf, iters=10):
+def shared_map_ba(engine, rank, nkf, iters=10, trace=None):
     """engine.phase(p, lam, io) -> io (see include/svslam.h, svslam_sba_phase); rank: dist.Rank.
-    Returns (iterations done, final lambda).  The optimised state stays in the engine."""
+    Returns (iterations done, final lambda).  The optimised state stays in the engine.
+    trace (optional list): receives one record per LM trial — (iteration, lambda, chi2 before, chi2 of the
+    trial, rho, accepted) — the layout of svslam_lm_trace, so tests can compare trajectories."""
     n = 6 * nkf
     nio = n * n + 3 * n + 8
     oS, obs, obp, ohd, osc = 0, n * n, n * n + n, n * n + 2 * n, n * n + 3 * n
@@ -44,6 +46,8 @@ def shared_map_ba(engine, rank, nkf, iters=10):
             temp = float(part[1]) if ok else 1.7976931348623157e308
             scale = float(part[0]) + float(out[osc + 4]) + 1e-3
             rho = (current - temp) / scale
+            if trace is not None:
+                trace.append((float(it), lam, current, temp, rho, 1.0 if (rho > 0 and math.isfinite(temp)) else 0.0))
             if rho > 0 and math.isfinite(temp):
                 t = 2 * rho - 1
                 alpha = min(1.0 - t * t * t, 2.0 / 3.0)

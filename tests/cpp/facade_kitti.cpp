@@ -65,6 +65,50 @@ int main(int argc, char **argv)
         CHECK(!vo.backend()->IsRunning());
     }
     CHECK(vo.saveSLAMOutputInFile(argv[2]));
+    // the shared Backend / Map handles outlive a frontend without dangling into it, and a backend
+    // attached AFTER the first frame still optimises (the reference wires them in any order before run())
+    {
+        std::shared_ptr<Backend> be(new Backend());
+        Map::Ptr mp(new Map());
+        {
+            FrontendT<Provider> fe;
+            fe.SetCameras(vo.dataset()->GetCamera(0), vo.dataset()->GetCamera(1));
+            fe.SetMap(mp);
+            Frame::Ptr f0 = vo.dataset()->FrameById(0);
+            CHECK(f0 && fe.AddFrame(f0));                       // pipeline exists, no backend yet
+            fe.SetBackend(be);                                    // attached late
+            CHECK(fe.pipeline()->BackendEnabled());
+            be->PauseRequest();
+            CHECK(!fe.pipeline()->BackendEnabled());
+            be->Resume();
+            CHECK(mp->GetAllKeyFrames().size() == 1);
+        }
+        be->UpdateMap();                                          // frontend gone: a no-op, not a dangling call
+        CHECK(mp->GetAllKeyFrames().empty() && mp->GetAllMapPoints().empty());
+    }
+    // corrupt image files give an empty image like cv::imread, never an out-of-bounds read or a huge allocation
+    {
+        Image img;
+        std::vector<uint8_t> sig = { 0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a };
+        auto chunk = [](std::vector<uint8_t> &f, const char *ty, const std::vector<uint8_t> &d) {
+            const uint32_t n = (uint32_t)d.size();
+            f.push_back(n >> 24); f.push_back(n >> 16); f.push_back(n >> 8); f.push_back(n);
+            f.insert(f.end(), ty, ty + 4); f.insert(f.end(), d.begin(), d.end());
+            f.insert(f.end(), 4, 0);                             // CRC (not checked)
+        };
+        std::vector<uint8_t> a = sig;                             // IHDR shorter than 13 bytes
+        chunk(a, "IHDR", std::vector<uint8_t>(5, 0)); chunk(a, "IDAT", std::vector<uint8_t>(16, 1)); chunk(a, "IEND", {});
+        CHECK(!read_png(a, img));
+        std::vector<uint8_t> b = sig;                             // first chunk is not IHDR
+        chunk(b, "IDAT", std::vector<uint8_t>(16, 1)); chunk(b, "IHDR", std::vector<uint8_t>(13, 0)); chunk(b, "IEND", {});
+        CHECK(!read_png(b, img));
+        std::vector<uint8_t> c = sig;                             // absurd size: 2^31 x 2^31
+        chunk(c, "IHDR", { 0x80, 0, 0, 0, 0x80, 0, 0, 0, 8, 0, 0, 0, 0 }); chunk(c, "IDAT", std::vector<uint8_t>(16, 1)); chunk(c, "IEND", {});
+        CHECK(!read_png(c, img));
+        const std::string bad = std::string(argv[2]) + "/corrupt.png";
+        { std::ofstream o(bad, std::ios::binary); o.write(reinterpret_cast<const char *>(c.data()), (long)c.size()); }
+        CHECK(imread(bad).empty());
+    }
     std::printf("frames %d keyframes %d landmarks %zu\nfacade ok\n", n, nkf, lms.size());
     return 0;
 }

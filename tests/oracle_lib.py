@@ -204,3 +204,40 @@ def local_ba(cam_l, ext_l, cam_r, ext_r, poses, pts, obs_kf, obs_lm, obs_is_righ
                             pts.shape[0], _p(pts), ne, _p(okf), _p(olm), _p(ori), _p(ouv),
                             C.c_double(huber_delta), iters, jac_mode, _p(chi2))
     return poses, pts, chi2[:ne], it
+
+
+TRACE_REC = 6     # ORC_TRACE_REC: iteration, lambda, chi2 before, chi2 of the trial, rho, accepted
+
+
+def local_ba_trace(cam_l, ext_l, cam_r, ext_r, poses, pts, obs_kf, obs_lm, obs_is_right, obs_uv,
+                   huber_delta=5.991, iters=10, jac_mode=0):
+    """orc_local_ba + the per-trial LM trajectory [ntrials, TRACE_REC] (rejected trials included)"""
+    poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 7).copy()
+    pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 3).copy()
+    okf = np.ascontiguousarray(obs_kf, np.int32)
+    olm = np.ascontiguousarray(obs_lm, np.int32)
+    ori = np.ascontiguousarray(obs_is_right, np.uint8)
+    ouv = np.ascontiguousarray(obs_uv, np.float32).reshape(-1, 2)
+    ne = okf.shape[0]
+    chi2 = np.zeros(max(ne, 1))
+    cap = 10 * max(iters, 1) + 1
+    trace = np.zeros((cap, TRACE_REC)); nt = C.c_int(0)
+    lib().orc_local_ba_trace.restype = C.c_int
+    it = lib().orc_local_ba_trace(_p(_d(cam_l)), _p(_d(ext_l)), _p(_d(cam_r)), _p(_d(ext_r)), poses.shape[0], _p(poses),
+                                  pts.shape[0], _p(pts), ne, _p(okf), _p(olm), _p(ori), _p(ouv),
+                                  C.c_double(huber_delta), iters, jac_mode, _p(chi2), _p(trace), cap, C.byref(nt))
+    return poses, pts, chi2[:ne], it, trace[:nt.value].copy()
+
+
+def pose_only_trace(cam, pose, xyz, uv, chi2_th=5.991, rounds=4, iters=10):
+    xyz = np.ascontiguousarray(xyz, np.float64).reshape(-1, 3)
+    uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+    n = xyz.shape[0]
+    T = _d(pose).copy()
+    outl = np.zeros(max(n, 1), np.uint8)
+    cap = 10 * rounds * max(iters, 1) + 1
+    trace = np.zeros((cap, TRACE_REC)); nt = C.c_int(0)
+    lib().orc_pose_only_trace.restype = C.c_int
+    ninl = lib().orc_pose_only_trace(n, _p(_d(cam)), _p(T), _p(xyz), _p(uv), _p(outl), C.c_double(chi2_th), rounds,
+                                     iters, _p(trace), cap, C.byref(nt))
+    return T, outl[:n], ninl, trace[:nt.value].copy()

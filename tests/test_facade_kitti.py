@@ -64,7 +64,7 @@ def _make_sequence(svs, root, seed, nframes):
         frames.append((l, r))
     cfg = os.path.join(root, "config.yaml")
     with open(cfg, "w") as f:
-        f.write("%YAML:1.0\n# written by tests/test_facade_kitti.py\ndataset_dir: " + seq + "\nleft_cam_index: 0\nright_cam_index: 1\n"
+        f.write("%YAML:1.0\n# written by tests/test_facade_kitti.py\ndataset_dir: \"" + seq + "\"\nleft_cam_index: 0\nright_cam_index: 1\n"
                 "is_color_input: 0\noutput_dir: " + root + "\nnum_features: 150\nnum_features_init: 50\nnum_features_tracking: 50\n"
                 "num_features_tracking_bad: 20\nnum_features_needed_for_keyframe: 80\nmax_triangulation_depth: 300.0\n"
                 "keypoint_feature_detector: GFTT\nnum_active_keyframes: 10\nbackend_on: 1\nchi2_th: 5.991\nloopclosure_on: 0\nvisualizer_on: 0\n")

@@ -1,0 +1,85 @@
+"""CPU side of the LM-trajectory tests: the oracle against the committed pipeline problems, the seeded cases
+really reject trials, and an independent implementation (numpy phases + the Python LM driver of shared_ba.py)
+follows the oracle through rejected trials."""
+import importlib
+
+import numpy as np
+import pytest
+
+import common as cm
+import lm_cases as lc
+
+
+def test_oracle_reproduces_the_captured_pipeline_problems(orc):
+    """tests/golden/ba_pipeline.npz pins the oracle's answer (analytic Jacobians) to 12 problems captured from
+    the host pipeline: 8 at K = 10 (~1700 landmarks / ~4000 edges, 75-79 % single-view), 4 at K = 7, 613x185."""
+    probs = lc.pipeline_problems()
+    assert sum(p["tag"] == "k10" for p in probs) >= 8 and sum(p["tag"] == "k7" for p in probs) >= 4
+    for i, P in enumerate(probs):
+        nkf = len(P["poses0"])
+        assert nkf == (10 if P["tag"] == "k10" else 7)
+        blocks = {}
+        for k, l in zip(P["okf"], P["olm"]):
+            blocks.setdefault(int(l), set()).add(int(k))
+        single = sum(1 for v in blocks.values() if len(v) == 1) / len(blocks)
+        assert 0.70 < single < 0.85, single            # the shape the synthetic generator never had
+        if i % 4:                                       # three of four only by shape (keeps the CPU suite short)
+            continue
+        po, xo, co, it, tr = orc.local_ba_trace(P["cam"], cm.EXT_L, P["cam"], P["ext_r"], P["poses0"], P["pts0"], P["okf"],
+                                                P["olm"], P["ori"], P["ouv"], jac_mode=0)
+        assert it == int(P["iters"][0])
+        assert np.allclose(po, P["poses"], rtol=0, atol=1e-12) and np.allclose(xo, P["pts"], rtol=1e-12, atol=1e-12)
+        assert np.allclose(co, P["chi2"], rtol=1e-9, atol=1e-12)
+        assert np.allclose(tr, P["trace"], rtol=1e-9)
+
+
+def test_trace_hook_does_not_change_the_result(orc):
+    job = lc.ba_synth_case(1000)
+    a = orc.local_ba(cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R, *job, jac_mode=0)
+    b = orc.local_ba_trace(cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R, *job, jac_mode=0)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3]
+    T0, P, uv = lc.po_case(14)
+    c = orc.pose_only(cm.CAM, T0, P, uv); d = orc.pose_only_trace(cm.CAM, T0, P, uv)
+    assert np.array_equal(c[0], d[0]) and np.array_equal(c[1], d[1]) and c[2] == d[2]
+
+
+def test_the_seeded_cases_reject_trials_where_it_matters(orc):
+    """every case must hold at least one rejected trial inside its significant prefix — otherwise the GPU
+    trajectory tests would silently stop exercising the path after a rejection"""
+    for seed, iters in lc.BA_SYNTH_REJECT:
+        tr = orc.local_ba_trace(cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R, *lc.ba_synth_case(seed), iters=iters, jac_mode=0)[4]
+        n = lc.sig_prefix(tr)
+        assert (tr[:n, 5] == 0).sum() >= 1, (seed, n, len(tr))
+        # and an accepted trial FOLLOWS a rejected one: the successor of a rejection is linearised / evaluated
+        rej = np.nonzero(tr[:n, 5] == 0)[0]
+        assert (tr[rej[0]:n, 5] == 1).any(), seed
+    for (idx, pn, rot, of, ptn, iters) in lc.BA_PIPE_REJECT[:2]:
+        cam, ext_r, job = lc.ba_pipe_case(idx, pn, rot, of, ptn)
+        tr = orc.local_ba_trace(cam, cm.EXT_L, cam, ext_r, *job, iters=iters, jac_mode=0)[4]
+        n = lc.sig_prefix(tr)
+        assert (tr[:n, 5] == 0).sum() >= 1, (idx, n, len(tr))
+    for seed in lc.PO_REJECT:
+        T0, P, uv = lc.po_case(seed)
+        tr = orc.pose_only_trace(cm.CAM, T0, P, uv)[3]
+        tot = 0
+        for r in range(4):
+            rr = tr[(tr[:, 0] // 16) == r]
+            tot += int((rr[:lc.sig_prefix(rr), 5] == 0).sum()) if len(rr) else 0
+        assert tot >= 1, seed
+
+
+@pytest.mark.parametrize("seed,iters", [(1024, 10), (1036, 10)])
+def test_independent_lm_follows_the_oracle_through_rejected_trials(orc, seed, iters):
+    """Outside pin of the oracle's path after a rejection: the numpy phases of tests/test_shared_map_ba.py
+    (dense, written from the equations) under the Python LM driver of shared_ba.py — no code shared with
+    orc_local_ba — must take the same accept / reject decisions with the same lambda and chi2."""
+    from test_shared_map_ba import NumpyEngine
+    sdist = importlib.import_module("stereovision-slam_amd.dist")
+    sba = importlib.import_module("stereovision-slam_amd.shared_ba")
+    poses, pts, okf, olm, ori, ouv = lc.ba_synth_case(seed)
+    ref = orc.local_ba_trace(cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R, poses, pts, okf, olm, ori, ouv, iters=iters, jac_mode=0)
+    eng = NumpyEngine(poses, pts, okf, olm, ori, ouv)
+    tr = []
+    it, lam = sba.shared_map_ba(eng, sdist.Rank(0, 0, 1), len(poses), iters=iters, trace=tr)
+    n, nrej = lc.assert_traces_agree(np.array(tr), ref[4], need_rejected=1, what="numpy LM seed %d" % seed)
+    assert nrej >= 1 and it == ref[3]

@@ -193,6 +193,14 @@ def test_shared_map_ba_on_the_gpu(svs, tmp_path):
     # one rank through the phases == the single-launch local BA (same kernel code, host-driven LM)
     (pr, xr, cr, itr), = ctx.local_ba([(poses, pts, okf, olm, ori, ouv)], cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R)
     eng = sba.HipEngine(ctx, cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R, poses, pts, okf, olm, ori, ouv)
+    # an open shard owns the staging arena and job 0 of the BA scratch: every other batched call is refused
+    # (used to overwrite the shard silently)
+    for call in (lambda: ctx.local_ba([(poses, pts, okf, olm, ori, ouv)], cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R),
+                 lambda: ctx.pose_only([(cm.EXT_L, pts[:50], np.zeros((50, 2), np.float32))], cm.CAM),
+                 lambda: ctx.pyramid([0], [np.zeros((cm.H, cm.W), np.uint8)]),
+                 lambda: ctx.triangulate([(np.ones((4, 2)), np.ones((4, 2)), None, 0.0)], cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R)):
+        with pytest.raises(RuntimeError, match="svslam_sba_close"):
+            call()
     it1, lam1 = sba.shared_map_ba(eng, sdist.Rank(0, 0, 1), len(poses), iters=10)
     P1, X1, C1 = eng.close()
     assert it1 == itr == 10
