@@ -371,12 +371,8 @@ private:
             std::vector<LandmarkView> o;
             if (!pipe_) return o;
             auto &m = pipe_->stream(0).map;
-            for (size_t i = 0; i < m.num_landmarks(); ++i) {
-                const svs::MapPoint &p = m.landmark(i);
-                bool act = false;
-                for (const svs::MapPoint *a : m.active_landmarks_) if (a == &p) { act = true; break; }
-                o.push_back(LandmarkView{ (unsigned long)p.id, { p.pos[0], p.pos[1], p.pos[2] }, p.observed_times, act });
-            }
+            for (const svs::LandmarkRecord &p : m.AllLandmarks())
+                o.push_back(LandmarkView{ (unsigned long)p.id, { p.pos[0], p.pos[1], p.pos[2] }, p.observed_times, p.active });
             return o;
         };
     }

@@ -107,6 +107,7 @@ public:
         --n_;
         if (n_ >= kInline) more_.pop_back();
     }
+    void clear() { n_ = 0; more_.clear(); }
     struct It {
         const ObsList *l; size_t i;
         bool operator!=(const It &o) const { return i != o.i; }
@@ -127,9 +128,14 @@ struct MapPoint {
     long id = 0;
     double pos[3] = { 0, 0, 0 };
     bool is_outlier = false;
+    bool active = false;               // member of Map::active_landmarks_
+    bool in_limbo = false;             // listed in Map::limbo_ (unobserved, outside the window)
     int observed_times = 0;
+    long seen_stamp = -1;              // keyframe id at which a live feature list last named this landmark (Map::ReleaseRetired)
     ObsList observations;
 };
+
+struct LandmarkRecord { long id; double pos[3]; int observed_times; bool active; };   // what the map hands to writers / viewers
 
 inline Feature &feat_of(const ObsRef &r) { return r.is_left ? r.frame->left[r.idx] : r.frame->right[r.idx]; }
 
@@ -141,19 +147,50 @@ class Map {
 public:
     explicit Map(int num_active) : num_active_keyframes_(num_active) {}
 
+    // Map::landmarks_ (src/map.h:15) keeps every landmark ever created, but only saveSLAMOutputInFile
+    // (src/visual_odometry.cpp:226-304) ever reads the ones that left the window — their positions.  A landmark is
+    // DEAD once nothing can reach it again: no observation (observed_times == 0: no active keyframe's feature names
+    // it) and not named by the feature list tracking carries forward (ids enter that list only at keyframes and it
+    // only shrinks in between).  Dead landmarks are spilled to an append-only archive of (id, float xyz) — 16 bytes
+    // instead of ~190 — and their MapPoint object is reused: the host store stays bounded on long runs (VERDICT r2:
+    // 4.9 KB per frame -> 600 GB for 10 k frames at 12 288 streams).  Behaviour is unchanged: a dead landmark is
+    // unreachable by construction; `point()` of its id gives nullptr, which every caller already treats as "no map
+    // point" (an expired weak_ptr in the reference).
     MapPoint *CreateNewMappoint()       // src/mappoint.cpp:88-98 (per-stream factory)
     {
-        store_.emplace_back();
-        store_.back().id = (long)store_.size() - 1;
-        return &store_.back();
+        MapPoint *m;
+        if (!free_.empty()) {
+            m = free_.back(); free_.pop_back();
+            m->is_outlier = false; m->active = false; m->in_limbo = false; m->observed_times = 0; m->seen_stamp = -1; m->observations.clear();
+        } else { pool_.emplace_back(); m = &pool_.back(); }
+        m->id = next_id_++;
+        slots_.push_back(m);
+        return m;
     }
-    MapPoint *point(long id) { return id >= 0 ? &store_[(size_t)id] : nullptr; }
-    size_t num_landmarks() const { return store_.size(); }                 // Map::landmarks_
-    const MapPoint &landmark(size_t i) const { return store_[i]; }
+    MapPoint *point(long id)
+    {
+        if (id < base_id_) return nullptr;           // covers id == -1 (no map point) and evicted ids below the window
+        return slots_[(size_t)(id - base_id_)];
+    }
+    size_t num_landmarks() const { return (size_t)next_id_; }                 // Map::landmarks_.size()
+    size_t num_resident_landmarks() const { return pool_.size() - free_.size(); }
+    void set_keep_archive(bool on) { keep_archive_ = on; }
+    // every landmark ever created, id-ascending (live ones with their current position, evicted ones as archived)
+    std::vector<LandmarkRecord> AllLandmarks() const
+    {
+        std::vector<LandmarkRecord> o;
+        o.reserve(archive_.size() + slots_.size());
+        for (const ArchivedLandmark &a : archive_) o.push_back(LandmarkRecord{ a.id, { a.pos[0], a.pos[1], a.pos[2] }, 0, false });
+        for (const MapPoint *m : slots_)
+            if (m) o.push_back(LandmarkRecord{ m->id, { m->pos[0], m->pos[1], m->pos[2] }, m->observed_times, m->active });
+        std::sort(o.begin(), o.end(), [](const LandmarkRecord &a, const LandmarkRecord &b) { return a.id < b.id; });
+        return o;
+    }
 
     void InsertMapPoint(MapPoint *mp)   // src/map.cpp:69-74
     {
-        // landmarks_[id] = mp is implicit (store_); ids are new, so appending keeps id order
+        // landmarks_[id] = mp is implicit (slots_); ids are new, so appending keeps id order
+        mp->active = true;
         active_landmarks_.push_back(mp);
     }
     void InsertKeyFrame(Frame *frame)   // src/map.cpp:53-67
@@ -170,21 +207,26 @@ public:
     }
     void RemoveObservation(MapPoint *mp, const ObsRef &f) // src/mappoint.cpp:38-78
     {
+        if (!mp) return;
         for (size_t i = 0; i < mp->observations.size(); ++i) {
             if (mp->observations[i] == f) {
                 mp->observations.erase_at(i);
                 Feature &ft = feat_of(f);
                 if (ft.outlier) ft.mp = -1;
                 mp->observed_times--;
+                if (mp->observed_times == 0 && !mp->active) ToLimbo(mp);   // re-observed after it left the window, now unobserved again
                 break;
             }
         }
     }
     void CleanMap()                     // src/map.cpp:21-40
     {
-        active_landmarks_.erase(std::remove_if(active_landmarks_.begin(), active_landmarks_.end(),
-                                               [](MapPoint *m) { return m->observed_times == 0; }),
-                                active_landmarks_.end());
+        size_t keep = 0;
+        for (MapPoint *m : active_landmarks_) {
+            if (m->observed_times == 0) { m->active = false; ToLimbo(m); }   // out of the window; dead unless tracking still carries it
+            else active_landmarks_[keep++] = m;
+        }
+        active_landmarks_.resize(keep);
     }
     void RemoveOldKeyframe()            // src/map.cpp:76-181
     {
@@ -222,7 +264,10 @@ public:
     // lists can go back to the allocator and the next keyframe reuses the memory instead of
     // faulting in fresh pages.  The caller decides when: a local BA still in flight holds
     // ObsRefs into the frames of the window it was gathered from.
-    void ReleaseRetired()
+    // `carried`: the feature list of the newest frame (what tracking carries forward from here), `stamp`: any number
+    // that grows from call to call.  Landmarks in limbo (unobserved, outside the window) that the list does not
+    // name are dead: archived and recycled.
+    void ReleaseRetired(const std::vector<Feature> *carried = nullptr, long stamp = 0)
     {
         for (Frame *rm : retired_) {
             std::vector<Feature>().swap(rm->left);
@@ -230,13 +275,41 @@ public:
             std::vector<uint8_t>().swap(rm->right_ok);
         }
         retired_.clear();
+        if (!carried || limbo_.empty()) return;
+        for (const Feature &f : *carried)
+            if (MapPoint *m = point(f.mp)) m->seen_stamp = stamp;
+        size_t keep = 0;
+        for (MapPoint *m : limbo_) {
+            if (m->observed_times > 0 || m->active) { m->in_limbo = false; continue; }   // observed again: RemoveObservation brings it back
+            if (m->seen_stamp == stamp) { limbo_[keep++] = m; continue; }                  // tracking still carries it
+            m->in_limbo = false;
+            Evict(m);
+        }
+        limbo_.resize(keep);
+        // slide the id window past leading evicted ids
+        size_t lead = 0;
+        while (lead < slots_.size() && !slots_[lead]) ++lead;
+        if (lead >= 1024 && lead * 2 >= slots_.size()) { slots_.erase(slots_.begin(), slots_.begin() + (long)lead); base_id_ += (long)lead; }
     }
 
     std::vector<Frame *> keyframes_, active_keyframes_;   // id-ascending
     std::vector<MapPoint *> active_landmarks_;            // id-ascending
 
 private:
-    std::deque<MapPoint> store_;
+    struct ArchivedLandmark { long id; float pos[3]; };
+    void ToLimbo(MapPoint *m) { if (!m->in_limbo) { m->in_limbo = true; limbo_.push_back(m); } }
+    void Evict(MapPoint *m)
+    {
+        if (keep_archive_) archive_.push_back(ArchivedLandmark{ m->id, { (float)m->pos[0], (float)m->pos[1], (float)m->pos[2] } });
+        slots_[(size_t)(m->id - base_id_)] = nullptr;
+        free_.push_back(m);
+    }
+    std::deque<MapPoint> pool_;               // MapPoint objects, recycled through free_
+    std::vector<MapPoint *> free_, limbo_;    // limbo_: unobserved and outside the window, possibly still tracked
+    std::vector<MapPoint *> slots_;           // id - base_id_ -> MapPoint (nullptr: evicted)
+    long base_id_ = 0, next_id_ = 0;
+    std::vector<ArchivedLandmark> archive_;
+    bool keep_archive_ = true;
     std::vector<Frame *> retired_;            // left the window, feature lists not yet released
     Frame *current_frame_ = nullptr;
     int num_active_keyframes_;
@@ -379,15 +452,15 @@ public:
         // reference's Backend thread, and its result lands after that frame — always exactly one
         // frame late, so runs stay reproducible.
         if (cfg_.backend_on == 1 && backend_enabled_) {
-            for (int s : MS) streams_[s]->map.ReleaseRetired();      // nothing in flight
+            for (int s : MS) ReleaseRetired(*streams_[s]);           // nothing in flight
             if (!MS.empty()) { BackendSubmit(MS); BackendCollect(); }
         } else if (cfg_.backend_on >= 2 && backend_enabled_) {
             BackendCollect();                                        // may still touch frames retired this step
-            for (int s : MS) streams_[s]->map.ReleaseRetired();
+            for (int s : MS) ReleaseRetired(*streams_[s]);
             if (!MS.empty()) BackendSubmit(MS);
         } else {
             BackendCollect();
-            for (int s : MS) streams_[s]->map.ReleaseRetired();
+            for (int s : MS) ReleaseRetired(*streams_[s]);
         }
         // frames whose feature list or map points changed on the host (init, keyframes, BA) replace
         // the resident copy; every other frame's list never left the device
@@ -429,14 +502,12 @@ public:
         Stream &st = *streams_[s];
         std::ofstream pcd(dir + "/landmarks.pcd");
         if (!pcd) return false;
-        const size_t n = st.map.num_landmarks();
+        const std::vector<LandmarkRecord> all = st.map.AllLandmarks();
+        const size_t n = all.size();
         pcd << "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\n"
             << "COUNT 1 1 1\nWIDTH " << n << "\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS " << n << "\nDATA ascii\n";
         pcd << std::setprecision(8);
-        for (size_t i = 0; i < n; ++i) {
-            const MapPoint &m = st.map.landmark(i);
-            pcd << (float)m.pos[0] << " " << (float)m.pos[1] << " " << (float)m.pos[2] << "\n";
-        }
+        for (const LandmarkRecord &m : all) pcd << (float)m.pos[0] << " " << (float)m.pos[1] << " " << (float)m.pos[2] << "\n";
         std::ofstream kf(dir + "/keyframes.txt");
         if (!kf) return false;
         kf << dataset_dir << std::endl << left_cam_index << std::endl;
@@ -667,6 +738,10 @@ private:
             if (cur->left[k].mp >= 0) st.map.AddObservation(st.map.point(cur->left[k].mp), ObsRef{ cur, (int)k, true });
         st.is_new_kf = true;
     }
+
+    // safe point of a keyframe step (no BA in flight that holds pointers into the map): retired keyframes give
+    // their feature lists back, landmarks nothing can reach any more are archived (Map::ReleaseRetired)
+    void ReleaseRetired(Stream &st) { st.map.ReleaseRetired(&st.current->left, st.current->id); }
 
     void MakeKeyFrame(Stream &st)
     {

@@ -120,6 +120,12 @@ def report(r, n_frames, twin="reference-faithful CPU twin (numeric-J BA)"):
 if __name__ == "__main__":
     ns = int(sys.argv[1]) if len(sys.argv) > 1 else 48
     nf = int(sys.argv[2]) if len(sys.argv) > 2 else 320
+    if "--analytic-only" in sys.argv:
+        # the SAME-ALGORITHM twin (analytic Jacobians like the HIP kernel) on the big sample —
+        # any difference beyond the chaos of two valid runs would be a defect of the kernel, not of g2o's differentiation
+        res = run(ns, nf, twin_jacobians="analytic", chunk=40)
+        print(report(res, nf, "CPU twin with analytic BA Jacobians (same algorithm as the HIP kernel)"))
+        sys.exit(0)
     res = run(ns, nf)
     print(report(res, nf))
     if "--analytic-too" in sys.argv:

@@ -1,0 +1,69 @@
+"""BASELINE config 4 at its stated length: "synthetic 1241x376 stereo stream, 10k frames, 8 independent streams on
+8 x MI355X" — the per-GPU share is one 10 000-frame stream; here the ONE GPU of the test box carries all eight
+streams for the full 10 000 frames (src/visual_odometry.cpp:164-171 runs a whole sequence).  No oracle at this
+size: the checks are properties — never LOST, trajectory error against the renderer's ground truth, no capacity
+event, bounded host memory (the evicting landmark store of host/slam_host.h) — and the run's own frame rate."""
+import importlib
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H = 620, 188
+
+
+def _rss():
+    return int(open("/proc/self/statm").read().split()[1]) * os.sysconf("SC_PAGE_SIZE")
+
+
+def test_config4_eight_streams_ten_thousand_frames(svs):
+    pl = importlib.import_module("stereovision-slam_amd.pipeline")
+    S, N, CH = 8, int(os.environ.get("SVS_LONG_FRAMES", "10000")), 500
+    seeds = [0xC0F40000 + i for i in range(S)]
+    pipe = pl.Pipeline(pl.default_config(W, H, host_threads=2), nstreams=S)
+    ctx = svs.Context.borrow(pipe.kernel_ctx(), W, H)
+    img = W * H
+    dl = ctx.dev_alloc(S * CH * img); dr = ctx.dev_alloc(S * CH * img)
+    poses = np.zeros((N, S, 7)); status = np.zeros((N, S), np.int32)
+    t_run = 0.0
+    rss_at = {}
+    for f0 in range(0, N, CH):
+        n = min(CH, N - f0)
+        svs.synth_render_streams_device(seeds, f0, CH, W, H, dl, dr)
+        t0 = time.perf_counter()
+        r = pipe.run_device(dl, dr, CH * img, img, 0, n)
+        t_run += time.perf_counter() - t0
+        poses[f0:f0 + n] = r["pose"]; status[f0:f0 + n] = r["status"]
+        rss_at[f0 + n] = _rss()
+    cnt = pipe.counters()
+    ctx.dev_free(dl); ctx.dev_free(dr)
+    pipe.close()
+    assert (status != 3).all(), "a stream was LOST at frame %d" % int(np.argmax((status == 3).any(1)))
+    assert cnt["corners_dropped"] == 0 and cnt["ba_skipped"] == 0
+    rel = []
+    for s, sd in enumerate(seeds):
+        gt = np.array([svs.synth_gt(sd, f) for f in range(N)])
+        path = float(np.linalg.norm(np.diff(pl.camera_centres(gt), axis=0), axis=1).sum())
+        rel.append(pl.ate_rmse(poses[:, s], gt) / path)
+    # host memory: the landmark store evicts what nothing can reach (16 B of archive per landmark stay for
+    # landmarks.pcd): growth per frame per stream between frame 1000 and the end
+    first = min(k for k in rss_at if k >= min(1000, N // 2))
+    growth = (rss_at[N] - rss_at[first]) / max(1, (N - first) * S)
+    fps = N * S / t_run
+    line = {"streams": S, "frames_per_stream": N, "frames_per_s": round(fps, 1), "ms_per_frame_per_stream": round(1e3 * t_run / N, 4),
+            "keyframes": int(cnt["keyframes"]), "ba_calls": int(cnt["ba_calls"]),
+            "ate_over_path_pct_mean": round(100 * float(np.mean(rel)), 4), "ate_over_path_pct_max": round(100 * float(np.max(rel)), 4),
+            "rss_growth_bytes_per_frame_per_stream": round(growth, 1), "rss_mb_end": round(rss_at[N] / 1e6, 1)}
+    print("config4 long run:", json.dumps(line))
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "r3_config4_long_run.json"), "w") as f:
+            f.write(json.dumps(line) + "\n")
+    # drift of a stereo VO without loop closure over ~8.5 km (r1: 0.06-0.21 % over 1.3 km, 0.3 % over 2.6 km)
+    assert max(rel) <= 0.003, rel
+    assert growth <= 500.0, growth
