@@ -122,6 +122,15 @@ def main():
                     help="untimed steps before the warm-up so that the timed region is the steady state (every stream's "
                          "active window holds num_active_keyframes keyframes); -1 = automatic: blocks of warmup+steps "
                          "frames until the local-BA problems of a block average a full window; 0 = none")
+    ap.add_argument("--spread-windows", type=int, default=5,
+                    help="further windows of --steps steps timed after the reported one in the same process (each behind "
+                         "its own untimed render + barrier): the line carries their values as value_spread (0 = none)")
+    ap.add_argument("--host-input-steps", type=int, default=10,
+                    help="steps of an extra leg that reads the frames from PINNED HOST memory (the pyramid kernel pulls "
+                         "them over PCIe, no staging copy): value_host_input, the rate a host-buffer boundary gets (0 = skip)")
+    ap.add_argument("--solo-steps", type=int, default=6,
+                    help="steps of an extra leg in which ONE group runs alone on the GPU: every kernel of its chain then "
+                         "has the chip to itself, so the HIP-event durations are solo durations (roofline_solo; 0 = skip)")
     ap.add_argument("--full-res", action="store_true",
                     help="keep the frames in HBM at the camera's 1241x376 and fuse the reference's 1/2 "
                          "decimation (Dataset::NextFrame) into the pyramid's level 0 (SURVEY 8 row f3); 4x the "
@@ -204,23 +213,27 @@ def main():
 
     import threading
 
-    def run_all(first, nframes, want):
+    def run_all(first, nframes, want, lbase=None, rbase=None, fb=None, groups=None):
         """every group advances its streams by nframes steps; groups run concurrently (ctypes
-        releases the GIL inside the C++ loop), each on its own HIP stream"""
+        releases the GIL inside the C++ loop), each on its own HIP stream.  lbase / rbase / fb: another frame
+        store laid out [stream][fb][img] (the pinned host ring of the host-input leg); groups: a subset"""
         outs = [None] * G
         errs = []
+        lb = d_left if lbase is None else lbase
+        rb = d_right if rbase is None else rbase
+        fbn = FB if fb is None else fb
 
         def work(g):
             try:
                 import ctypes
                 ctypes.CDLL(None).prctl(15, b"svs-group", 0, 0, 0)      # PR_SET_NAME, for the CPU breakdown
-                base = g * Sg * FB * img
-                outs[g] = pipes[g].run_device(d_left + base, d_right + base, FB * img, img, first, nframes,
+                base = g * Sg * fbn * img
+                outs[g] = pipes[g].run_device(lb + base, rb + base, fbn * img, img, first, nframes,
                                               want_results=want)
                 pipes[g].flush()     # a backend optimisation still in flight completes inside the timed region
             except Exception as e:   # noqa: BLE001
                 errs.append(e)
-        th = [threading.Thread(target=work, args=(g,)) for g in range(G)]
+        th = [threading.Thread(target=work, args=(g,)) for g in (range(G) if groups is None else groups)]
         for t_ in th:
             t_.start()
         for t_ in th:
@@ -286,6 +299,79 @@ def main():
     for f in svs.FAMILIES:
         parts = [c.timing_get(f) for c in ctxs]
         fam_t[f] = (sum(p[0] for p in parts), sum(p[1] for p in parts), sum(p[2] for p in parts))
+    for c in ctxs:
+        c.timing(False)
+    frame_pos = pre + Wm + K                      # next frame of every stream
+
+    # ---- value_spread: further windows of K steps, same process, same operating point (the 0.6-s
+    #      window of the driver's 20 steps scatters by +-10 % from run to run; here is the scatter inside one run)
+    spread = []
+    for _ in range(max(0, args.spread_windows)):
+        render_block(frame_pos)
+        barrier()
+        ts0 = time.perf_counter()
+        run_all(0, K, False)
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        ts1 = time.perf_counter()
+        barrier()
+        spread.append(S * K * world / rk.max_over_ranks(ts1 - ts0))
+        frame_pos += K
+
+    # ---- value_host_input: the same step with the frames in pinned host memory (what a host-buffer boundary
+    #      hands over): k_pyr_fused reads them across PCIe itself, nothing is staged or copied by the CPU
+    host_input = None
+    Kh = max(0, min(args.host_input_steps, FB))
+    if Kh > 0:
+        try:
+            svs.synth_render_streams_device(seeds, frame_pos, Kh, SW, SH, d_left, d_right, device=local_rank, cam=cam_r)
+            hl = torch.empty(S * Kh * img, dtype=torch.uint8, pin_memory=True)
+            hr = torch.empty(S * Kh * img, dtype=torch.uint8, pin_memory=True)
+            ctx.L.svslam_dev_download(ctx.h, _vp(hl.data_ptr()), _vp(d_left), S * Kh * img)
+            ctx.L.svslam_dev_download(ctx.h, _vp(hr.data_ptr()), _vp(d_right), S * Kh * img)
+            barrier()
+            th0 = time.perf_counter()
+            run_all(0, Kh, False, lbase=hl.data_ptr(), rbase=hr.data_ptr(), fb=Kh)
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            th1 = time.perf_counter()
+            barrier()
+            eh = rk.max_over_ranks(th1 - th0)
+            host_input = {"value": round(S * Kh * world / eh, 2), "unit": "frames/s", "steps": Kh,
+                          "ms_per_step": round(1e3 * eh / Kh, 4),
+                          "pcie_gbs": round(2 * S * Kh * img / eh / 1e9, 2),
+                          "how": "frames in pinned host memory (torch pin_memory), read by k_pyr_fused over PCIe; "
+                                 "no CPU staging copy; same streams, same operating point, directly after the timed region"}
+            frame_pos += Kh
+            del hl, hr
+        except Exception as e:   # noqa: BLE001
+            host_input = {"error": repr(e)[:300]}
+
+    # ---- roofline_solo: group 0 alone on the GPU, so each kernel of its chain runs by itself
+    solo = {}
+    Ks = max(0, min(args.solo_steps, FB))
+    if Ks > 0 and host_input is not None and "error" not in host_input or Ks > 0 and Kh == 0:
+        render_block(frame_pos)
+        cs0 = pipes[0].counters()
+        ctxs[0].timing(True)
+        if args.backend_mode == 2:
+            ctxs[G].timing(True)
+        run_all(0, Ks, False, groups=[0])
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        cs1 = pipes[0].counters()
+        cnt_s = {k: cs1[k] - cs0[k] for k in cs1}
+        for f in svs.FAMILIES:
+            parts = [ctxs[0].timing_get(f)] + ([ctxs[G].timing_get(f)] if args.backend_mode == 2 else [])
+            fms, fl = sum(p[0] for p in parts), sum(p[1] for p in parts)
+            fb_ = algorithmic_bytes(f, cnt_s, fl)
+            if fl and fms > 0:
+                solo[f] = {"achieved": round(fb_ / (fms / 1e3) / 1e9, 2), "frac": round(fb_ / (fms / 1e3) / 1e9 / HBM_PEAK_GBS, 6),
+                           "avg_launch_us": round(1e3 * fms / fl, 2), "launches": fl,
+                           "algorithmic_bytes_per_launch": round(fb_ / fl, 1)}
+        solo["_how"] = ("one group of %d streams runs %d steps alone after the timed region: its kernels are launched back "
+                        "to back on one HIP stream, so every launch has the whole chip (no co-resident kernels of other "
+                        "groups); same accounting as roofline_by_family" % (Sg, Ks))
     res = np.concatenate(res_g, axis=1)
     import ctypes as _C
     hostns = np.zeros(8)
@@ -356,6 +442,13 @@ def main():
             # family's duration is its own HIP-event time, not a share of the wall clock), and the
             # whole step: all algorithmic bytes of the timed region over its wall time
             "roofline_by_family": by_fam,
+            "roofline_solo": solo,
+            "value_spread": {"windows": [round(v, 1) for v in spread], "steps_each": K,
+                             "min": round(min(spread), 1) if spread else None, "max": round(max(spread), 1) if spread else None,
+                             "mean": round(float(np.mean(spread)), 1) if spread else None,
+                             "rel_std": round(float(np.std(spread) / np.mean(spread)), 4) if spread else None,
+                             "how": "further windows of the same length timed in the same process after the reported one"},
+            "value_host_input": host_input,
             "roofline_whole_step": {"achieved": round(all_bytes * world / elapsed / 1e9, 2), "unit": "GB/s (all ranks)",
                                     "frac_of_peak_per_gpu": round(all_bytes / elapsed / 1e9 / HBM_PEAK_GBS, 6),
                                     "algorithmic_bytes_per_frame": round(all_bytes / max(cnt["frames"], 1), 1)},
@@ -385,6 +478,11 @@ def main():
     for p in pipes:
         p.close()
     rk.close()
+
+
+def _vp(v):
+    import ctypes
+    return ctypes.c_void_p(int(v))
 
 
 def cpu_baseline(svs, pl, ctx, cfg, seeds, preroll, timed_frames, device, cam_r, src, cores):

@@ -235,6 +235,18 @@ int svslam_sba_open(svslam_ctx *ctx, const double cam_l[4], const double ext_l[7
                     const uint8_t *obs_is_right, const float *obs_uv, double huber_delta);
 int svslam_sba_phase(svslam_ctx *ctx, int phase, double lambda, double *io);
 int svslam_sba_close(svslam_ctx *ctx, double *poses, double *pts, double *edge_chi2);
+/* The same optimisation as ONE call: the LM control flow runs inside the library, the reduced camera system is
+ * all-reduced in place on the device buffer with RCCL (ncclAllReduce on the context's stream; librccl.so is bound
+ * with dlopen at the first svslam_sba_comm_* call, nothing links it otherwise), two launches and one 64-byte
+ * read-back per LM trial.  Communicator: rank 0 creates the 128-byte id, every rank receives it over any channel
+ * and calls svslam_sba_comm_init; without a communicator svslam_sba_solve runs the single-rank problem.
+ * trace (optional): 6 doubles per LM trial as svslam_lm_trace.  stats (optional, 4 doubles): trials, total ms,
+ * ms per trial, bytes all-reduced per trial.                                                                 */
+int svslam_sba_comm_unique_id(char out128[128]);
+int svslam_sba_comm_init(svslam_ctx *ctx, int nranks, int rank, const char id128[128]);
+int svslam_sba_comm_destroy(svslam_ctx *ctx);
+int svslam_sba_solve(svslam_ctx *ctx, int iters, int *iters_done, double *lambda_out, double *trace, int trace_cap,
+                     int *n_trace, double *stats);
 
 /* test hook: accumulated per-phase ticks (wall_clock64, 100 MHz) of BA job 0;
  * out12[11] = LM trials.  enable=1 allocates the counters, out12 != NULL reads

@@ -23,6 +23,7 @@ ABI_SYMBOLS = [
     "svslam_pose_only_batch", "svslam_local_ba_batch", "svslam_local_ba_submit", "svslam_local_ba_collect",
     "svslam_track_batch", "svslam_rtrack_batch", "svslam_rtrack_upload",
     "svslam_sba_io_doubles", "svslam_sba_open", "svslam_sba_phase", "svslam_sba_close",
+    "svslam_sba_comm_unique_id", "svslam_sba_comm_init", "svslam_sba_comm_destroy", "svslam_sba_solve",
     "svslam_dev_alloc", "svslam_dev_free", "svslam_dev_upload", "svslam_dev_download", "svslam_sync",
     "svslam_timing_enable", "svslam_timing_reset", "svslam_timing_get", "svslam_ba_profile",
     "svslam_set_host_threads", "svslam_debug_host_ns", "svslam_debug_clock_mhz", "svslam_lm_trace",
@@ -391,6 +392,24 @@ class Context:
         self._chk(self.L.svslam_sba_phase(self.h, phase, C.c_double(lam), _p(io)), "sba_phase")
         return io
 
+    def sba_comm_init(self, nranks, rank, id128):
+        """RCCL communicator of this context's rank for svslam_sba_solve (id128: sba_comm_unique_id() of rank 0)"""
+        buf = (C.c_char * 128).from_buffer_copy(bytes(id128))
+        self._chk(self.L.svslam_sba_comm_init(self.h, nranks, rank, buf), "sba_comm_init")
+
+    def sba_comm_destroy(self):
+        self._chk(self.L.svslam_sba_comm_destroy(self.h), "sba_comm_destroy")
+
+    def sba_solve(self, iters=10):
+        """the LM loop of the open shard inside the library (svslam_sba_solve): returns (iterations, lambda,
+        trace[ntrials, 6], stats dict)"""
+        it = C.c_int(0); lam = C.c_double(0); nt = C.c_int(0)
+        cap = 10 * max(iters, 1) + 2
+        tr = np.zeros((cap, 6)); st = np.zeros(4)
+        self._chk(self.L.svslam_sba_solve(self.h, iters, C.byref(it), C.byref(lam), _p(tr), cap, C.byref(nt), _p(st)), "sba_solve")
+        return it.value, lam.value, tr[:nt.value].copy(), dict(trials=int(st[0]), ms=float(st[1]), ms_per_trial=float(st[2]),
+                                                                 allreduce_bytes_per_trial=int(st[3]))
+
     def sba_close(self):
         nkf, nlm, nobs = self._sba
         poses = np.zeros((nkf, 7)); pts = np.zeros((nlm, 3)); chi2 = np.zeros(max(nobs, 1))
@@ -475,6 +494,14 @@ class SynthView(C.Structure):
 KITTI00_HALF_CAM = (718.856 * 0.5, 718.856 * 0.5, 607.1928 * 0.5, 185.2157 * 0.5)
 KITTI00_BASELINE = 0.537166
 _synth = None
+
+
+def sba_comm_unique_id():
+    """the 128-byte RCCL id rank 0 hands to every rank (svslam_sba_comm_unique_id)"""
+    buf = (C.c_char * 128)()
+    if load().svslam_sba_comm_unique_id(buf) != 0:
+        raise RuntimeError("svslam_sba_comm_unique_id failed (librccl.so missing?)")
+    return bytes(buf.raw)
 
 
 def synth_lib():

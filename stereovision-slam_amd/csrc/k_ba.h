@@ -379,6 +379,14 @@ __device__ __forceinline__ void st_block18(double *p, const double *o)
     for (int t = 0; t < 9; ++t) q[t] = make_double2(o[2 * t], o[2 * t + 1]);
 }
 
+// The LM loop nest of k_local_ba_t<0> keeps every phase of a trial inside two loops; the compiler hoists the per-thread
+// address arithmetic of all phases (row / lane indices, pointers into part, PTab, the record arrays ...) out of the
+// nest and then spills it: 165 VGPRs of scratch, and every reload is followed by s_waitcnt vmcnt(0), which also
+// drains the global loads in flight.  Each phase therefore derives its thread index from an opaque copy: nothing
+// computed from it can be hoisted, live ranges end with the phase.
+__device__ __forceinline__ int ba_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+#define BA_PHASE_TID const int tid = ba_opaque(tid0), lane = tid & 63, wv = tid >> 6; (void)lane; (void)wv
+
 // optional cycle profile of job 0 (thread 0): index = phase
 #define BA_PROF_N 12
 #define BA_PROF(i) do { if (prof && tid == 0) { long long t_ = wall_clock64(); prof[i] += t_ - tprev; tprev = t_; } } while (0)
@@ -542,7 +550,8 @@ __device__ __forceinline__ void ba_schur_task(int a, int b2, int rg, int c0, int
 //   phase 4  reject: restore the backup      phase 5  finalise: per-edge chi2, positions in caller numbering
 // io layout per job (doubles): S[np*np] | bs[np] | bp[np] | hdiag[np] | scalars[8]
 //   scalars: 0 chi2, 1 landmark diagonal max, 2 cholesky ok, 3 scale (landmarks), 4 scale (poses), 5 chi2 of the trial
-struct SbaArgs { int phase, first; double lambda; double *io; double *trace; };   // trace: svslam_lm_trace test hook (MODE 0)
+struct SbaArgs { int phase, first; double lambda; double *io; double *trace; int add_lambda; };   // trace: svslam_lm_trace test hook (MODE 0);
+                                                                   // add_lambda: phase 3 adds lambda I to the reduced system itself (svslam_sba_solve)
 #define SBA_IO_DOUBLES(np) ((size_t)(np) * (np) + 3 * (size_t)(np) + 8)
 
 template <int MODE>
@@ -554,7 +563,8 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int job = blockIdx.x;
     BaDev &jd = jobs[job];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid0 = threadIdx.x;
+    const int tid = tid0, lane = tid & 63, wv = tid >> 6;
     const int nkf = jd.nkf, nlm = jd.nlm, nobs = jd.nobs, na = jd.na, np = 6 * jd.na, nblk = jd.nblk;
     if (nobs <= 0 || na <= 0) { if (tid == 0) jd.iters_done = 0; return; }
     long long *prof = (prof_all && job == 0) ? prof_all : nullptr;
@@ -600,11 +610,19 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
     double *pts_b = wk.pts_b + J * 3 * wk.max_lm;
     double *pts = wk.pts_i + J * 3 * wk.max_lm;            // internal numbering (see BaHostStruct::build)
     const int *lm_orig = aux + AL.lm_orig;
+    // The state is double-buffered (MODE 0): an LM trial writes its poses / positions into the `trial` buffers, an
+    // accepted trial swaps the roles, a rejected one costs nothing — no backup copy per trial (round 2: 41 KB of
+    // positions copied, and copied back on rejection).  MODE 1 spans launches, so it updates in place and keeps the
+    // backup copies (cur == trial).
+    double *cur = pts, *trial = MODE == 0 ? pts_b : pts;
+    double *pcur = poses, *ptrial = MODE == 0 ? poses_b : poses;
     if (MODE == 0 || sba.first)
         for (int j = tid; j < nlm; j += BA_THREADS) {
             const double *s3 = pts_io + 3 * (size_t)lm_orig[j];
             pts[3 * (size_t)j] = s3[0]; pts[3 * (size_t)j + 1] = s3[1]; pts[3 * (size_t)j + 2] = s3[2];
+            if (MODE == 0) { pts_b[3 * (size_t)j] = s3[0]; pts_b[3 * (size_t)j + 1] = s3[1]; pts_b[3 * (size_t)j + 2] = s3[2]; }   // edge-less landmarks never move
         }
+    if (MODE == 0) for (int i = tid; i < 7 * nkf; i += BA_THREADS) poses_b[i] = poses[i];   // keyframes without edges never move
     double *sio = MODE == 1 ? sba.io + (size_t)job * SBA_IO_DOUBLES(np) : nullptr;
     double *sio_S = sio, *sio_bs = sio + (size_t)np * np, *sio_bp = sio_bs + np, *sio_hd = sio_bp + np, *sio_sc = sio_hd + np;
 
@@ -615,36 +633,48 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
         CT[9] = cams.ext[tid][4]; CT[10] = cams.ext[tid][5]; CT[11] = cams.ext[tid][6];
         CT[12] = cams.cam[tid][0]; CT[13] = cams.cam[tid][1]; CT[14] = cams.cam[tid][2]; CT[15] = cams.cam[tid][3];
     }
-    auto pose_table_into = [&](double *tab) {
+    auto pose_table_into = [&](double *tab, const double *src) {
+        BA_PHASE_TID;
         __syncthreads();
         if (tid < na) {
-            const double *T = poses + 7 * act_kf[tid];
+            const double *T = src + 7 * act_kf[tid];
             double *PT = tab + BA_PT * tid;
             d_quat_to_R(T, PT);
             PT[9] = T[4]; PT[10] = T[5]; PT[11] = T[6];
         }
         __syncthreads();
     };
-    auto pose_table = [&]() { pose_table_into(PTab); };
+    auto pose_table = [&]() { pose_table_into(PTab, pcur); };
 
     // errors at the current state: thread per edge in landmark-major order (coalesced records,
     // near-coalesced landmark reads, poses from the LDS table)
     // (evaluated through the SECOND pose table: the first keeps the linearisation point of the iteration, which is
     // also where the successor of a rejected trial has to linearise)
-    auto error_pass = [&]() -> double {
-        pose_table_into(PTab2);
+    auto error_pass = [&](const double *epts, const double *eposes) -> double {
+        pose_table_into(PTab2, eposes);
+        BA_PHASE_TID;
         double chi = 0;
+        // two dependent global loads per edge (record -> landmark position) and eight edges per thread: the loop is
+        // software-pipelined — the record two edges ahead and the position one edge ahead are in flight while an
+        // edge is evaluated (with two waves per SIMD there is no other latency hiding; this phase and the pose pass
+        // were bound by 16 serialised memory latencies per thread)
+        // (prefetch indices are clamped, not predicated: a predicated 16-byte load compiles to a branch per dword)
+        BaRec rc = recL[min(tid, nobs - 1)];
+        BaRec rn = recL[min(tid + BA_THREADS, nobs - 1)];
+        double X[3];
+        { const double *Xp = epts + 3 * (size_t)(rc.lmkc & BA_LM_MASK); X[0] = Xp[0]; X[1] = Xp[1]; X[2] = Xp[2]; }
         for (int i = tid; i < nobs; i += BA_THREADS) {
-            const BaRec rc = recL[i];
+            const BaRec rnn = recL[min(i + 2 * BA_THREADS, nobs - 1)];
+            const double *Xq = epts + 3 * (size_t)(rn.lmkc & BA_LM_MASK);
+            const double Xn[3] = { Xq[0], Xq[1], Xq[2] };
             const int kc = (unsigned)rc.lmkc >> 24;
-            const double *Xp = pts + 3 * (size_t)(rc.lmkc & BA_LM_MASK);
-            const double X[3] = { Xp[0], Xp[1], Xp[2] };
             BaProj o;
             ba_project(PTab2 + BA_PT * (kc >> 1), CTab + BA_CT * (kc & 1), X, rc.u, rc.v, o);
             err[2 * i] = o.ex; err[2 * i + 1] = o.ey;
             double r0, r1;
             d_huber(o.ex * o.ex + o.ey * o.ey, delta, r0, r1);
             chi += r0;
+            rc = rn; rn = rnn; X[0] = Xn[0]; X[1] = Xn[1]; X[2] = Xn[2];
         }
         return block_sum(chi, red, tid);
     };
@@ -666,6 +696,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
         // ---- pose pass: Hpp (block diagonal), bp -> LDS.  16-lane rows; pose a is shared by
         // the rows a, a + na, a + 2 na ... (< BA_ROWS), partial sums combined in row order
         if (lin) {
+            BA_PHASE_TID;
             const int row = tid >> 4, rl = tid & 15;
             const int rpp = BA_ROWS / na;                 // rows per pose (>= 1: na <= 32)
             double acc[27];
@@ -674,11 +705,16 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
             const int a = row % na, sub = row / na;
             if (sub < rpp) {
                 const int k = act_kf[a];
-                for (int i = kf_estart[k] + sub * 16 + rl; i < kf_estart[k + 1]; i += 16 * rpp) {
-                    const BaRec rc = recP[i];
+                const int i0 = kf_estart[k] + sub * 16 + rl, i1 = kf_estart[k + 1], ist = 16 * rpp;
+                BaRec rc = recP[min(i0, nobs - 1)];            // software pipeline as in the error pass
+                BaRec rn = recP[min(i0 + ist, nobs - 1)];
+                double X[3];
+                { const double *Xp = cur + 3 * (size_t)(rc.lmkc & BA_LM_MASK); X[0] = Xp[0]; X[1] = Xp[1]; X[2] = Xp[2]; }
+                for (int i = i0; i < i1; i += ist) {
+                    const BaRec rnn = recP[min(i + 2 * ist, nobs - 1)];
+                    const double *Xq = cur + 3 * (size_t)(rn.lmkc & BA_LM_MASK);
+                    const double Xn[3] = { Xq[0], Xq[1], Xq[2] };
                     const int kc = (unsigned)rc.lmkc >> 24;
-                    const double *Xp = pts + 3 * (size_t)(rc.lmkc & BA_LM_MASK);
-                    const double X[3] = { Xp[0], Xp[1], Xp[2] };
                     const double *CT = CTab + BA_CT * (kc & 1);
                     BaProj o;
                     ba_project(PTab + BA_PT * a, CT, X, rc.u, rc.v, o);
@@ -694,6 +730,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                         for (int c = r; c < 6; ++c) { acc[t] += w0 * jp[c] + w1 * jp[6 + c]; ++t; }
                         acc[21 + r] -= w0 * o.ex + w1 * o.ey;
                     }
+                    rc = rn; rn = rnn; X[0] = Xn[0]; X[1] = Xn[1]; X[2] = Xn[2];
                 }
             }
 #pragma unroll
@@ -718,12 +755,13 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
         __syncthreads();
         BA_PROF(1);
         if (it == 0 && (MODE == 0 || sba.phase == 1)) {
+            BA_PHASE_TID;
             // lambda_0 = 1e-5 * max diagonal of the Hessian: the landmark diagonals need one cheap sweep
             double md = 0;
             if (MODE == 0) for (int i = tid; i < np; i += BA_THREADS) md = fmax(md, fabs(Hpp[36 * (i / 6) + (i % 6) * 7]));
             else for (int i = tid; i < np; i += BA_THREADS) sio_hd[i] = Hpp[36 * (i / 6) + (i % 6) * 7];   // summed over the ranks first
             for (int j = tid; j < nlm; j += BA_THREADS) {
-                const double X[3] = { pts[3 * (size_t)j], pts[3 * (size_t)j + 1], pts[3 * (size_t)j + 2] };
+                const double X[3] = { cur[3 * (size_t)j], cur[3 * (size_t)j + 1], cur[3 * (size_t)j + 2] };
                 double h0 = 0, h3 = 0, h5 = 0;
                 for (int i = lm_estart[j]; i < lm_estart[j + 1]; ++i) {
                     const BaRec rc = recL[i];
@@ -746,8 +784,11 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
         do {
             // backup, S = blockdiag(Hpp) + lambda I, bs = bp
             if (lin) {
-            for (int i = tid; i < 7 * nkf; i += BA_THREADS) poses_b[i] = poses[i];
-            for (int i = tid; i < 3 * nlm; i += BA_THREADS) pts_b[i] = pts[i];
+            BA_PHASE_TID;
+            if (MODE == 1) {
+                for (int i = tid; i < 7 * nkf; i += BA_THREADS) poses_b[i] = poses[i];
+                for (int i = tid; i < 3 * nlm; i += BA_THREADS) pts_b[i] = pts[i];
+            }
             for (int r = wv; r < np; r += BA_WAVES)
                 for (int c = lane; c < np; c += 64) {
                     double v = 0;
@@ -766,6 +807,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
             // accumulators; the rows are dealt over the poses like the pose pass, row totals by the butterfly,
             // the rows of a pose added in row order.
             if (lin && jd.nmv < nlm) {
+                BA_PHASE_TID;
                 const int row = tid >> 4, rl = tid & 15;
                 const int rpp = BA_ROWS / na, a = row % na, sub = row / na;
                 double acc[32];
@@ -774,13 +816,20 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                 if (sub < rpp) {
                     const int k = act_kf[a];
                     const double *PT = PTab + BA_PT * a;
-                    for (int j = sv_start[k] + sub * 16 + rl; j < sv_start[k + 1]; j += 16 * rpp) {
-                        const double X[3] = { pts[3 * (size_t)j], pts[3 * (size_t)j + 1], pts[3 * (size_t)j + 2] };
+                    const int j0 = sv_start[k] + sub * 16 + rl, j1 = sv_start[k + 1], jst = 16 * rpp;
+                    int e0, e1;
+                    double X[3];
+                    { const int jc = min(j0, nlm - 1); e0 = lm_estart[jc]; e1 = lm_estart[jc + 1]; X[0] = cur[3 * (size_t)jc]; X[1] = cur[3 * (size_t)jc + 1]; X[2] = cur[3 * (size_t)jc + 2]; }
+                    for (int j = j0; j < j1; j += jst) {
+                        const int jn = min(j + jst, nlm - 1);
+                        const int ne0 = lm_estart[jn], ne1 = lm_estart[jn + 1];
+                        const double Xn[3] = { cur[3 * (size_t)jn], cur[3 * (size_t)jn + 1], cur[3 * (size_t)jn + 2] };
                         double h[6] = { 0, 0, 0, 0, 0, 0 }, b3[3] = { 0, 0, 0 }, ww[18];
 #pragma unroll
                         for (int t = 0; t < 18; ++t) ww[t] = 0;
-                        for (int i = lm_estart[j]; i < lm_estart[j + 1]; ++i) {
-                            const BaRec rc = recL[i];
+                        BaRec rc = recL[min(e0, nobs - 1)];
+                        for (int i = e0; i < e1; ++i) {
+                            const BaRec rn = recL[min(i + 1, nobs - 1)];
                             const int kc = (unsigned)rc.lmkc >> 24;
                             BaLin L;
                             ba_linearize(PT, CTab + BA_CT * (kc & 1), X, rc.u, rc.v, delta, L);
@@ -797,6 +846,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                             b3[0] -= wl0 * L.ex + wl3 * L.ey; b3[1] -= wl1 * L.ex + wl4 * L.ey; b3[2] -= wl2 * L.ex + wl5 * L.ey;
                             h[0] += wl0 * L.jl[0] + wl3 * L.jl[3]; h[1] += wl0 * L.jl[1] + wl3 * L.jl[4]; h[2] += wl0 * L.jl[2] + wl3 * L.jl[5];
                             h[3] += wl1 * L.jl[1] + wl4 * L.jl[4]; h[4] += wl1 * L.jl[2] + wl4 * L.jl[5]; h[5] += wl2 * L.jl[2] + wl5 * L.jl[5];
+                            rc = rn;
                         }
                         double D[9] = { h[0] + lambda, h[1], h[2], h[1], h[3] + lambda, h[4], h[2], h[4], h[5] + lambda }, Di[9];
                         d_inv3(D, Di);
@@ -810,6 +860,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                             for (int cc = r; cc < 6; ++cc) { acc[t] += y0 * ww[cc * 3] + y1 * ww[cc * 3 + 1] + y2 * ww[cc * 3 + 2]; ++t; }
                             acc[21 + r] += y0 * b3[0] + y1 * b3[1] + y2 * b3[2];
                         }
+                        e0 = ne0; e1 = ne1; X[0] = Xn[0]; X[1] = Xn[1]; X[2] = Xn[2];
                     }
                 }
                 const int code = ba_row_sum32(acc, lane);
@@ -833,6 +884,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
             // ---- tile sweep (landmarks seen from two or more poses): linearise the tile's landmarks into LDS,
             // then fold the tile into S / bs
             for (int tl = 0; lin && tl < ntile; ++tl) {
+                BA_PHASE_TID;
                 const int l0 = tile_lm[tl], l1 = tile_lm[tl + 1], bt0 = lm_bstart[l0];
                 // the tile's pair ranges and items go to LDS too: issued here, stored after the
                 // landmark work, so their latency hides behind it (the Schur pass then never
@@ -853,7 +905,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                 for (int bq = tid; bq < nbt; bq += BA_THREADS) {
                     const int b = bt0 + bq, j = blk_lm[b];
                     const int e0 = blk_es[b], e1 = blk_es[b + 1];
-                    const double X[3] = { pts[3 * (size_t)j], pts[3 * (size_t)j + 1], pts[3 * (size_t)j + 2] };
+                    const double X[3] = { cur[3 * (size_t)j], cur[3 * (size_t)j + 1], cur[3 * (size_t)j + 2] };
                     double h[6] = { 0, 0, 0, 0, 0, 0 }, b3[3] = { 0, 0, 0 }, wacc[18];
 #pragma unroll
                     for (int t = 0; t < 18; ++t) wacc[t] = 0;
@@ -952,7 +1004,8 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                 return;
             }
             if (MODE == 1) {                                   // phase 3: the reduced system comes back
-                for (int i = tid; i < np * np; i += BA_THREADS) S[(size_t)(i / np) * ld + (i % np)] = sio_S[i];
+                for (int i = tid; i < np * np; i += BA_THREADS)
+                    S[(size_t)(i / np) * ld + (i % np)] = sio_S[i] + ((sba.add_lambda && i / np == i % np) ? sba.lambda : 0.0);
                 for (int i = tid; i < np; i += BA_THREADS) { bs[i] = sio_bs[i]; bp[i] = sio_bp[i]; }
                 __syncthreads();
             }
@@ -963,6 +1016,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
             // row solves the panel, one thread per (row, block) updates the trailing matrix.
             int ok = 1;
             {
+                BA_PHASE_TID;
                 double *rhs = S + (size_t)np * ld;        // extra row: bs on entry, y on exit
                 double *invd = xp;                         // 1 / L_kk (xp is free until the back-substitution)
                 for (int i = tid; i < np; i += BA_THREADS) rhs[i] = bs[i];
@@ -995,16 +1049,11 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                             Ld[r][c] = v * y;
                         }
                     }
-                    __syncthreads();                       // everybody has read the diagonal block
                     if (!ok) break;                        // uniform: all threads factor the same block
-                    if (tid < 6) {
-                        double v = inv[0];
-#pragma unroll
-                        for (int c = 1; c < 6; ++c) v = (tid == c) ? inv[c] : v;
-                        invd[c0 + tid] = v;
-                    }
-                    // 3. panel: one thread per row i >= c0 (rows inside the diagonal block reproduce Ld)
-                    for (int i = c0 + tid; i <= np; i += BA_THREADS) {
+                    // 3. panel: one thread per row i below the diagonal block.  (The rows of the diagonal block itself
+                    // are written after the panel barrier: until then other threads may still be reading the block, and
+                    // nothing reads its factor before the final back-substitution — one barrier per block column less.)
+                    for (int i = c0 + 6 + tid; i <= np; i += BA_THREADS) {
                         double *ri = S + (size_t)i * ld + c0;
                         double x[6];
 #pragma unroll
@@ -1016,11 +1065,24 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                             for (int m = 0; m < c; ++m) v -= x[m] * Ld[c][m];
                             x[c] = v * inv[c];
                         }
-                        const int r = i - c0;
 #pragma unroll
-                        for (int c = 0; c < 6; ++c) ri[c] = (r < 6 && c > r) ? 0.0 : x[c];
+                        for (int c = 0; c < 6; ++c) ri[c] = x[c];
                     }
                     __syncthreads();
+                    if (tid < 6) {                         // factor rows of the diagonal block, inverse pivots
+                        double *ro = S + (size_t)(c0 + tid) * ld + c0;
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) {
+                            double v = Ld[0][c];
+#pragma unroll
+                            for (int r = 1; r < 6; ++r) v = (tid == r) ? Ld[r][c] : v;
+                            ro[c] = c > tid ? 0.0 : v;
+                        }
+                        double v = inv[0];
+#pragma unroll
+                        for (int c = 1; c < 6; ++c) v = (tid == c) ? inv[c] : v;
+                        invd[c0 + tid] = v;
+                    }
                     // 4. trailing update, one thread per (row i, block column jb):
                     //    S[i][6jb + c'] -= sum_c L[i][c0 + c] * L[6jb + c'][c0 + c]   (lower triangle only)
                     const int nbm = na - kb - 1, nrows = np + 1 - (c0 + 6);
@@ -1044,10 +1106,29 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                 }
             }
             if (wv == 0) {
+                BA_PHASE_TID;
                 double *rhs = S + (size_t)np * ld;
                 double *invd = xp;
                 if (prof && tid == 0) { long long t_ = wall_clock64(); prof[7] += t_ - tprev; }
-                if (ok) {
+                if (ok && np <= 64) {
+                    // rhs holds y; back-substitution L^T x = y with the stored inverse pivots, one unknown per lane
+                    // (np <= 64: K <= 10 keyframes, the only shape the pipeline produces; the general version below
+                    // carries three 64-lane chunks through every step and cost 11.6 us of a 136-us trial).  x lives in
+                    // a register, the pivot comes over v_readlane, rows k - 1 and k - 2 of L are already requested
+                    // when step k runs: the serial chain per unknown is readlane -> multiply -> FMA.
+                    const double iv = lane < np ? invd[lane] : 0.0;
+                    double x = lane < np ? rhs[lane] : 0.0;
+                    double r0 = lane < np ? S[(size_t)(np - 1) * ld + lane] : 0.0;                  // row np - 1 of L
+                    double r1 = (np >= 2 && lane < np - 1) ? S[(size_t)(np - 2) * ld + lane] : 0.0;   // row np - 2
+                    for (int k = np - 1; k >= 0; --k) {
+                        const double r2 = (k >= 2 && lane < k - 1) ? S[(size_t)(k - 2) * ld + lane] : 0.0;
+                        const double xk = readlane_f64(x, k) * readlane_f64(iv, k);
+                        x = lane < k ? x - r0 * xk : (lane == k ? xk : x);
+                        r0 = r1; r1 = r2;
+                    }
+                    if (lane < np) xp[lane] = x;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                } else if (ok) {
                     // rhs holds y; back-substitution L^T x = y with the stored inverse pivots.  x lives in registers
                     // (lane i: x_i, x_{i+64}, x_{i+128}), the pivot comes over v_readlane, row k of L is requested one
                     // step ahead: the serial chain per unknown is readlane -> multiply -> FMA, no LDS round trip.
@@ -1061,10 +1142,10 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                     }
                     for (int k = np - 1; k >= 0; --k) {
                         const int kc = k >> 6, kl = k & 63;
-                        double cur[3], nxt[3];
+                        double crow[3], nxt[3];
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
-                            cur[c] = srow[c];
+                            crow[c] = srow[c];
                             const int i = lane + 64 * c;
                             nxt[c] = (k > 0 && i < k) ? S[(size_t)(k - 1) * ld + i] : 0.0;
                         }
@@ -1074,7 +1155,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
                             const int i = lane + 64 * c;
-                            if (i < k) xr[c] -= cur[c] * xk;
+                            if (i < k) xr[c] -= crow[c] * xk;
                             else if (i == k) xr[c] = xk;
                             srow[c] = nxt[c];
                         }
@@ -1090,14 +1171,22 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
             const int ok2 = iflag[0];
             double scale_part = 0, scale_pose_part = 0;
             if (ok2) {
+                BA_PHASE_TID;
                 // back-substitution with the Jacobians recomputed (the pose table still holds the
                 // linearisation point): dl = Dinv (bl - sum W^T dp) = -Dinv sum Jl^T w (r + Jp dp)
+                // (the next landmark's edge range and position, and the next edge record, are requested while the
+                // current ones are worked on)
+                int e0, e1;
+                double X[3];
+                { const int jc = min(tid, nlm - 1); e0 = lm_estart[jc]; e1 = lm_estart[jc + 1]; X[0] = cur[3 * (size_t)jc]; X[1] = cur[3 * (size_t)jc + 1]; X[2] = cur[3 * (size_t)jc + 2]; }
                 for (int j = tid; j < nlm; j += BA_THREADS) {
-                    if (lm_estart[j + 1] == lm_estart[j]) continue;
-                    const double X[3] = { pts[3 * (size_t)j], pts[3 * (size_t)j + 1], pts[3 * (size_t)j + 2] };
+                    const int jn = min(j + BA_THREADS, nlm - 1);
+                    const int ne0 = lm_estart[jn], ne1 = lm_estart[jn + 1];
+                    const double Xn[3] = { cur[3 * (size_t)jn], cur[3 * (size_t)jn + 1], cur[3 * (size_t)jn + 2] };
                     double h[6] = { 0, 0, 0, 0, 0, 0 }, g3[3] = { 0, 0, 0 }, b3[3] = { 0, 0, 0 };
-                    for (int i = lm_estart[j]; i < lm_estart[j + 1]; ++i) {
-                        const BaRec rc = recL[i];
+                    BaRec rc = recL[min(e0, nobs - 1)];
+                    for (int i = e0; i < e1; ++i) {
+                        const BaRec rn = recL[min(i + 1, nobs - 1)];
                         const int kc = (unsigned)rc.lmkc >> 24;
                         BaLin L;
                         ba_linearize(PTab + BA_PT * (kc >> 1), CTab + BA_CT * (kc & 1), X, rc.u, rc.v, delta, L);
@@ -1111,16 +1200,20 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                         g3[0] += wl0 * t0 + wl3 * t1; g3[1] += wl1 * t0 + wl4 * t1; g3[2] += wl2 * t0 + wl5 * t1;
                         h[0] += wl0 * L.jl[0] + wl3 * L.jl[3]; h[1] += wl0 * L.jl[1] + wl3 * L.jl[4]; h[2] += wl0 * L.jl[2] + wl3 * L.jl[5];
                         h[3] += wl1 * L.jl[1] + wl4 * L.jl[4]; h[4] += wl1 * L.jl[2] + wl4 * L.jl[5]; h[5] += wl2 * L.jl[2] + wl5 * L.jl[5];
+                        rc = rn;
                     }
-                    double D[9] = { h[0] + lambda, h[1], h[2], h[1], h[3] + lambda, h[4], h[2], h[4], h[5] + lambda }, Di[9];
-                    d_inv3(D, Di);
-                    const double c0 = b3[0] - g3[0], c1 = b3[1] - g3[1], c2 = b3[2] - g3[2];
+                    if (e1 > e0) {
+                        double D[9] = { h[0] + lambda, h[1], h[2], h[1], h[3] + lambda, h[4], h[2], h[4], h[5] + lambda }, Di[9];
+                        d_inv3(D, Di);
+                        const double c0 = b3[0] - g3[0], c1 = b3[1] - g3[1], c2 = b3[2] - g3[2];
 #pragma unroll
-                    for (int a = 0; a < 3; ++a) {
-                        const double x = Di[a * 3] * c0 + Di[a * 3 + 1] * c1 + Di[a * 3 + 2] * c2;
-                        pts[3 * j + a] += x;
-                        scale_part += x * (lambda * x + b3[a]);
+                        for (int a = 0; a < 3; ++a) {
+                            const double x = Di[a * 3] * c0 + Di[a * 3 + 1] * c1 + Di[a * 3 + 2] * c2;
+                            trial[3 * (size_t)j + a] = X[a] + x;
+                            scale_part += x * (lambda * x + b3[a]);
+                        }
                     }
+                    e0 = ne0; e1 = ne1; X[0] = Xn[0]; X[1] = Xn[1]; X[2] = Xn[2];
                 }
                 for (int a = tid; a < na; a += BA_THREADS) {
                     const int k = act_kf[a];
@@ -1133,16 +1226,17 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                         else scale_pose_part += x6[t] * (lambda * x6[t] + bp[6 * a + t]);
                     }
                     d_se3_exp(x6, dT);
-                    d_se3_mul(dT, poses + 7 * k, Tn);
+                    d_se3_mul(dT, pcur + 7 * k, Tn);
 #pragma unroll
-                    for (int t = 0; t < 7; ++t) poses[7 * k + t] = Tn[t];
+                    for (int t = 0; t < 7; ++t) ptrial[7 * k + t] = Tn[t];
                 }
             }
             double scale = block_sum(scale_part, red, tid);
             const double scale_pose = MODE == 1 ? block_sum(scale_pose_part, red, tid) : 0.0;
             __syncthreads();
             BA_PROF(5);
-            tempChi = error_pass();
+            // (a failed factorisation updates nothing: its errors are those of the unchanged state, like the oracle's)
+            tempChi = ok2 ? error_pass(trial, ptrial) : error_pass(cur, pcur);
             BA_PROF(6);
             if (MODE == 1) {                                   // the host sums the partials and runs the rho test
                 if (tid == 0) { sio_sc[2] = (double)ok2; sio_sc[3] = scale; sio_sc[4] = scale_pose; sio_sc[5] = tempChi; }
@@ -1159,11 +1253,9 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                 alpha = fmin(alpha, 2. / 3.);
                 double sf = fmax(1. / 3., alpha);
                 lambda *= sf; ni = 2; currentChi = tempChi;
+                if (ok2) { double *t_ = cur; cur = trial; trial = t_; t_ = pcur; pcur = ptrial; ptrial = t_; }   // MODE 0 only gets here
             } else {
-                lambda *= ni; ni *= 2;
-                for (int i = tid; i < 7 * nkf; i += BA_THREADS) poses[i] = poses_b[i];
-                for (int i = tid; i < 3 * nlm; i += BA_THREADS) pts[i] = pts_b[i];
-                __syncthreads();
+                lambda *= ni; ni *= 2;                     // rejected: `cur` was never touched
                 if (!isfinite(lambda)) break;
             }
             ++qmax;
@@ -1176,8 +1268,9 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
     for (int i = tid; i < nobs; i += BA_THREADS) edge_chi2[lm_edges[i]] = err[2 * i] * err[2 * i] + err[2 * i + 1] * err[2 * i + 1];
     for (int j = tid; j < nlm; j += BA_THREADS) {
         double *d3 = pts_io + 3 * (size_t)lm_orig[j];
-        d3[0] = pts[3 * (size_t)j]; d3[1] = pts[3 * (size_t)j + 1]; d3[2] = pts[3 * (size_t)j + 2];
+        d3[0] = cur[3 * (size_t)j]; d3[1] = cur[3 * (size_t)j + 1]; d3[2] = cur[3 * (size_t)j + 2];
     }
+    if (pcur != poses) for (int i = tid; i < 7 * nkf; i += BA_THREADS) poses[i] = pcur[i];
     if (tid == 0) jd.iters_done = it_done;
 }
 

@@ -16,6 +16,8 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>          // types only: the library is bound with dlopen when a shared-map communicator is asked for
 #include "../../include/svslam.h"
 #include "../host/thread_pool.h"
 #include <atomic>
@@ -94,6 +96,8 @@ struct svslam_ctx {
     // an open shared-map BA problem (svslam_sba_*): this rank's shard lives in the arena like a submitted batch
     struct { bool open = false; int nkf = 0, nlm = 0, nobs = 0, np = 0; size_t ojobs = 0, ocams = 0, oposes = 0, opts = 0, orecs = 0,
              oaux = 0, ochi = 0, oio = 0; double delta = 0; int launches = 0; } sba;
+    // shared-map BA over RCCL (svslam_sba_comm_* / svslam_sba_solve): communicator of this context's rank
+    struct { ncclComm_t comm = nullptr; int nranks = 1, rank = 0; } sbac;
     // timing
     bool timing = false;
     Timing tm;
@@ -505,6 +509,7 @@ void svslam_destroy(svslam_ctx *c)
     ba_work_free(c->bw);
     if (c->d_ba_prof) (void)hipFree(c->d_ba_prof);
     if (c->d_lm_trace) (void)hipFree(c->d_lm_trace);
+    (void)svslam_sba_comm_destroy(c);
     for (int i = 0; i < 16; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->done) (void)hipEventDestroy(c->done);   // the stream belongs to the pool
     delete c;
@@ -992,7 +997,7 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
     hipLaunchKernelGGL(k_local_ba_t<0>, dim3(njobs), dim3(BA_THREADS), ba_lds_bytes(c->lim.max_kf), c->stream,
                        dp<BaDev>(c, ojobs), dp<BaCams>(c, ocams), dp<double>(c, oposes), dp<double>(c, opts),
                        dp<BaRec>(c, orecs), dp<int>(c, oaux), c->bw, huber_delta, iters, dp<double>(c, ochi), c->d_ba_prof,
-                       tile_cap, SbaArgs{ 0, 0, 0.0, nullptr, c->d_lm_trace });
+                       tile_cap, SbaArgs{ 0, 0, 0.0, nullptr, c->d_lm_trace, 0 });
     tm_end(c);
     HIPCHK(c, hipGetLastError());
     c->ba_pending.oflag = oflag;
@@ -1105,14 +1110,9 @@ int svslam_sba_open(svslam_ctx *c, const double cam_l[4], const double ext_l[7],
 
 // phase: 1 diagonal (lambda_0), 2 linearise at lambda, 3 solve with the reduced system in io + update + errors,
 //        4 reject (restore), 5 finalise.  io: svslam_sba_io_doubles(nkf) doubles, in for phase 3, out for 1-3.
-int svslam_sba_phase(svslam_ctx *c, int phase, double lambda, double *io)
+static int sba_launch(svslam_ctx *c, int phase, double lambda, int add_lambda)
 {
-    if (!c->sba.open) return fail(c, "sba_phase: no shard is open");
-    if (phase < 1 || phase > 5) return fail(c, "sba_phase: phase %d", phase);
-    const size_t nio = SBA_IO_DOUBLES(c->sba.np) * sizeof(double);
-    if (phase == 3) { memcpy(hp<void>(c, c->sba.oio), io, nio); if (h2d(c, c->sba.oio, c->sba.oio + nio)) return -1; }
-    else HIPCHK(c, hipMemsetAsync(dp<void>(c, c->sba.oio), 0, nio, c->stream));
-    SbaArgs a{ phase, c->sba.launches == 0 ? 1 : 0, lambda, dp<double>(c, c->sba.oio), nullptr };
+    SbaArgs a{ phase, c->sba.launches == 0 ? 1 : 0, lambda, dp<double>(c, c->sba.oio), nullptr, add_lambda };
     tm_begin(c, FAM_BA, 1);
     hipLaunchKernelGGL(k_local_ba_t<1>, dim3(1), dim3(BA_THREADS), ba_lds_bytes(c->lim.max_kf), c->stream, dp<BaDev>(c, c->sba.ojobs),
                        dp<BaCams>(c, c->sba.ocams), dp<double>(c, c->sba.oposes), dp<double>(c, c->sba.opts), dp<BaRec>(c, c->sba.orecs),
@@ -1121,8 +1121,177 @@ int svslam_sba_phase(svslam_ctx *c, int phase, double lambda, double *io)
     tm_end(c);
     HIPCHK(c, hipGetLastError());
     c->sba.launches++;
+    return 0;
+}
+
+int svslam_sba_phase(svslam_ctx *c, int phase, double lambda, double *io)
+{
+    if (!c->sba.open) return fail(c, "sba_phase: no shard is open");
+    if (phase < 1 || phase > 5) return fail(c, "sba_phase: phase %d", phase);
+    const size_t nio = SBA_IO_DOUBLES(c->sba.np) * sizeof(double);
+    if (phase == 3) { memcpy(hp<void>(c, c->sba.oio), io, nio); if (h2d(c, c->sba.oio, c->sba.oio + nio)) return -1; }
+    else HIPCHK(c, hipMemsetAsync(dp<void>(c, c->sba.oio), 0, nio, c->stream));
+    if (sba_launch(c, phase, lambda, 0)) return -1;
     if (d2h_sync(c, c->sba.oio, c->sba.oio + nio)) return -1;
     if (io && phase <= 3) memcpy(io, hp<void>(c, c->sba.oio), nio);
+    return 0;
+}
+
+// ---- the shared-map LM as a product path: the control flow of g2o's Levenberg-Marquardt (exactly the loop of
+// k_local_ba_t<0> / shared_ba.py) in the library, the reduced camera system all-reduced IN PLACE on the device buffer
+// by RCCL (ncclAllReduce on the context's stream: (6K)^2 + 3 (6K) + 1 doubles per trial, 3 781 at K = 10, plus two
+// scalars), no host copy of the system, two launches and one 64-byte read-back per trial.
+namespace {
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi *rccl_api(std::string *why)
+{
+    static RcclApi api;
+    static std::once_flag once;
+    static std::string err;
+    std::call_once(once, [] {
+        for (const char *n : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
+            api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (api.lib) break;
+        }
+        if (!api.lib) { err = std::string("librccl.so not found: ") + dlerror(); return; }
+#define SVS_RCCL_SYM(field, name) api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.lib, name)); if (!api.field) err = std::string("missing RCCL symbol ") + name
+        SVS_RCCL_SYM(GetUniqueId, "ncclGetUniqueId"); SVS_RCCL_SYM(CommInitRank, "ncclCommInitRank");
+        SVS_RCCL_SYM(CommDestroy, "ncclCommDestroy"); SVS_RCCL_SYM(AllReduce, "ncclAllReduce");
+        SVS_RCCL_SYM(GroupStart, "ncclGroupStart"); SVS_RCCL_SYM(GroupEnd, "ncclGroupEnd");
+        SVS_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef SVS_RCCL_SYM
+    });
+    if (!err.empty()) { if (why) *why = err; return nullptr; }
+    return &api;
+}
+} // namespace
+
+// 128 bytes that rank 0 creates and hands to every rank (over any channel: torch.distributed, MPI, a file)
+int svslam_sba_comm_unique_id(char out128[128])
+{
+    std::string why;
+    RcclApi *r = rccl_api(&why);
+    if (!r) return -1;
+    ncclUniqueId id;
+    static_assert(sizeof(id) == 128, "ncclUniqueId");
+    if (r->GetUniqueId(&id) != ncclSuccess) return -2;
+    memcpy(out128, &id, 128);
+    return 0;
+}
+int svslam_sba_comm_init(svslam_ctx *c, int nranks, int rank, const char id128[128])
+{
+    if (c->sbac.comm) return fail(c, "sba_comm_init: the context already has a communicator");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(c, "sba_comm_init: rank %d of %d", rank, nranks);
+    std::string why;
+    RcclApi *r = rccl_api(&why);
+    if (!r) return fail(c, "sba_comm_init: %s", why.c_str());
+    HIPCHK(c, hipSetDevice(c->device));
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    const ncclResult_t rc = r->CommInitRank(&c->sbac.comm, nranks, id, rank);
+    if (rc != ncclSuccess) { c->sbac.comm = nullptr; return fail(c, "ncclCommInitRank: %s", r->GetErrorString(rc)); }
+    c->sbac.nranks = nranks; c->sbac.rank = rank;
+    return 0;
+}
+int svslam_sba_comm_destroy(svslam_ctx *c)
+{
+    if (!c->sbac.comm) return 0;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    RcclApi *r = rccl_api(nullptr);
+    if (r) (void)r->CommDestroy(c->sbac.comm);
+    c->sbac.comm = nullptr; c->sbac.nranks = 1; c->sbac.rank = 0;
+    return 0;
+}
+
+// The whole optimize(iters) of the open shard.  trace (optional): 6 doubles per LM trial as svslam_lm_trace;
+// stats (optional, 4 doubles): trials, milliseconds in total, mean milliseconds per trial, all-reduced bytes per trial.
+int svslam_sba_solve(svslam_ctx *c, int iters, int *iters_done, double *lambda_out, double *trace, int trace_cap,
+                     int *n_trace, double *stats)
+{
+    if (!c->sba.open) return fail(c, "sba_solve: no shard is open");
+    RcclApi *r = c->sbac.comm ? rccl_api(nullptr) : nullptr;
+    const int n = c->sba.np;
+    const size_t oS = 0, ohd = (size_t)n * n + 2 * (size_t)n, osc = ohd + n;
+    double *dio = dp<double>(c, c->sba.oio);
+    double *hio = hp<double>(c, c->sba.oio);
+    const size_t off_sc = c->sba.oio + osc * sizeof(double);
+    auto allreduce = [&](double *buf, size_t cnt, ncclRedOp_t op) -> int {
+        if (!r) return 0;                               // one rank, no communicator: the sums are the local values
+        const ncclResult_t rc = r->AllReduce(buf, buf, cnt, ncclDouble, op, c->sbac.comm, c->stream);
+        return rc == ncclSuccess ? 0 : fail(c, "ncclAllReduce: %s", r->GetErrorString(rc));
+    };
+    const long long t_begin = now_ns();
+    HIPCHK(c, hipMemsetAsync(dio, 0, SBA_IO_DOUBLES(n) * sizeof(double), c->stream));
+    double lam = 0, ni = 2, current = 0;
+    bool have_current = false;
+    int it_done = 0, ntr = 0, trials = 0;
+    for (int it = 0; it < iters; ++it) {
+        if (it == 0) {
+            if (sba_launch(c, 1, 0.0, 0)) return -1;
+            if (allreduce(dio + ohd, (size_t)n, ncclSum)) return -1;
+            if (allreduce(dio + osc + 1, 1, ncclMax)) return -1;
+            if (d2h_sync(c, c->sba.oio + ohd * sizeof(double), c->sba.oio + (osc + 8) * sizeof(double))) return -1;
+            double md = hio[osc + 1];
+            for (int i = 0; i < n; ++i) md = std::max(md, std::fabs(hio[ohd + i]));
+            lam = 1e-5 * md; ni = 2;
+        }
+        double rho = 0; int qmax = 0;
+        for (;;) {
+            if (sba_launch(c, 2, lam, 0)) return -1;
+            if (allreduce(dio + oS, osc + 1, ncclSum)) return -1;               // S | bs | bp | (hd) | chi2
+            if (sba_launch(c, 3, lam, 1)) return -1;                               // adds lambda I itself
+            if (r) {                                                               // landmark part of the rho denominator, chi2 of the trial
+                if (r->GroupStart() != ncclSuccess) return fail(c, "ncclGroupStart");
+                if (allreduce(dio + osc + 3, 1, ncclSum) || allreduce(dio + osc + 5, 1, ncclSum)) return -1;
+                if (r->GroupEnd() != ncclSuccess) return fail(c, "ncclGroupEnd");
+            }
+            if (d2h_sync(c, off_sc, off_sc + 8 * sizeof(double))) return -1;
+            const double *sc = hio + osc;
+            if (!have_current) { current = sc[0]; have_current = true; }
+            const bool ok = sc[2] != 0.0;
+            const double temp = ok ? sc[5] : 1.7976931348623157e308;
+            const double scale = sc[3] + sc[4] + 1e-3;
+            rho = (current - temp) / scale;
+            const bool accept = rho > 0 && std::isfinite(temp);
+            if (trace && ntr < trace_cap) {
+                double *t = trace + 6 * (size_t)ntr++;
+                t[0] = it; t[1] = lam; t[2] = current; t[3] = temp; t[4] = rho; t[5] = accept ? 1.0 : 0.0;
+            }
+            ++trials;
+            if (accept) {
+                const double t = 2 * rho - 1;
+                const double alpha = std::min(1.0 - t * t * t, 2.0 / 3.0);
+                lam *= std::max(1.0 / 3.0, alpha); ni = 2; current = temp;
+            } else {
+                lam *= ni; ni *= 2;
+                if (sba_launch(c, 4, lam, 0)) return -1;
+                if (!std::isfinite(lam)) break;
+            }
+            ++qmax;
+            if (!(rho < 0 && qmax < 10)) break;
+        }
+        ++it_done;
+        if (qmax == 10 || rho == 0 || !std::isfinite(lam)) break;
+    }
+    if (sba_launch(c, 5, lam, 0)) return -1;
+    if (d2h_sync(c, off_sc, off_sc + 8 * sizeof(double))) return -1;
+    if (iters_done) *iters_done = it_done;
+    if (lambda_out) *lambda_out = lam;
+    if (n_trace) *n_trace = ntr;
+    if (stats) {
+        const double ms = (now_ns() - t_begin) / 1e6;
+        stats[0] = trials; stats[1] = ms; stats[2] = trials ? ms / trials : 0.0;
+        stats[3] = (double)((osc + 1 + 2) * sizeof(double));
+    }
     return 0;
 }
 

@@ -39,6 +39,8 @@ typedef struct svs_pipe_counters {
     long long ba_calls, ba_edges, ba_kf, ba_lm, ba_iters, pyr_left, pyr_right;
     long long ns_step, ns_kernel_calls;
     long long corners_dropped, ba_skipped;   /* per-stream capacity events (max_pts / max_lm / max_obs) */
+    long long lm_total, lm_resident;         /* landmarks ever created / MapPoint objects the host still holds (the rest
+                                                were evicted to the 16-byte archive, Map::ReleaseRetired)              */
 } svs_pipe_counters;
 
 void *svs_pipe_create(const svs_pipe_config *cfg, int nstreams, int device);

@@ -180,7 +180,7 @@ public:
     {
         std::vector<LandmarkRecord> o;
         o.reserve(archive_.size() + slots_.size());
-        for (const ArchivedLandmark &a : archive_) o.push_back(LandmarkRecord{ a.id, { a.pos[0], a.pos[1], a.pos[2] }, 0, false });
+        for (const ArchivedLandmark &a : archive_) o.push_back(LandmarkRecord{ (long)a.id, { a.pos[0], a.pos[1], a.pos[2] }, 0, false });
         for (const MapPoint *m : slots_)
             if (m) o.push_back(LandmarkRecord{ m->id, { m->pos[0], m->pos[1], m->pos[2] }, m->observed_times, m->active });
         std::sort(o.begin(), o.end(), [](const LandmarkRecord &a, const LandmarkRecord &b) { return a.id < b.id; });
@@ -296,11 +296,11 @@ public:
     std::vector<MapPoint *> active_landmarks_;            // id-ascending
 
 private:
-    struct ArchivedLandmark { long id; float pos[3]; };
+    struct ArchivedLandmark { uint32_t id; float pos[3]; };     // 16 bytes
     void ToLimbo(MapPoint *m) { if (!m->in_limbo) { m->in_limbo = true; limbo_.push_back(m); } }
     void Evict(MapPoint *m)
     {
-        if (keep_archive_) archive_.push_back(ArchivedLandmark{ m->id, { (float)m->pos[0], (float)m->pos[1], (float)m->pos[2] } });
+        if (keep_archive_) archive_.push_back(ArchivedLandmark{ (uint32_t)m->id, { (float)m->pos[0], (float)m->pos[1], (float)m->pos[2] } });
         slots_[(size_t)(m->id - base_id_)] = nullptr;
         free_.push_back(m);
     }

@@ -67,6 +67,32 @@ def shared_map_ba(engine, rank, nkf, iters=10, trace=None):
     return it_done, lam
 
 
+def broadcast_comm_id(rank):
+    """rank 0 creates the RCCL unique id, every rank receives it over torch.distributed (whatever backend the
+    ranks were launched with); a single rank creates its own"""
+    import importlib
+    svs = importlib.import_module(__package__)
+    if rank.dist is None:
+        return svs.sba_comm_unique_id()
+    import torch
+    t = torch.zeros(128, dtype=torch.uint8)
+    if rank.rank == 0:
+        t = torch.frombuffer(bytearray(svs.sba_comm_unique_id()), dtype=torch.uint8).clone()
+    if rank.device:
+        t = t.to(rank.device)
+    rank.dist.broadcast(t, src=0)
+    return bytes(t.cpu().numpy().tobytes())
+
+
+def shared_map_ba_native(ctx, rank, iters=10):
+    """The product path: the open shard of `ctx` (Context.sba_open) optimised by svslam_sba_solve — LM control flow
+    in the library, ncclAllReduce on the device buffer.  Sets the communicator up on first use."""
+    if not getattr(ctx, "_sba_comm", False):
+        ctx.sba_comm_init(rank.world, rank.rank, broadcast_comm_id(rank))
+        ctx._sba_comm = True
+    return ctx.sba_solve(iters)
+
+
 class HipEngine:
     """this rank's shard on its GPU (Context.sba_*)"""
 

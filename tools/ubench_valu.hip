@@ -42,7 +42,33 @@ template <int KIND> __device__ __forceinline__ void step(uint32_t (&a)[CH], uint
         if (KIND == 24) asm volatile("v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[k]));
         if (KIND == 25) asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[k]));
         if (KIND == 26) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(*reinterpret_cast<double *>(&a[k & ~1])) : "v"(a[k]));
+        if (KIND == 30) asm volatile("v_pk_add_i16 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+        if (KIND == 31) asm volatile("v_pk_sub_i16 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+        if (KIND == 32) asm volatile("v_pk_mad_i16 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+        if (KIND == 33) asm volatile("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+        if (KIND == 34) asm volatile("v_pk_lshlrev_b16 %0, 1, %0" : "+v"(a[k]));
+        if (KIND == 35) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+        if (KIND == 36) asm volatile("v_mad_i16 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+        if (KIND == 37) asm volatile("v_sad_u8 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+        if (KIND == 38) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(a[k]) : "v"(b));
+        if (KIND == 39) asm volatile("v_bfe_u32 %0, %0, 8, 8" : "+v"(a[k]));
+        if (KIND == 40) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[k]) : "v"(b));
         if (KIND == 13) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(*reinterpret_cast<double *>(&a[k & ~1])) : "v"(__hiloint2double((int)b, (int)c)));
+    }
+    if (KIND == 41 || KIND == 42 || KIND == 43) {
+        double *d = reinterpret_cast<double *>(a);
+        const double one = __hiloint2double((int)(c | 0x3ff00000u), (int)b);
+#pragma unroll
+        for (int k = 0; k < CH / 2; ++k) {
+            if (KIND == 41) { asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(d[k]) : "v"(one)); asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(d[k]) : "v"(one)); }
+            if (KIND == 42) { asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d[k]) : "v"(one)); asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d[k]) : "v"(one)); }
+            if (KIND == 43) for (int rep = 0; rep < 2; ++rep) {      // what dpp_f64 + add costs: no DPP form of v_add_f64 exists
+                uint32_t lo, hi;
+                asm volatile("v_mov_b32_dpp %0, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %1, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+                             : "=&v"(lo), "=&v"(hi) : "v"(a[2 * k]), "v"(a[2 * k + 1]));
+                asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[k]) : "v"(__hiloint2double((int)hi, (int)lo)));
+            }
+        }
     }
     if (KIND == 9) {
         double *d = reinterpret_cast<double *>(a);
@@ -127,5 +153,20 @@ int main()
     run<24>("v_mov_b32 dpp", 1, d_out, d_cyc, ncu);
     run<25>("v_sqrt_f32", 1, d_out, d_cyc, ncu);
     run<26>("v_cvt_f64_f32", 1, d_out, d_cyc, ncu);
+    // round 3: packed 16-bit integer VALU, priced before k_lk's Scharr / A stage moves onto it
+    run<30>("v_pk_add_i16", 1, d_out, d_cyc, ncu);
+    run<31>("v_pk_sub_i16", 1, d_out, d_cyc, ncu);
+    run<35>("v_pk_add_u16", 1, d_out, d_cyc, ncu);
+    run<32>("v_pk_mad_i16", 1, d_out, d_cyc, ncu);
+    run<33>("v_pk_mul_lo_u16", 1, d_out, d_cyc, ncu);
+    run<34>("v_pk_lshlrev_b16", 1, d_out, d_cyc, ncu);
+    run<36>("v_mad_i16", 1, d_out, d_cyc, ncu);
+    run<37>("v_sad_u8", 1, d_out, d_cyc, ncu);
+    run<38>("v_lshl_add_u32", 1, d_out, d_cyc, ncu);
+    run<39>("v_bfe_u32", 1, d_out, d_cyc, ncu);
+    run<40>("v_cndmask_b32", 1, d_out, d_cyc, ncu);
+    run<41>("v_fma_f64", 1, d_out, d_cyc, ncu);
+    run<42>("v_mul_f64", 1, d_out, d_cyc, ncu);
+    run<43>("2 v_mov dpp + v_add_f64", 3, d_out, d_cyc, ncu);
     return 0;
 }
