@@ -47,6 +47,9 @@ typedef struct svslam_limits {
     int max_obs;       /* BA: max observations (edges) per problem             */
     int max_streams;   /* streams whose last-frame features stay resident in HBM
                           (svslam_rtrack_*); 0 = none                          */
+    int device_map;    /* 1: every resident stream also keeps its MAP in HBM (keyframe window of
+                          max_kf slots x max_pts features, max_lm landmark slots — a power of two):
+                          svslam_dmap_*                                          */
 } svslam_limits;
 
 /* ---- lifetime -------------------------------------------------------- */
@@ -242,6 +245,7 @@ int svslam_sba_close(svslam_ctx *ctx, double *poses, double *pts, double *edge_c
  * and calls svslam_sba_comm_init; without a communicator svslam_sba_solve runs the single-rank problem.
  * trace (optional): 6 doubles per LM trial as svslam_lm_trace.  stats (optional, 4 doubles): trials, total ms,
  * ms per trial, bytes all-reduced per trial.                                                                 */
+int svslam_device_count(void);      /* HIP devices visible to this process */
 int svslam_sba_comm_unique_id(char out128[128]);
 int svslam_sba_comm_init(svslam_ctx *ctx, int nranks, int rank, const char id128[128]);
 int svslam_sba_comm_destroy(svslam_ctx *ctx);
@@ -314,6 +318,49 @@ int svslam_rtrack_batch(svslam_ctx *ctx, int njobs, svslam_rtrack_job *jobs,
 int svslam_rtrack_upload(svslam_ctx *ctx, int n, const int *streams, const int *ofs,
                          const int *counts, const float *xy, const int *mp,
                          const double *xyz);
+
+/* ---- the map resident in HBM: the keyframe path without per-feature host work ------------------
+ * With limits.device_map = 1 every resident stream (svslam_rtrack_*) also keeps its keyframe window, the features
+ * of those keyframes, its landmarks and their observation counts on the device.  One call then runs everything
+ * the reference does when a frame becomes a keyframe — Map::InsertKeyFrame / RemoveOldKeyframe / CleanMap
+ * (src/map.cpp:53-181), SetObservationsForKeyFrame, DetectFeatures, FindFeaturesInRight, TriangulateNewPoints
+ * (src/frontend.cpp:36-141, 251-320, 560-616; StereoInit / BuildInitMap :143-249 with is_init), Backend::Optimize
+ * with its outlier handling and write-back (src/backend.cpp:22-246) — and leaves the keyframe's features as the
+ * list the next frame tracks from.  The host supplies what is O(window): ids, the slot of the new keyframe and
+ * the slot of the keyframe to retire (-1: none; the se3-log distance rule of RemoveOldKeyframe stays on the host),
+ * and reads counts and the window's poses back.  mp values in the resident lists are landmark SLOTS here.       */
+typedef struct svslam_dmap_job {
+    int    stream, slot_cur, slot_right, is_init;
+    int    kf_slot, remove_slot, kf_id, npts;   /* npts: features the frame has (tracked survivors); 0 at init   */
+    long long frame_id;
+    double pose[7];        /* in: T_cw (identity at init); out: after the local BA                              */
+    double T_camr_w[7];    /* cam_right.pose * T_cw (src/camera.cpp:74)                                          */
+    double T_wc[7];        /* inverse of pose (identity at init)                                                 */
+    int    src_buf, dst_buf; /* filled by the library                                                            */
+    int    stamp, reserved0;
+    /* out */
+    int    ok;             /* init: enough stereo matches (otherwise nothing was created); keyframe: 1           */
+    int    n_features, n_corners, n_right_ok, n_tri_in, n_tri_ok;
+    int    ba_nkf, ba_nlm, ba_nobs, ba_iters;
+    int    flags;          /* 1 corners dropped (max_pts), 2 landmark slots exhausted, 4 BA skipped (max_obs)    */
+    int    dead;
+    double win_pose[12][7];/* poses of the BA problem's keyframes after the solve ...                            */
+    int    win_slot[12];   /* ... and their slots                                                                */
+} svslam_dmap_job;
+
+typedef struct svslam_dmap_params {
+    int    num_features, num_features_init, num_active_keyframes, ba_iters;
+    double max_triangulation_depth, chi2_th;
+} svslam_dmap_params;
+
+int svslam_dmap_keyframe_batch(svslam_ctx *ctx, int njobs, svslam_dmap_job *jobs,
+                               const void *const *left_imgs, const void *const *right_imgs, const int *strides,
+                               int src_is_device, const double cam_l[4], const double ext_l[7],
+                               const double cam_r[4], const double ext_r[7], const svslam_dmap_params *p);
+/* test / writer hook: one stream's window (max_kf entries; kf_frame < 0 = empty slot) and landmark arena
+ * (max_lm entries; lm_id < 0 = free slot; lm_state 1 = active, 2 = outside the window)                           */
+int svslam_dmap_read(svslam_ctx *ctx, int stream, long long *kf_frame, int *kf_id, double *kf_pose, int *kf_n,
+                     int *lm_id, double *lm_pos, int *lm_obs, uint8_t *lm_state);
 
 /* host threads the library may use to prepare a batched call (per-problem BA structure
  * building); default 1.                                                        */

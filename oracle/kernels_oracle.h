@@ -151,6 +151,10 @@ public:
         }
         return 0;
     }
+    // the device-resident map is a property of the HIP provider (the twin IS the host map that checks it)
+    int dmap_keyframe(int, svslam_dmap_job *, const void *const *, const void *const *, const int *, int, const double *,
+                      const double *, const double *, const double *, const svslam_dmap_params *)
+    { err_ = "the CPU twin keeps its map on the host (device_map = 0)"; return -1; }
     int rtrack_upload(int n, const int *streams, const int *ofs, const int *counts, const float *xy, const int *mp,
                       const double *xyz)
     {

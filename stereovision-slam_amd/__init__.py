@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "svslam_pose_only_batch", "svslam_local_ba_batch", "svslam_local_ba_submit", "svslam_local_ba_collect",
     "svslam_track_batch", "svslam_rtrack_batch", "svslam_rtrack_upload",
     "svslam_sba_io_doubles", "svslam_sba_open", "svslam_sba_phase", "svslam_sba_close",
-    "svslam_sba_comm_unique_id", "svslam_sba_comm_init", "svslam_sba_comm_destroy", "svslam_sba_solve",
+    "svslam_device_count", "svslam_dmap_keyframe_batch", "svslam_dmap_read", "svslam_sba_comm_unique_id", "svslam_sba_comm_init", "svslam_sba_comm_destroy", "svslam_sba_solve",
     "svslam_dev_alloc", "svslam_dev_free", "svslam_dev_upload", "svslam_dev_download", "svslam_sync",
     "svslam_timing_enable", "svslam_timing_reset", "svslam_timing_get", "svslam_ba_profile",
     "svslam_set_host_threads", "svslam_debug_host_ns", "svslam_debug_clock_mhz", "svslam_lm_trace",
@@ -36,7 +36,7 @@ DEBUG_FAMILIES = {"dbg0": 6, "dbg1": 7, "dbg2": 8, "dbg3": 9}     # per-kernel s
 class Limits(C.Structure):
     _fields_ = [("device", C.c_int), ("width", C.c_int), ("height", C.c_int), ("max_slots", C.c_int),
                 ("max_jobs", C.c_int), ("max_pts", C.c_int), ("max_corners", C.c_int), ("max_kf", C.c_int),
-                ("max_lm", C.c_int), ("max_obs", C.c_int), ("max_streams", C.c_int)]
+                ("max_lm", C.c_int), ("max_obs", C.c_int), ("max_streams", C.c_int), ("device_map", C.c_int)]
 
 
 class RtrackJob(C.Structure):
@@ -130,10 +130,10 @@ class Context:
     """One svslam_ctx: own HIP stream, resident pyramid slots, staging arena."""
 
     def __init__(self, width, height, max_slots=4, max_jobs=1, max_pts=512, max_corners=150, max_kf=10,
-                 max_lm=2048, max_obs=8192, device=0, max_streams=0):
+                 max_lm=2048, max_obs=8192, device=0, max_streams=0, device_map=0):
         self.L = load()
         self.lim = Limits(device, width, height, max_slots, max_jobs, max_pts, max_corners, max_kf, max_lm,
-                          max_obs, max_streams)
+                          max_obs, max_streams, device_map)
         self.h = C.c_void_p()
         rc = self.L.svslam_create(C.byref(self.lim), C.byref(self.h))
         if rc != 0:
@@ -415,6 +415,15 @@ class Context:
         poses = np.zeros((nkf, 7)); pts = np.zeros((nlm, 3)); chi2 = np.zeros(max(nobs, 1))
         self._chk(self.L.svslam_sba_close(self.h, _p(poses), _p(pts), _p(chi2)), "sba_close")
         return poses, pts, chi2[:nobs]
+
+    def dmap_read(self, stream, max_kf, max_lm):
+        """test hook: one stream's device-resident window and landmark arena (svslam_dmap_read)"""
+        d = dict(kf_frame=np.zeros(max_kf, np.int64), kf_id=np.zeros(max_kf, np.int32), kf_pose=np.zeros((max_kf, 7)),
+                 kf_n=np.zeros(max_kf, np.int32), lm_id=np.zeros(max_lm, np.int32), lm_pos=np.zeros((max_lm, 3)),
+                 lm_obs=np.zeros(max_lm, np.int32), lm_state=np.zeros(max_lm, np.uint8))
+        self._chk(self.L.svslam_dmap_read(self.h, stream, _p(d["kf_frame"]), _p(d["kf_id"]), _p(d["kf_pose"]), _p(d["kf_n"]),
+                                          _p(d["lm_id"]), _p(d["lm_pos"]), _p(d["lm_obs"]), _p(d["lm_state"])), "dmap_read")
+        return d
 
     # ---- resident tracking -----------------------------------------------------
     def rtrack_upload(self, lists):

@@ -30,6 +30,7 @@
 #include "k_geom.h"
 #include "k_ba.h"
 #include "k_ba_build.h"
+#include "k_dmap.h"
 
 namespace {
 
@@ -89,6 +90,9 @@ struct svslam_ctx {
     // resident feature lists (svslam_rtrack_*): two alternating buffers per stream
     RtStore rt = {};
     std::vector<int> rt_which, rt_count;
+    DMap dm = {};                 // device-resident maps (limits.device_map)
+    void *dm_all = nullptr;
+    int dm_stamp = 0;
     hipEvent_t done = nullptr;   // recorded after the last enqueue of a call; the stream may be shared
     // a submitted, not yet collected local-BA batch owns the staging arena
     struct { bool active = false; int njobs = 0, total_kf = 0, total_lm = 0, total_obs = 0;
@@ -474,6 +478,34 @@ int svslam_create(const svslam_limits *lim, svslam_ctx **out)
         c->rt_which.assign((size_t)lim->max_streams, 0);
         c->rt_count.assign((size_t)lim->max_streams, 0);
     }
+    if (lim->device_map) {
+        if (lim->max_streams <= 0 || lim->max_kf <= 0) return fail(c, "device_map needs max_streams > 0 and BA limits");
+        if (lim->max_lm & (lim->max_lm - 1)) return fail(c, "device_map: max_lm %d must be a power of two", lim->max_lm);
+        if (lim->max_kf > 12 || lim->max_pts >= 32768 || lim->max_lm >= 65536) return fail(c, "device_map: max_kf <= 12, max_pts < 32768, max_lm < 65536");
+        if (dmg_lds_bytes(lim->max_lm) > 160 * 1024) return fail(c, "device_map: max_lm %d does not fit the gather's LDS", lim->max_lm);
+        DMap &m = c->dm;
+        m.KW = lim->max_kf; m.NF = lim->max_pts; m.NL = lim->max_lm;
+        const size_t S = lim->max_streams, KF = S * m.KW, FT = KF * m.NF, LM = S * m.NL;
+        const size_t bytes = KF * (8 + 4 + 56 + 4) + FT * (8 + 8 + 4 + 4 + 1) + LM * (24 + 4 + 4 + 1 + 4) + S * 4 + 4096;
+        HIPCHK(c, hipMalloc(&c->dm_all, bytes));
+        HIPCHK(c, hipMemsetAsync(c->dm_all, 0, bytes, c->stream));
+        unsigned char *q = static_cast<unsigned char *>(c->dm_all);
+        auto take = [&](size_t n) { unsigned char *r = q; q += (n + 255) & ~(size_t)255; return r; };
+        m.kf_pose = reinterpret_cast<double *>(take(KF * 56)); m.lm_pos = reinterpret_cast<double *>(take(LM * 24));
+        m.kf_frame = reinterpret_cast<long long *>(take(KF * 8));
+        m.f_xy = reinterpret_cast<float2 *>(take(FT * 8)); m.f_xyr = reinterpret_cast<float2 *>(take(FT * 8));
+        m.kf_id = reinterpret_cast<int *>(take(KF * 4)); m.kf_n = reinterpret_cast<int *>(take(KF * 4));
+        m.f_lm = reinterpret_cast<int *>(take(FT * 4)); m.f_lmr = reinterpret_cast<int *>(take(FT * 4));
+        m.lm_id = reinterpret_cast<int *>(take(LM * 4)); m.lm_obs = reinterpret_cast<int *>(take(LM * 4)); m.lm_stamp = reinterpret_cast<int *>(take(LM * 4));
+        m.next_lm_id = reinterpret_cast<int *>(take(S * 4));
+        m.f_fl = take(FT); m.lm_st = take(LM);
+        // empty window slots / free landmark slots are marked by -1
+        HIPCHK(c, hipMemsetAsync(m.kf_frame, 0xff, KF * 8, c->stream));
+        HIPCHK(c, hipMemsetAsync(m.lm_id, 0xff, LM * 4, c->stream));
+        HIPCHK(c, hipMemsetAsync(m.lm_stamp, 0xff, LM * 4, c->stream));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_dmap_ba_gather), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)dmg_lds_bytes(lim->max_lm)));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -485,6 +517,7 @@ void svslam_destroy(svslam_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (int b = 0; b < 2; ++b) { (void)hipFree(c->rt.xy[b]); (void)hipFree(c->rt.mp[b]); (void)hipFree(c->rt.xyz[b]); }
     (void)hipFree(c->d_pyr);
+    if (c->dm_all) (void)hipFree(c->dm_all);
     (void)hipFree(c->ar.d);
     if (c->ar.h) (void)hipHostFree(c->ar.h);
     (void)hipFree(c->d_img);
@@ -1158,9 +1191,26 @@ RcclApi *rccl_api(std::string *why)
     static std::once_flag once;
     static std::string err;
     std::call_once(once, [] {
+        // RCCL must sit on the SAME HIP runtime as this library (a hipStream_t means nothing to another runtime), and
+        // PyTorch-ROCm ships its own libamdhip64.so + librccl.so: in a process that imported torch first this library
+        // is bound to torch's runtime, otherwise to the ROCm installation's.  So: the librccl next to the
+        // libamdhip64 this library actually resolved (dladdr), then the generic names.  SVSLAM_RCCL_LIB overrides.
+        if (const char *e = std::getenv("SVSLAM_RCCL_LIB")) api.lib = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
+        Dl_info di;
+        if (!api.lib && dladdr(reinterpret_cast<void *>(&hipStreamCreateWithFlags), &di) && di.dli_fname) {
+            std::string dir(di.dli_fname);
+            const size_t sl = dir.rfind('/');
+            if (sl != std::string::npos) {
+                dir.resize(sl + 1);
+                for (const char *n : { "librccl.so.1", "librccl.so" }) {
+                    api.lib = dlopen((dir + n).c_str(), RTLD_NOW | RTLD_GLOBAL);
+                    if (api.lib) break;
+                }
+            }
+        }
         for (const char *n : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
-            api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
             if (api.lib) break;
+            api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         }
         if (!api.lib) { err = std::string("librccl.so not found: ") + dlerror(); return; }
 #define SVS_RCCL_SYM(field, name) api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.lib, name)); if (!api.field) err = std::string("missing RCCL symbol ") + name
@@ -1174,6 +1224,12 @@ RcclApi *rccl_api(std::string *why)
     return &api;
 }
 } // namespace
+
+int svslam_device_count(void)
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
 
 // 128 bytes that rank 0 creates and hands to every rank (over any channel: torch.distributed, MPI, a file)
 int svslam_sba_comm_unique_id(char out128[128])
@@ -1304,6 +1360,137 @@ int svslam_sba_close(svslam_ctx *c, double *poses, double *pts, double *edge_chi
     if (poses) memcpy(poses, hp<void>(c, c->sba.oposes), sizeof(double) * 7 * c->sba.nkf);
     if (pts) memcpy(pts, hp<void>(c, c->sba.opts), sizeof(double) * 3 * c->sba.nlm);
     if (edge_chi2) memcpy(edge_chi2, hp<void>(c, c->sba.ochi), sizeof(double) * c->sba.nobs);
+    return 0;
+}
+
+// ------------------------------------------------------------------ the keyframe path on the device-resident map
+int svslam_dmap_keyframe_batch(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, const void *const *left_imgs,
+                               const void *const *right_imgs, const int *strides, int src_is_device,
+                               const double cam_l[4], const double ext_l[7], const double cam_r[4], const double ext_r[7],
+                               const svslam_dmap_params *p)
+{
+    if (njobs <= 0) return 0;
+    if (!c->dm_all) return fail(c, "dmap: context created without device_map");
+    static_assert(sizeof(DmJob) == sizeof(svslam_dmap_job), "job layout");
+    const DMap &m = c->dm;
+    if (2 * njobs > c->lim.max_jobs) return fail(c, "dmap: %d jobs need max_jobs >= %d", njobs, 2 * njobs);
+    if (p->num_features < 1 || p->num_features > c->lim.max_corners) return fail(c, "dmap: num_features %d out of [1,%d]", p->num_features, c->lim.max_corners);
+    if (p->num_active_keyframes + 1 > m.KW) return fail(c, "dmap: window of %d keyframes needs max_kf >= %d", p->num_active_keyframes, p->num_active_keyframes + 1);
+    std::vector<int> slots; std::vector<const void *> imgs; std::vector<int> strd;
+    for (int i = 0; i < njobs; ++i) {
+        svslam_dmap_job &j = jobs[i];
+        if (j.stream < 0 || j.stream >= c->lim.max_streams) return fail(c, "dmap: job %d stream %d out of range", i, j.stream);
+        if (check_slot(c, j.slot_cur) || check_slot(c, j.slot_right)) return -1;
+        if (j.kf_slot < 0 || j.kf_slot >= m.KW || j.remove_slot >= m.KW) return fail(c, "dmap: job %d keyframe slot out of range", i);
+        if (j.is_init ? j.npts != 0 : j.npts != c->rt_count[(size_t)j.stream])
+            return fail(c, "dmap: job %d says %d features, stream %d holds %d", i, j.npts, j.stream, c->rt_count[(size_t)j.stream]);
+        if (j.is_init) { slots.push_back(j.slot_cur); imgs.push_back(left_imgs[i]); strd.push_back(strides[i]); }
+    }
+    for (int i = 0; i < njobs; ++i) { slots.push_back(jobs[i].slot_right); imgs.push_back(right_imgs[i]); strd.push_back(strides[i]); }
+    {
+        const bool dec = c->src_w > 0;
+        if (pyramid_common(c, (int)slots.size(), slots.data(), imgs.data(), strd.data(), src_is_device, dec, dec ? c->src_w : c->geom.w[0],
+                           dec ? c->src_h : c->geom.h[0], false)) return -1;
+    }
+    const int NF = m.NF, NL = m.NL, MO = c->lim.max_obs, MK = c->lim.max_kf, MC = p->num_features;
+    const int tile_cap = ba_tile_cap(MK);
+    const size_t aux_stride = ba_aux_layout(MK, NL, MO, MO, MK, 0, ba_tile_bound(NL, MO, MK, tile_cap)).total + ba_pitem_bound(MO, MK);
+    const size_t n = njobs, P = n * NF, E = n * MO;
+    const size_t base = c->ar.off;
+    size_t ojobs = c->ar.take(sizeof(DmJob) * n);
+    size_t ogj = c->ar.take(sizeof(GfttJob) * n);
+    size_t ocams = c->ar.take(sizeof(BaCams));
+    size_t in_end = c->ar.off;
+    // device-only scratch of this call
+    size_t ocor = c->ar.take(sizeof(float2) * n * MC), oncor = c->ar.take(sizeof(int) * n);
+    size_t olk = c->ar.take(sizeof(LkJob) * n), oprev = c->ar.take(sizeof(float2) * P), onext = c->ar.take(sizeof(float2) * P);
+    size_t ostat = c->ar.take(P), oerr = c->ar.take(sizeof(float) * P);
+    size_t otj = c->ar.take(sizeof(TriJob) * n), oul = c->ar.take(sizeof(float2) * P), our_ = c->ar.take(sizeof(float2) * P);
+    size_t otidx = c->ar.take(sizeof(int) * P), oxyz = c->ar.take(sizeof(double) * 3 * P), ook = c->ar.take(P), oslot = c->ar.take(sizeof(int) * P);
+    size_t obd = c->ar.take(sizeof(BaDev) * n), oposes = c->ar.take(sizeof(double) * 7 * MK * n), opts = c->ar.take(sizeof(double) * 3 * NL * n);
+    size_t opk = c->ar.take(sizeof(unsigned int) * E), ouv = c->ar.take(sizeof(float2) * E), oref = c->ar.take(sizeof(int) * E);
+    size_t olms = c->ar.take(sizeof(int) * NL * n), ochi = c->ar.take(sizeof(double) * E), oflag = c->ar.take(sizeof(int) * 4);
+    size_t orecs = c->ar.take(sizeof(BaRec) * 2 * E), oaux = c->ar.take(sizeof(int) * aux_stride * n);
+    if (c->ar.off > c->ar.cap) return fail(c, "dmap: staging arena too small (%zu > %zu bytes); fewer jobs per call", c->ar.off, c->ar.cap);
+    DmJob *hj = hp<DmJob>(c, ojobs);
+    GfttJob *gj = hp<GfttJob>(c, ogj);
+    memcpy(hj, jobs, sizeof(DmJob) * n);
+    c->dm_stamp++;
+    for (int i = 0; i < njobs; ++i) {
+        hj[i].src_buf = c->rt_which[(size_t)hj[i].stream];
+        hj[i].dst_buf = c->rt_which[(size_t)hj[i].stream];      // the survivors have been copied into the keyframe by then
+        hj[i].stamp = c->dm_stamp;
+        gj[i].slot = hj[i].slot_cur; gj[i].nrect = hj[i].npts;
+        gj[i].rect_ofs = (int)(((size_t)hj[i].stream * m.KW + hj[i].kf_slot) * NF);
+    }
+    BaCams *cams = hp<BaCams>(c, ocams);
+    memcpy(cams->cam[0], cam_l, 32); memcpy(cams->cam[1], cam_r, 32);
+    memcpy(cams->ext[0], ext_l, 56); memcpy(cams->ext[1], ext_r, 56);
+    DmParams prm;
+    prm.num_features = p->num_features; prm.num_features_init = p->num_features_init; prm.num_active = p->num_active_keyframes;
+    prm.zmax = p->max_triangulation_depth; prm.chi2_th = p->chi2_th;
+    memcpy(prm.cam_l, cam_l, 32); memcpy(prm.cam_r, cam_r, 32);
+    prm.max_obs = MO; prm.max_lm = NL; prm.w = c->geom.w[0]; prm.h = c->geom.h[0];
+    TriCams tc;
+    memcpy(tc.cam_l, cam_l, 32); memcpy(tc.ext_l, ext_l, 56); memcpy(tc.cam_r, cam_r, 32); memcpy(tc.ext_r, ext_r, 56);
+    if (h2d(c, base, in_end)) return -1;
+    HIPCHK(c, hipMemsetAsync(dp<void>(c, oflag), 0, sizeof(int) * 4, c->stream));
+    DmJob *dj = dp<DmJob>(c, ojobs);
+    hipLaunchKernelGGL(k_dmap_begin, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, c->rt);
+    if (launch_gftt(c, njobs, dp<GfttJob>(c, ogj), m.f_xy, MC, 0.01, 20.0, dp<float2>(c, ocor), dp<int>(c, oncor))) return -1;   // src/frontend.cpp:24
+    hipLaunchKernelGGL(k_dmap_stereo_prep, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, prm, dp<float2>(c, ocor), dp<int>(c, oncor), MC,
+                       dp<LkJob>(c, olk), dp<float2>(c, oprev), dp<float2>(c, onext));
+    {
+        svslam_lk_params lp = { 3, 30, 0.01, 1e-4, 1 };                     // src/frontend.cpp:105-109
+        tm_begin(c, FAM_LK, 0);
+        launch_lk(c, njobs, NF, dp<LkJob>(c, olk), dp<float2>(c, oprev), dp<float2>(c, onext), dp<uint8_t>(c, ostat), dp<float>(c, oerr), &lp);
+        tm_end(c);
+    }
+    hipLaunchKernelGGL(k_dmap_stereo_finish, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, prm, dp<float2>(c, onext), dp<uint8_t>(c, ostat),
+                       dp<TriJob>(c, otj), dp<float2>(c, oul), dp<float2>(c, our_), dp<int>(c, otidx));
+    tm_begin(c, FAM_TRI, 0);
+    hipLaunchKernelGGL(k_triangulate, dim3(cdiv(NF, 64), njobs), dim3(64), 0, c->stream, dp<TriJob>(c, otj), tc, dp<float2>(c, oul), dp<float2>(c, our_),
+                       dp<double>(c, oxyz), dp<uint8_t>(c, ook));
+    tm_end(c);
+    hipLaunchKernelGGL(k_dmap_commit, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, dp<double>(c, oxyz), dp<uint8_t>(c, ook), dp<int>(c, otidx), dp<int>(c, oslot));
+    tm_begin(c, FAM_BA, njobs);
+    hipLaunchKernelGGL(k_dmap_ba_gather, dim3(njobs), dim3(DMG_THREADS), dmg_lds_bytes(NL), c->stream, dj, m, prm, dp<BaDev>(c, obd), dp<double>(c, oposes),
+                       dp<double>(c, opts), dp<unsigned int>(c, opk), dp<float2>(c, ouv), dp<int>(c, oref), dp<int>(c, olms), MK, tile_cap, aux_stride);
+    hipLaunchKernelGGL(k_ba_build, dim3(njobs), dim3(BB_THREADS), bb_lds_bytes(NL, MO), c->stream, dp<BaDev>(c, obd), dp<unsigned int>(c, opk), dp<float2>(c, ouv),
+                       dp<int>(c, oref) /* order: identity, not read */, dp<BaRec>(c, orecs), dp<int>(c, oaux), tile_cap, NL, dp<int>(c, oflag), 0,
+                       bb_edge_cache_fits(NL, MO) ? 1 : 0);
+    hipLaunchKernelGGL(k_local_ba_t<0>, dim3(njobs), dim3(BA_THREADS), ba_lds_bytes(MK), c->stream, dp<BaDev>(c, obd), dp<BaCams>(c, ocams), dp<double>(c, oposes),
+                       dp<double>(c, opts), dp<BaRec>(c, orecs), dp<int>(c, oaux), c->bw, p->chi2_th, p->ba_iters, dp<double>(c, ochi), (long long *)nullptr,
+                       tile_cap, SbaArgs{ 0, 0, 0.0, nullptr, nullptr, 0 });
+    hipLaunchKernelGGL(k_dmap_ba_scatter, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, prm, dp<BaDev>(c, obd), dp<double>(c, oposes), dp<double>(c, opts),
+                       dp<double>(c, ochi), dp<int>(c, oref), dp<int>(c, olms), MK);
+    tm_end(c);
+    hipLaunchKernelGGL(k_dmap_refresh, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, c->rt);
+    HIPCHK(c, hipGetLastError());
+    if (d2h_sync(c, ojobs, ojobs + sizeof(DmJob) * n)) return -1;
+    if (d2h_sync(c, oflag, oflag + sizeof(int) * 4)) return -1;
+    if (const int fl = hp<int>(c, oflag)[0]) return fail(c, "dmap: the BA structure build overflowed a capacity (code %d)", fl);
+    memcpy(jobs, hj, sizeof(DmJob) * n);
+    for (int i = 0; i < njobs; ++i) c->rt_count[(size_t)jobs[i].stream] = jobs[i].n_features;
+    return 0;
+}
+
+int svslam_dmap_read(svslam_ctx *c, int stream, long long *kf_frame, int *kf_id, double *kf_pose, int *kf_n, int *lm_id,
+                     double *lm_pos, int *lm_obs, uint8_t *lm_state)
+{
+    if (!c->dm_all) return fail(c, "dmap_read: context created without device_map");
+    if (stream < 0 || stream >= c->lim.max_streams) return fail(c, "dmap_read: stream %d out of range", stream);
+    const DMap &m = c->dm;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t K = (size_t)stream * m.KW, L = (size_t)stream * m.NL;
+    if (kf_frame) HIPCHK(c, hipMemcpy(kf_frame, m.kf_frame + K, sizeof(long long) * m.KW, hipMemcpyDeviceToHost));
+    if (kf_id) HIPCHK(c, hipMemcpy(kf_id, m.kf_id + K, sizeof(int) * m.KW, hipMemcpyDeviceToHost));
+    if (kf_pose) HIPCHK(c, hipMemcpy(kf_pose, m.kf_pose + K * 7, sizeof(double) * 7 * m.KW, hipMemcpyDeviceToHost));
+    if (kf_n) HIPCHK(c, hipMemcpy(kf_n, m.kf_n + K, sizeof(int) * m.KW, hipMemcpyDeviceToHost));
+    if (lm_id) HIPCHK(c, hipMemcpy(lm_id, m.lm_id + L, sizeof(int) * m.NL, hipMemcpyDeviceToHost));
+    if (lm_pos) HIPCHK(c, hipMemcpy(lm_pos, m.lm_pos + L * 3, sizeof(double) * 3 * m.NL, hipMemcpyDeviceToHost));
+    if (lm_obs) HIPCHK(c, hipMemcpy(lm_obs, m.lm_obs + L, sizeof(int) * m.NL, hipMemcpyDeviceToHost));
+    if (lm_state) HIPCHK(c, hipMemcpy(lm_state, m.lm_st + L, m.NL, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -62,6 +62,10 @@ public:
     int rtrack_upload(int n, const int *streams, const int *ofs, const int *counts, const float *xy, const int *mp,
                       const double *xyz)
     { return svslam_rtrack_upload(ctx_, n, streams, ofs, counts, xy, mp, xyz); }
+    int dmap_keyframe(int n, svslam_dmap_job *jobs, const void *const *left, const void *const *right, const int *strides,
+                      int is_device, const double *cam_l, const double *ext_l, const double *cam_r, const double *ext_r,
+                      const svslam_dmap_params *p)
+    { return svslam_dmap_keyframe_batch(ctx_, n, jobs, left, right, strides, is_device, cam_l, ext_l, cam_r, ext_r, p); }
     int lk(int n, const svslam_lk_job *jobs, int total, const float *prev_xy, float *next_xy, uint8_t *status,
            float *err, const svslam_lk_params *p)
     { return svslam_lk_batch(ctx_, n, jobs, total, prev_xy, next_xy, status, err, p); }

@@ -26,6 +26,9 @@ typedef struct svs_pipe_config {
     int low_latency;          /* 1: latency shape of the serial kernels (svslam_set_low_latency), for a
                                   few streams per GPU                                                */
     int max_pts;              /* features per frame the kernel provider holds per stream (0 = 512)   */
+    int device_map;           /* 1: the map of every stream lives in device memory (svslam_dmap_*): the
+                                  keyframe path costs the host O(window) per keyframe, no per-feature work.
+                                  Needs resident_track = 1, backend_on = 1.  The HIP provider only.          */
 } svs_pipe_config;
 
 typedef struct svs_frame_result {

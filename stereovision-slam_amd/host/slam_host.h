@@ -60,6 +60,10 @@ struct Config {                       // config/stereo_slam_configs/config-00.ya
     // max_lm / max_obs) — the reference's own backend drops optimisation requests too (lossy
     // notify).  Counters::corners_dropped / ba_skipped report how often.
     int max_pts = 0, max_kf = 0, max_lm = 0, max_obs = 0;
+    // 1: the kernel provider keeps every stream's map (window, keyframe features, landmarks, observation counts) in
+    // device memory and runs the whole keyframe path there (K::dmap_keyframe); the host keeps O(window) per stream —
+    // the keyframes' ids, slots and poses.  Needs resident_track and backend_on == 1.
+    int device_map = 0;
 };
 
 enum class FrontendStatus { INITING = 0, TRACKING_GOOD = 1, TRACKING_BAD = 2, LOST = 3 };
@@ -80,6 +84,7 @@ struct Frame {
     Frame *prev_keyframe = nullptr;
     SE3 relative_pose_pkf;
     int ba_local = -1;                // index in the current BA problem (scratch of Backend::Optimize)
+    int dslot = -1;                   // device_map: slot of this keyframe in the provider's window arena
 };
 
 struct ObsRef {
@@ -228,14 +233,14 @@ public:
         }
         active_landmarks_.resize(keep);
     }
-    void RemoveOldKeyframe()            // src/map.cpp:76-181
+    // which keyframe leaves the window (src/map.cpp:76-120): the nearest one if it is closer than 0.2, else the farthest
+    static Frame *ChooseKeyframeToRemove(const std::vector<Frame *> &active, Frame *current)
     {
-        if (!current_frame_) return;
         double max_dis = 0, min_dis = 999999;
         Frame *max_kf = nullptr, *min_kf = nullptr;
-        SE3 Twc = current_frame_->pose.inverse();
-        for (Frame *kf : active_keyframes_) {
-            if (kf == current_frame_) continue;
+        SE3 Twc = current->pose.inverse();
+        for (Frame *kf : active) {
+            if (kf == current) continue;
             double dis = (kf->pose * Twc).log_norm();
             if (dis > max_dis) { max_dis = dis; max_kf = kf; }
             if (dis < min_dis) { min_dis = dis; min_kf = kf; }
@@ -247,7 +252,13 @@ public:
         // shrinks: fall back to the oldest active keyframe that is not the current one.
         Frame *rm = (min_dis < min_dis_th) ? min_kf : max_kf;
         if (!rm)
-            for (Frame *kf : active_keyframes_) if (kf != current_frame_) { rm = kf; break; }
+            for (Frame *kf : active) if (kf != current) { rm = kf; break; }
+        return rm;
+    }
+    void RemoveOldKeyframe()            // src/map.cpp:76-181
+    {
+        if (!current_frame_) return;
+        Frame *rm = ChooseKeyframeToRemove(active_keyframes_, current_frame_);
         if (!rm) return;
         active_keyframes_.erase(std::remove(active_keyframes_.begin(), active_keyframes_.end(), rm), active_keyframes_.end());
         for (size_t i = 0; i < rm->left.size(); ++i)
@@ -433,7 +444,9 @@ public:
         std::vector<int> DS = IS;                 // streams that detect this frame
         DS.insert(DS.end(), KS.begin(), KS.end());
         std::vector<int> MS;                      // streams that triangulate + BA
-        if (!DS.empty()) {
+        if (device_map()) {
+            if (!DS.empty()) KeyframeOnDevice(IS, KS, left, right, strides, is_device, MS);
+        } else if (!DS.empty()) {
             BuildPyramids(IS, DS, left, right, strides, is_device);
             DetectFeatures(DS);
             FindFeaturesInRight(DS);
@@ -451,7 +464,9 @@ public:
         // thread was fast").  backend_on 2: it runs beside the next frame's Track() like the
         // reference's Backend thread, and its result lands after that frame — always exactly one
         // frame late, so runs stay reproducible.
-        if (cfg_.backend_on == 1 && backend_enabled_) {
+        if (device_map()) {
+            // everything below happened on the device
+        } else if (cfg_.backend_on == 1 && backend_enabled_) {
             for (int s : MS) ReleaseRetired(*streams_[s]);           // nothing in flight
             if (!MS.empty()) { BackendSubmit(MS); BackendCollect(); }
         } else if (cfg_.backend_on >= 2 && backend_enabled_) {
@@ -464,7 +479,7 @@ public:
         }
         // frames whose feature list or map points changed on the host (init, keyframes, BA) replace
         // the resident copy; every other frame's list never left the device
-        if (resident() && !DS.empty()) UploadFeatures(DS);
+        if (resident() && !device_map() && !DS.empty()) UploadFeatures(DS);
         if (on_keyframe) for (int s : MS) on_keyframe(s, *streams_[s]->current);
         long long t_e = now_ns();
         for (int s : TS) {
@@ -605,6 +620,121 @@ private:
     }
 
     bool resident() const { return cfg_.resident_track && cfg_.backend_on <= 1; }
+    bool device_map() const { return cfg_.device_map && resident() && cfg_.backend_on == 1; }
+
+    // ---- the keyframe path with the map in device memory: InsertKeyframe (:576-643) / StereoInit (:216-249) and
+    // Backend::Optimize as ONE call of the kernel provider.  The host keeps the window's frames (ids, poses, slots):
+    // it picks the keyframe to retire (Map::ChooseKeyframeToRemove) and a free slot for the new one.
+    void KeyframeOnDevice(const std::vector<int> &IS, const std::vector<int> &KS, const void *const *left,
+                          const void *const *right, const int *strides, int is_device, std::vector<int> &MS)
+    {
+        long long t_h = now_ns();
+        std::vector<int> DS = IS;
+        DS.insert(DS.end(), KS.begin(), KS.end());
+        const int n = (int)DS.size();
+        jobs_dm_.assign((size_t)n, svslam_dmap_job());
+        dm_left_.resize(n); dm_right_.resize(n); strides_.resize(n);
+        pool_.parallel_for(n, [&](int i) {
+            Stream &st = *streams_[DS[i]];
+            const bool init = i < (int)IS.size();
+            Frame *cur = st.current;
+            svslam_dmap_job &j = jobs_dm_[i];
+            std::memset(&j, 0, sizeof(j));
+            j.stream = DS[i]; j.slot_cur = st.slot_cur; j.slot_right = st.slot_right; j.is_init = init ? 1 : 0;
+            j.frame_id = cur->id; j.remove_slot = -1;
+            if (init) {
+                j.kf_slot = FreeWindowSlot(st); j.kf_id = (int)st.kf_factory_id; j.npts = 0;
+            } else {
+                // Frame::SetKeyFrame + Map::InsertKeyFrame (src/map.cpp:53-67) on the host mirror
+                cur->is_keyframe = true;
+                cur->keyframe_id = st.kf_factory_id++;
+                st.kf_store.push_back(std::move(st.cur_owned));
+                st.map.keyframes_.push_back(cur);
+                st.map.active_keyframes_.push_back(cur);
+                st.c_keyframes++;
+                if ((int)st.map.active_keyframes_.size() > cfg_.num_active_keyframes) {
+                    Frame *rm = Map::ChooseKeyframeToRemove(st.map.active_keyframes_, cur);
+                    if (rm) {
+                        j.remove_slot = rm->dslot; rm->dslot = -1;
+                        auto &ak = st.map.active_keyframes_;
+                        ak.erase(std::remove(ak.begin(), ak.end(), rm), ak.end());
+                    }
+                }
+                cur->dslot = j.kf_slot = FreeWindowSlot(st, j.remove_slot);
+                j.kf_id = (int)cur->keyframe_id; j.npts = st.dev_feat;
+                st.frontend_prev_kf = st.frontend_current_kf;
+                st.frontend_current_kf = cur;
+                cur->prev_keyframe = st.frontend_prev_kf;
+                if (st.frontend_prev_kf) cur->relative_pose_pkf = cur->pose * st.frontend_prev_kf->pose.inverse();
+            }
+            std::memcpy(j.pose, cur->pose.v, sizeof(j.pose));
+            const SE3 T_camr_w = cfg_.cam_r.pose * cur->pose;
+            std::memcpy(j.T_camr_w, T_camr_w.v, sizeof(j.T_camr_w));
+            const SE3 Twc = init ? SE3() : cur->pose.inverse();       // :261
+            std::memcpy(j.T_wc, Twc.v, sizeof(j.T_wc));
+            dm_left_[i] = left[DS[i]]; dm_right_[i] = right[DS[i]];
+            strides_[i] = strides ? strides[DS[i]] : (cfg_.src_width > 0 ? cfg_.src_width : cfg_.width);
+        });
+        svslam_dmap_params prm;
+        prm.num_features = cfg_.num_features; prm.num_features_init = cfg_.num_features_init;
+        prm.num_active_keyframes = cfg_.num_active_keyframes; prm.ba_iters = backend_enabled_ ? 10 : 0;   // src/backend.cpp:163
+        prm.max_triangulation_depth = cfg_.max_triangulation_depth; prm.chi2_th = cfg_.chi2_th;
+        st_[6] += now_ns() - t_h;
+        // a provider call holds at most dm_chunk_ jobs (its staging memory is sized for that)
+        for (int c0 = 0; c0 < n; c0 += dm_chunk_) {
+            const int m = std::min(dm_chunk_, n - c0);
+            KTimer kt_(cnt_);
+            check(k_.dmap_keyframe(m, jobs_dm_.data() + c0, dm_left_.data() + c0, dm_right_.data() + c0, strides_.data() + c0, is_device,
+                                   cam_l_, cfg_.cam_l.pose.v, cam_r_, cfg_.cam_r.pose.v, &prm), "dmap_keyframe");
+        }
+        t_h = now_ns();
+        for (int i = 0; i < n; ++i) {
+            Stream &st = *streams_[DS[i]];
+            const svslam_dmap_job &j = jobs_dm_[i];
+            Frame *cur = st.current;
+            const bool init = j.is_init != 0;
+            cnt_.gftt_calls++; cnt_.gftt_rects += j.npts; cnt_.right_pts += j.n_features; cnt_.pyr_right++;
+            st.c_corners += j.n_corners;
+            if (init) cnt_.pyr_left++;
+            if (j.flags & 1) st.c_dropped++;
+            st.dev_feat = j.n_features;
+            if (init) {
+                if (!j.ok) continue;                                  // StereoInit failed (:227): try again with the next frame
+                st.init_ok = true;
+                // StereoInit :232-246 + BuildInitMap :195-203
+                st.frontend_current_kf = cur;
+                cur->is_keyframe = true;
+                cur->keyframe_id = st.kf_factory_id++;
+                cur->dslot = j.kf_slot;
+                st.kf_store.push_back(std::move(st.cur_owned));
+                st.map.keyframes_.push_back(cur);
+                st.map.active_keyframes_.push_back(cur);
+                st.c_keyframes++;
+                st.status = FrontendStatus::TRACKING_GOOD;
+            }
+            MS.push_back(DS[i]);
+            cnt_.tri_pts += j.n_tri_in;
+            if (j.flags & 4) cnt_.ba_skipped++;
+            if (prm.ba_iters > 0 && !(j.flags & 4)) {
+                cnt_.ba_calls++; cnt_.ba_edges += j.ba_nobs; cnt_.ba_kf += j.ba_nkf; cnt_.ba_lm += j.ba_nlm; cnt_.ba_iters += j.ba_iters;
+                // :224-246 on the mirror: the window's poses
+                for (int a = 0; a < j.ba_nkf; ++a)
+                    for (Frame *kf : st.map.active_keyframes_)
+                        if (kf->dslot == j.win_slot[a]) { kf->pose = SE3(j.win_pose[a]); break; }
+                for (Frame *kf : st.map.active_keyframes_)
+                    if (kf->keyframe_id != 0 && kf->prev_keyframe) kf->relative_pose_pkf = kf->pose * kf->prev_keyframe->pose.inverse();
+            }
+        }
+        st_[7] += now_ns() - t_h;
+    }
+    int FreeWindowSlot(const Stream &st, int just_freed = -1) const
+    {
+        if (just_freed >= 0) return just_freed;
+        unsigned used = 0;
+        for (const Frame *kf : st.map.active_keyframes_) if (kf->dslot >= 0) used |= 1u << kf->dslot;
+        for (int k = 0; k < cfg_.num_active_keyframes + 1; ++k) if (!(used & (1u << k))) return k;
+        return 0;
+    }
 
     // ---- Track() with the last frame's features resident in the kernel provider's memory: the
     // gather of :331-347 and the scatter of :361-381 / :546-553 run on the device, the host
@@ -653,6 +783,7 @@ private:
         else if (st.tracking_inliers > cfg_.num_features_tracking_bad) st.status = FrontendStatus::TRACKING_BAD;
         else st.status = FrontendStatus::LOST;                     // :665-679
         if (st.tracking_inliers >= cfg_.num_features_needed_for_keyframe) return;
+        if (device_map()) { st.is_new_kf = true; return; }          // InsertKeyframe runs on the device (KeyframeOnDevice)
         // InsertKeyframe :576-616 — only now does the host need the frame's features
         cur->left.reserve((size_t)j.n_tracked + (size_t)cfg_.num_features);
         for (int r = 0; r < j.n_tracked; ++r) {
@@ -1180,6 +1311,9 @@ private:
     std::vector<svslam_gftt_job> jobs_gftt_;
     std::vector<svslam_tri_job> jobs_tri_;
     std::vector<svslam_ba_job> jobs_ba_;
+    std::vector<svslam_dmap_job> jobs_dm_;
+    std::vector<const void *> dm_left_, dm_right_;
+    int dm_chunk_ = 256;
     std::vector<const void *> imgs_;
     std::vector<int> strides_;
     std::vector<float> prev_xy_, next_xy_, rects_, corners_, uv_l_, uv_r_, err_, ba_uv_;

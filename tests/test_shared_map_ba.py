@@ -219,8 +219,100 @@ def test_shared_map_ba_on_the_gpu(svs, tmp_path):
     assert np.allclose(X, X1, atol=1e-8)
 
 
+def _native_single_main():
+    """svslam_sba_solve on one rank with a one-rank RCCL communicator; runs in its own process so that the test
+    process never loads RCCL (the GPU box's pytest also imports torch, which brings its own RCCL + HIP runtime)"""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import lm_cases as lc
+    import oracle_lib as orc
+    svs = importlib.import_module("stereovision-slam_amd")
+    sdist = importlib.import_module("stereovision-slam_amd.dist")
+    sba = importlib.import_module("stereovision-slam_amd.shared_ba")
+    rank = sdist.Rank(0, 0, 1)
+    for name, job, iters in (("default", _problem(7, 10, 900), 10), ("rejecting 1024", lc.ba_synth_case(1024), 10),
+                             ("rejecting 1013", lc.ba_synth_case(1013), 10)):
+        poses, pts, okf, olm, ori, ouv = job
+        ctx = svs.Context(cm.W, cm.H, max_slots=1, max_jobs=1, max_kf=11, max_lm=2048, max_obs=20000)
+        (pr, xr, cr, itr), = ctx.local_ba([job], cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R, iters=iters)
+        eng = sba.HipEngine(ctx, cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R, poses, pts, okf, olm, ori, ouv)
+        tr_py = []
+        it_py, lam_py = sba.shared_map_ba(eng, rank, len(poses), iters=iters, trace=tr_py)
+        P_py, X_py, C_py = eng.close()
+        eng = sba.HipEngine(ctx, cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R, poses, pts, okf, olm, ori, ouv)
+        it_n, lam_n, tr_n, stats = sba.shared_map_ba_native(ctx, rank, iters=iters)          # creates the RCCL communicator
+        P_n, X_n, C_n = eng.close()
+        assert it_n == it_py == itr, name
+        assert np.array_equal(tr_n, np.array(tr_py)), (name, np.abs(tr_n - np.array(tr_py)).max())
+        assert lam_n == lam_py
+        assert np.array_equal(P_n, P_py) and np.array_equal(X_n, X_py) and np.array_equal(C_n, C_py)
+        assert np.allclose(P_n, pr, atol=1e-9) and np.allclose(X_n, xr, atol=1e-8), name
+        ref = orc.local_ba_trace(cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R, *job, iters=iters, jac_mode=0)[4]
+        lc.assert_traces_agree(tr_n, ref, need_rejected=0 if name == "default" else 1, what="native sba " + name)
+        K = len(poses)       # (6K)^2 + 3 (6K) + 1 doubles of the reduced system + chi2, and two scalars
+        assert stats["trials"] == len(tr_n) and stats["allreduce_bytes_per_trial"] == 8 * (36 * K * K + 18 * K + 3)
+        print("native shared-map BA (%s): %d trials, %.3f ms per trial (1 rank, RCCL world 1, %d B all-reduced per trial)"
+              % (name, stats["trials"], stats["ms_per_trial"], stats["allreduce_bytes_per_trial"]))
+        ctx.sba_comm_destroy()
+        ctx.close()
+    print("native-single ok")
+
+
+@pytest.mark.gpu
+def test_native_shared_map_ba_with_rccl_on_the_device_buffer():
+    """svslam_sba_solve: the LM loop inside the library, ncclAllReduce on the device buffer (a one-rank RCCL
+    communicator on the 1-GPU test box: RCCL is initialised and every collective of the path runs).  Must equal
+    the Python-driven phases trial for trial (same kernels, same control flow), the single-launch local BA at
+    1e-9, and follow the oracle through rejected trials."""
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--native-single-main"], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-1500:])
+    assert r.returncode == 0 and "native-single ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def _native_rank_main():
+    """one rank per GPU, nccl backend: the product path of BASELINE config 5"""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    svs = importlib.import_module("stereovision-slam_amd")
+    sdist = importlib.import_module("stereovision-slam_amd.dist")
+    sba = importlib.import_module("stereovision-slam_amd.shared_ba")
+    rk = sdist.init("nccl")
+    poses, pts, okf, olm, ori, ouv = _problem(7, 10, 900)
+    mine, k2, l2, r2, u2, _ = sba.shard_by_landmark(len(pts), okf, olm, ori, ouv, rk.rank, rk.world)
+    ctx = svs.Context(cm.W, cm.H, max_slots=1, max_jobs=1, max_kf=11, max_lm=2048, max_obs=20000, device=rk.local_rank)
+    eng = sba.HipEngine(ctx, cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R, poses, pts[mine], k2, l2, r2, u2)
+    it, lam, tr, stats = sba.shared_map_ba_native(ctx, rk, iters=10)
+    P, X, chi2 = eng.close()
+    np.savez(os.environ["SBA_OUT"] + ".%d.npz" % rk.rank, poses=P, pts=X, mine=mine, it=it, lam=lam, ms_per_trial=stats["ms_per_trial"])
+    ctx.sba_comm_destroy(); ctx.close(); rk.close()
+
+
+@pytest.mark.gpu
+def test_native_shared_map_ba_two_gpus_over_rccl(svs, tmp_path):
+    """two ranks on two GPUs, nccl backend (= RCCL over xGMI), landmarks sharded, ncclAllReduce of the reduced camera
+    system on the device buffers — runs wherever two GPUs are visible, skipped on the 1-GPU test box"""
+    if svs.load().svslam_device_count() < 2:
+        pytest.skip("needs two GPUs")
+    poses, pts, okf, olm, ori, ouv = _problem(7, 10, 900)
+    ctx = svs.Context(cm.W, cm.H, max_slots=1, max_jobs=1, max_kf=11, max_lm=2048, max_obs=20000)
+    (pr, xr, cr, itr), = ctx.local_ba([(poses, pts, okf, olm, ori, ouv)], cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R)
+    ctx.close()
+    out = str(tmp_path / "sba")
+    env = dict(os.environ, SBA_OUT=out, MASTER_ADDR="127.0.0.1", MASTER_PORT="29535", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29535", os.path.abspath(__file__), "--native-rank-main"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    a, b = np.load(out + ".0.npz"), np.load(out + ".1.npz")
+    assert int(a["it"]) == int(b["it"]) == itr and np.array_equal(a["poses"], b["poses"])
+    assert np.allclose(a["poses"], pr, atol=1e-9)
+    X = np.zeros_like(pts); X[a["mine"]] = a["pts"]; X[b["mine"]] = b["pts"]
+    assert np.allclose(X, xr, atol=1e-8)
+
+
 if __name__ == "__main__":
     if "--rank-main" in sys.argv:
         _cpu_rank_main()
     elif "--gpu-rank-main" in sys.argv:
         _gpu_rank_main()
+    elif "--native-rank-main" in sys.argv:
+        _native_rank_main()
+    elif "--native-single-main" in sys.argv:
+        _native_single_main()

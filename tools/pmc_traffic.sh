@@ -1,12 +1,14 @@
 #!/bin/bash
 # HBM-side traffic per kernel from two PMC passes (FETCH_SIZE, WRITE_SIZE separately: they do not fit one
-# pass) over a small bench run (256 streams, 1 group); aggregated per kernel name -> gpurun_out/pmc_traffic_raw.json
+# pass) over a bench run; aggregated per kernel name -> gpurun_out/pmc_traffic_raw.json.
+# PMC_BENCH_ARGS chooses the operating point: default the small one of round 2 (256 streams, 1 group); round 3 also
+# runs the headline one: PMC_BENCH_ARGS="--steps 20 --warmup 5" (12288 streams x 12 groups)
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 for ctr in FETCH_SIZE WRITE_SIZE; do
   O=gpurun_out/pmc_$ctr; rm -rf "$O"; mkdir -p "$O"
-  timeout 400 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$O" -- python bench.py --streams 256 --groups 1 --host-threads 4 --steps 30 --warmup 5 --preroll 100 --no-cpu-baseline > gpurun_out/pmc_${ctr}_bench.json 2> gpurun_out/pmc_${ctr}.err < /dev/null
+  timeout ${PMC_TIMEOUT:-400} rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$O" -- python bench.py ${PMC_BENCH_ARGS:---streams 256 --groups 1 --host-threads 4 --steps 30 --warmup 5 --preroll 100} --no-cpu-baseline --spread-windows 0 --host-input-steps 0 --solo-steps 0 > gpurun_out/pmc_${ctr}_bench.json 2> gpurun_out/pmc_${ctr}.err < /dev/null
 done
 python - <<'PY'
 import csv, glob, json, collections, re
