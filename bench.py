@@ -131,6 +131,10 @@ def main():
     ap.add_argument("--solo-steps", type=int, default=6,
                     help="steps of an extra leg in which ONE group runs alone on the GPU: every kernel of its chain then "
                          "has the chip to itself, so the HIP-event durations are solo durations (roofline_solo; 0 = skip)")
+    ap.add_argument("--host-map", action="store_true",
+                    help="keep every stream's map (window, features, landmarks, observations) on the HOST as in rounds 1-2; "
+                         "default: the map lives in HBM and the keyframe path is one chain of kernels (svslam_dmap_*) — "
+                         "bit-identical results, a fraction of the host CPU")
     ap.add_argument("--full-res", action="store_true",
                     help="keep the frames in HBM at the camera's 1241x376 and fuse the reference's 1/2 "
                          "decimation (Dataset::NextFrame) into the pyramid's level 0 (SURVEY 8 row f3); 4x the "
@@ -167,8 +171,10 @@ def main():
         S = next((c for c in (12288, 8192, 6144) if c <= cap), cap)
         # a rank that may use only a few cores (N ranks sharing one CPU quota) cannot feed that many streams:
         # ~27 us of host CPU per frame; keep its memory footprint in proportion
+        # (only with the map on the host: the device-resident map costs the host < 1 core per 12 288 streams)
         lw = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-        S = min(S, 1024 * max(1, effective_cpus() // max(1, lw)))
+        if args.host_map or args.backend_mode != 1:
+            S = min(S, 1024 * max(1, effective_cpus() // max(1, lw)))
     if S > cap:
         S = max(512, cap // 512 * 512) if cap >= 512 else max(1, cap)
     # host layout from the cores this rank may actually use (cgroup quota / ranks on the node):
@@ -178,15 +184,19 @@ def main():
     cores = max(1, effective_cpus() // max(1, local_world))
     pinned = set() if args.no_pin else sdist.pin_to_device_numa(local_rank, min_cpus=cores)
     # (about 1024 streams per group: 8 groups up to 8192 streams, 12 beyond; tools/sweep.sh)
-    G = args.groups if args.groups > 0 else min(12 if S >= 12288 else 8, cores)
+    dev_map = not (args.host_map or args.backend_mode != 1)
+    # with the map on the device a group's thread only enqueues and waits: the group count follows the GPU (kernels
+    # of different groups overlap), not the cores, and one bookkeeping thread per group is plenty
+    G = args.groups if args.groups > 0 else ((12 if S >= 12288 else 8) if dev_map else min(12 if S >= 12288 else 8, cores))
     G = max(1, min(G, S))
     S -= S % G                                       # whole groups (8192 streams in 12 groups: 12 x 682)
     if args.host_threads <= 0:
-        args.host_threads = max(1, min(4, (2 * cores + G - 1) // G))
+        args.host_threads = 1 if dev_map else max(1, min(4, (2 * cores + G - 1) // G))
     Sg = S // G
     cfg = pl.default_config(W, H, host_threads=max(1, args.host_threads), backend_on=args.backend_mode,
                             src_width=SW if args.full_res else 0, src_height=SH if args.full_res else 0,
-                            low_latency=1 if args.low_latency else 0)
+                            low_latency=1 if args.low_latency else 0,
+                            device_map=0 if (args.host_map or args.backend_mode != 1) else 1)
     pipes = [pl.Pipeline(cfg, nstreams=Sg, device=local_rank) for _ in range(G)]
     ctxs = [svs.Context.borrow(p.kernel_ctx(), W, H) for p in pipes]   # alloc / timing through the pipelines' contexts
     ctx = ctxs[0]
@@ -419,6 +429,8 @@ def main():
                                    "keyframes)" % ("completes before the next frame" if args.backend_mode == 1 else
                                                    "runs beside the next frame like the reference's backend thread, "
                                                    "lands one frame late, all of it inside the timed region"),
+                       "map": "host (Frontend/Map/Backend bookkeeping on the CPU)" if cfg.device_map == 0 else
+                              "device-resident (svslam_dmap_*: window, features, landmarks, observation counts in HBM; the host keeps ids and poses of the window)",
                        "preroll_steps": pre, "preroll_last_block_ba_keyframes_mean": round(preroll_kf, 2),
                        "streams_per_gpu": S, "host_threads_per_gpu": G, "bookkeeping_threads_per_group": args.host_threads, "frame": "%dx%d u8 stereo pair" % (W, H) + (" decimated on the fly from %dx%d frames in HBM" % (SW, SH) if args.full_res else ""),
                        "keyframes_in_timed_region": cnt["keyframes"],

@@ -32,6 +32,8 @@
 #include "k_ba_build.h"
 #include "k_dmap.h"
 
+#define SVSLAM_DMAP_CHUNK 256     /* keyframe jobs per svslam_dmap_keyframe_batch call the staging arena is sized for */
+
 namespace {
 
 enum { FAM_PYR = 0, FAM_LK, FAM_GFTT, FAM_TRI, FAM_POSE, FAM_BA, FAM_DBG0, FAM_DBG1, FAM_DBG2, FAM_DBG3, FAM_COUNT };
@@ -436,6 +438,19 @@ int svslam_create(const svslam_limits *lim, svslam_ctx **out)
                   ((size_t)lim->max_kf * (lim->max_kf + 1) / 2 + 1);          // per-tile pair ranges at their upper bound
     size_t per_job = std::max(per_job_pts, per_job_ba) + (size_t)lim->max_corners * 8 + 4096;
     c->ar.cap = per_job * J + (1 << 20);
+    if (lim->device_map) {
+        // With the map on the device the big consumer — BA staging for max_jobs host-gathered problems — is not used:
+        // the keyframe path takes at most SVSLAM_DMAP_CHUNK jobs per call and keeps its scratch device-side (the arena
+        // mirrors host and device, and 12 contexts x 4 GB of pinned host memory per process was the price of the old
+        // sizing).  Tracking calls still get their per-point staging for every job; host-side BA calls on such a
+        // context are limited to 64 problems per call.
+        const size_t MO = lim->max_obs, NL = lim->max_lm, NF = lim->max_pts, MK = lim->max_kf;
+        const int tc = std::max(ba_tile_cap(lim->max_kf), 64);
+        const size_t aux = ba_aux_layout((int)MK, (int)NL, (int)MO, (int)MO, (int)MK, 0, ba_tile_bound((int)NL, (int)MO, (int)MK, tc)).total + ba_pitem_bound((int)MO, (int)MK);
+        const size_t per_dm = sizeof(DmJob) + NF * 80 + NL * 32 + MO * 64 + aux * 4 + MK * 56 + (size_t)lim->max_corners * 8 + 8192;
+        const size_t chunk = std::min<size_t>(SVSLAM_DMAP_CHUNK, (size_t)std::max(1, lim->max_streams));
+        c->ar.cap = std::max(chunk * per_dm, std::max(per_job_pts * J, std::min<size_t>(J, 64) * per_job)) + (4 << 20);
+    }
     HIPCHK(c, hipHostMalloc(&c->ar.h, c->ar.cap));
     HIPCHK(c, hipMalloc(&c->ar.d, c->ar.cap));
 
@@ -1374,6 +1389,7 @@ int svslam_dmap_keyframe_batch(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, 
     static_assert(sizeof(DmJob) == sizeof(svslam_dmap_job), "job layout");
     const DMap &m = c->dm;
     if (2 * njobs > c->lim.max_jobs) return fail(c, "dmap: %d jobs need max_jobs >= %d", njobs, 2 * njobs);
+    if (njobs > SVSLAM_DMAP_CHUNK) return fail(c, "dmap: at most %d jobs per call", SVSLAM_DMAP_CHUNK);
     if (p->num_features < 1 || p->num_features > c->lim.max_corners) return fail(c, "dmap: num_features %d out of [1,%d]", p->num_features, c->lim.max_corners);
     if (p->num_active_keyframes + 1 > m.KW) return fail(c, "dmap: window of %d keyframes needs max_kf >= %d", p->num_active_keyframes, p->num_active_keyframes + 1);
     std::vector<int> slots; std::vector<const void *> imgs; std::vector<int> strd;
@@ -1739,7 +1755,8 @@ int svslam_rtrack_batch(svslam_ctx *c, int njobs, svslam_rtrack_job *jobs, const
     hipLaunchKernelGGL(k_rt_finish, dim3(njobs), dim3(64), 0, c->stream, dp<RtJob>(c, ort), c->rt, dp<float2>(c, onext),
                        dp<uint8_t>(c, ostat), dp<uint8_t>(c, oout), dp<double>(c, oxyz), dp<float2>(c, oxy), dp<int>(c, ompo));
     HIPCHK(c, hipGetLastError());
-    if (d2h_sync(c, opj, out_end)) return -1;      // pose jobs, rt jobs, compacted survivors
+    // pose jobs, rt jobs (+ the compacted survivors unless the caller keeps its map on the device and passes no buffers)
+    if (d2h_sync(c, opj, (out_xy || out_mp) ? out_end : in_end)) return -1;
     for (int i = 0; i < njobs; ++i) {
         svslam_rtrack_job &j = jobs[i];
         memcpy(j.pose, pj[i].pose, 56);

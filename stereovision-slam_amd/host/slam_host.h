@@ -762,11 +762,12 @@ private:
             strides_[i] = strides ? strides[TS[i]] : (cfg_.src_width > 0 ? cfg_.src_width : cfg_.width);
         }
         const size_t tot = (size_t)std::max(ofs, 1);
-        next_xy_.resize(2 * tot); rt_mp_.resize(tot);
+        const bool want_lists = !device_map();      // with the map on the device nobody on the host reads the survivors
+        if (want_lists) { next_xy_.resize(2 * tot); rt_mp_.resize(tot); }
         st_[1] += now_ns() - t_p;
         svslam_lk_params prm = { 3, 30, 0.01, 1e-4, 1 };            // :353-357
         { KTimer kt_(cnt_); check(k_.rtrack(n, jobs_rt_.data(), imgs_.data(), strides_.data(), is_device, ofs, cam_l_,
-                       next_xy_.data(), rt_mp_.data(), &prm, 5.991), "rtrack"); }
+                       want_lists ? next_xy_.data() : nullptr, want_lists ? rt_mp_.data() : nullptr, &prm, 5.991), "rtrack"); }
         cnt_.track_pts += ofs; cnt_.pyr_left += n;
     }
 
