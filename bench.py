@@ -117,6 +117,9 @@ def main():
                     help="1 (default): local BA completes before the next frame; 2: it runs beside the next "
                          "frame like the reference's backend thread and lands exactly one frame late "
                          "(measured: no throughput gain, the GPU is already saturated by the other streams)")
+    ap.add_argument("--backend-lag", type=int, default=1,
+                    help="--backend-mode 2: frames a local BA may stay in flight before its result is applied (1 = one frame, "
+                         "round 2; 6 hides a lone camera's 1.3-ms BA behind the next frames' tracking)")
     ap.add_argument("--cpu-frames", type=int, default=1200, help="timed frames per CPU-baseline thread (after its pre-roll)")
     ap.add_argument("--preroll", type=int, default=-1,
                     help="untimed steps before the warm-up so that the timed region is the steady state (every stream's "
@@ -187,7 +190,9 @@ def main():
     dev_map = not (args.host_map or args.backend_mode != 1)
     # with the map on the device a group's thread only enqueues and waits: the group count follows the GPU (kernels
     # of different groups overlap), not the cores, and one bookkeeping thread per group is plenty
-    G = args.groups if args.groups > 0 else ((12 if S >= 12288 else 8) if dev_map else min(12 if S >= 12288 else 8, cores))
+    # (measured, tools/sweep_devmap.sh: 4 / 6 / 8 / 12 / 16 groups at 12 288 streams = 483 / 487 / 500 / 495 / 480 k frames/s,
+    # 24 groups 450 k — the GPU is the limit whatever the layout; 6 keeps fewer kernels co-resident per launch)
+    G = args.groups if args.groups > 0 else (6 if dev_map else min(12 if S >= 12288 else 8, cores))
     G = max(1, min(G, S))
     S -= S % G                                       # whole groups (8192 streams in 12 groups: 12 x 682)
     if args.host_threads <= 0:
@@ -196,7 +201,7 @@ def main():
     cfg = pl.default_config(W, H, host_threads=max(1, args.host_threads), backend_on=args.backend_mode,
                             src_width=SW if args.full_res else 0, src_height=SH if args.full_res else 0,
                             low_latency=1 if args.low_latency else 0,
-                            device_map=0 if (args.host_map or args.backend_mode != 1) else 1)
+                            device_map=0 if (args.host_map or args.backend_mode != 1) else 1, backend_lag=max(1, args.backend_lag))
     pipes = [pl.Pipeline(cfg, nstreams=Sg, device=local_rank) for _ in range(G)]
     ctxs = [svs.Context.borrow(p.kernel_ctx(), W, H) for p in pipes]   # alloc / timing through the pipelines' contexts
     ctx = ctxs[0]

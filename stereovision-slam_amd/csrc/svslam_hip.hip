@@ -32,7 +32,7 @@
 #include "k_ba_build.h"
 #include "k_dmap.h"
 
-#define SVSLAM_DMAP_CHUNK 256     /* keyframe jobs per svslam_dmap_keyframe_batch call the staging arena is sized for */
+#define SVSLAM_DMAP_CHUNK 512     /* keyframe jobs per svslam_dmap_keyframe_batch call the staging arena is sized for */
 
 namespace {
 

@@ -29,6 +29,7 @@ typedef struct svs_pipe_config {
     int device_map;           /* 1: the map of every stream lives in device memory (svslam_dmap_*): the
                                   keyframe path costs the host O(window) per keyframe, no per-feature work.
                                   Needs resident_track = 1, backend_on = 1.  The HIP provider only.          */
+    int backend_lag;          /* backend_on == 2: frames a submitted local BA may stay in flight (0 / 1: one frame) */
 } svs_pipe_config;
 
 typedef struct svs_frame_result {

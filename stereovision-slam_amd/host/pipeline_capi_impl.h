@@ -36,6 +36,7 @@ svs::Config to_config(const svs_pipe_config &c)
     g.max_pts = c.max_pts > 0 ? c.max_pts : 512;
     g.max_kf = c.num_active_keyframes + 1; g.max_lm = c.max_lm; g.max_obs = c.max_obs;
     g.device_map = (c.device_map && c.resident_track && c.backend_on == 1) ? 1 : 0;
+    g.backend_lag = c.backend_lag > 0 ? c.backend_lag : 1;
     return g;
 }
 } // namespace

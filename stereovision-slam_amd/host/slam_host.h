@@ -64,6 +64,12 @@ struct Config {                       // config/stereo_slam_configs/config-00.ya
     // device memory and runs the whole keyframe path there (K::dmap_keyframe); the host keeps O(window) per stream —
     // the keyframes' ids, slots and poses.  Needs resident_track and backend_on == 1.
     int device_map = 0;
+    // backend_on >= 2: frames a submitted local BA may stay in flight before its result is applied.  1 = the result
+    // lands exactly one frame late (round 2).  The reference's backend thread takes several frame times (g2o on the
+    // CPU) and its result lands whenever it is done; a fixed lag keeps that overlap AND reproducibility: a lone
+    // camera's frame then costs the tracking chain only, the 1.3-ms BA of a keyframe runs beside the next frames.
+    // A new keyframe always collects the optimisation in flight first.
+    int backend_lag = 1;
 };
 
 enum class FrontendStatus { INITING = 0, TRACKING_GOOD = 1, TRACKING_BAD = 2, LOST = 3 };
@@ -470,9 +476,10 @@ public:
             for (int s : MS) ReleaseRetired(*streams_[s]);           // nothing in flight
             if (!MS.empty()) { BackendSubmit(MS); BackendCollect(); }
         } else if (cfg_.backend_on >= 2 && backend_enabled_) {
-            BackendCollect();                                        // may still touch frames retired this step
+            if (ba_inflight_ && (++ba_age_ >= std::max(1, cfg_.backend_lag) || !MS.empty()))
+                BackendCollect();                                    // may still touch frames retired this step
             for (int s : MS) ReleaseRetired(*streams_[s]);
-            if (!MS.empty()) BackendSubmit(MS);
+            if (!MS.empty()) { BackendSubmit(MS); ba_age_ = 0; }
         } else {
             BackendCollect();
             for (int s : MS) ReleaseRetired(*streams_[s]);
@@ -517,7 +524,20 @@ public:
         Stream &st = *streams_[s];
         std::ofstream pcd(dir + "/landmarks.pcd");
         if (!pcd) return false;
-        const std::vector<LandmarkRecord> all = st.map.AllLandmarks();
+        std::vector<LandmarkRecord> all = st.map.AllLandmarks();
+        if (device_map()) {
+            // the map lives in the provider's memory: the landmarks it still holds (those that left the window AND
+            // tracking were freed there; this mode keeps no archive of them), id-ascending
+            const int NL = cfg_.max_lm;
+            std::vector<int> id((size_t)NL), obs((size_t)NL);
+            std::vector<double> pos(3 * (size_t)NL);
+            std::vector<uint8_t> stt((size_t)NL);
+            check(k_.dmap_read(s, nullptr, nullptr, nullptr, nullptr, id.data(), pos.data(), obs.data(), stt.data()), "dmap_read");
+            all.clear();
+            for (int l = 0; l < NL; ++l)
+                if (id[(size_t)l] >= 0) all.push_back(LandmarkRecord{ id[(size_t)l], { pos[3 * (size_t)l], pos[3 * (size_t)l + 1], pos[3 * (size_t)l + 2] }, obs[(size_t)l], stt[(size_t)l] == 1 });
+            std::sort(all.begin(), all.end(), [](const LandmarkRecord &a, const LandmarkRecord &b) { return a.id < b.id; });
+        }
         const size_t n = all.size();
         pcd << "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\n"
             << "COUNT 1 1 1\nWIDTH " << n << "\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS " << n << "\nDATA ascii\n";
@@ -1294,6 +1314,7 @@ private:
     int dump_seq_ = 0;
     std::vector<int> ba_ms_;
     bool ba_inflight_ = false;
+    int ba_age_ = 0;
     int ba_ko_ = 0, ba_lo_ = 0, ba_oo_ = 0;
     long long st_[12] = { 0 };   // 0 begin 1 track-prep 2 track-finish 3 detect 4 right 5 tri 6 ba-gather 7 ba-scatter 8 end
     Config cfg_;
@@ -1314,7 +1335,7 @@ private:
     std::vector<svslam_ba_job> jobs_ba_;
     std::vector<svslam_dmap_job> jobs_dm_;
     std::vector<const void *> dm_left_, dm_right_;
-    int dm_chunk_ = 256;
+    int dm_chunk_ = 512;              // SVSLAM_DMAP_CHUNK of the provider
     std::vector<const void *> imgs_;
     std::vector<int> strides_;
     std::vector<float> prev_xy_, next_xy_, rects_, corners_, uv_l_, uv_r_, err_, ba_uv_;

@@ -18,7 +18,7 @@ class PipeConfig(C.Structure):
                 ("ext_l", C.c_double * 7), ("cam_r", C.c_double * 4), ("ext_r", C.c_double * 7),
                 ("max_lm", C.c_int), ("max_obs", C.c_int), ("host_threads", C.c_int),
                 ("src_width", C.c_int), ("src_height", C.c_int), ("resident_track", C.c_int),
-                ("low_latency", C.c_int), ("max_pts", C.c_int), ("device_map", C.c_int)]
+                ("low_latency", C.c_int), ("max_pts", C.c_int), ("device_map", C.c_int), ("backend_lag", C.c_int)]
 
 
 class FrameResult(C.Structure):
@@ -55,7 +55,7 @@ def default_config(width=620, height=188, cam=(359.428, 359.428, 303.5964, 92.60
     c.ext_l = (C.c_double * 7)(0, 0, 0, 1, 0, 0, 0)
     c.ext_r = (C.c_double * 7)(0, 0, 0, 1, -baseline, 0, 0)
     c.max_lm = 4096; c.max_obs = 16384; c.host_threads = 1
-    c.src_width = 0; c.src_height = 0; c.resident_track = 1; c.low_latency = 0; c.max_pts = 512; c.device_map = 0
+    c.src_width = 0; c.src_height = 0; c.resident_track = 1; c.low_latency = 0; c.max_pts = 512; c.device_map = 0; c.backend_lag = 1
     for k, v in kw.items():
         setattr(c, k, v)
     return c
