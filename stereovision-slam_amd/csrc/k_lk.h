@@ -331,36 +331,40 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // 2. Scharr at the 12x12 positions (ipx+c, ipy+r); zero outside the image
+        // 2. Scharr at the 12x12 positions (ipx+c, ipy+r); zero outside the image.  Packed 16-bit arithmetic: every
+        // intermediate fits 16 bits (|t0| <= 4080, |t1| <= 255, |dx|, |dy| <= 8160 < 2^15) and v_pk_add / v_pk_mad /
+        // v_pk_mul_lo / v_pk_sub issue in the same 4-cycle class as the 32-bit v_mad_i32_i24 they replace, two results
+        // each (tools/ubench_valu.hip, profiles/r3_ubench_valu_issue_rates.txt): ~35 instead of ~65 instructions.
         if (lane < 48) {
             const int ab = sr * LK_IROW + a0 + sc;      // top-left byte of the 3x5 block
             const int k8 = (ab & 3) * 8;
             const uint32_t *q = sI32 + (ab >> 2);
-            int t0[5], t1[5];
-            {
-                const uint32_t al = q[0], ah = q[1], bl = q[LK_IROW / 4], bh = q[LK_IROW / 4 + 1],
-                               cl = q[2 * (LK_IROW / 4)], ch = q[2 * (LK_IROW / 4) + 1];
-                const uint32_t a4 = __builtin_amdgcn_alignbyte(ah, al, ab & 3), b4 = __builtin_amdgcn_alignbyte(bh, bl, ab & 3),
-                               c4 = __builtin_amdgcn_alignbyte(ch, cl, ab & 3);
-                const int a5 = (int)((ah >> k8) & 0xff), b5 = (int)((bh >> k8) & 0xff), c5 = (int)((ch >> k8) & 0xff);
-#pragma unroll
-                for (int k = 0; k < 5; ++k) {
-                    const int a = k < 4 ? (int)((a4 >> (8 * k)) & 0xff) : a5;
-                    const int b = k < 4 ? (int)((b4 >> (8 * k)) & 0xff) : b5;
-                    const int c = k < 4 ? (int)((c4 >> (8 * k)) & 0xff) : c5;
-                    t0[k] = (a + c) * 3 + b * 10;
-                    t1[k] = c - a;
-                }
-            }
+            const uint32_t al = q[0], ah = q[1], bl = q[LK_IROW / 4], bh = q[LK_IROW / 4 + 1],
+                           cl = q[2 * (LK_IROW / 4)], ch = q[2 * (LK_IROW / 4) + 1];
+            const uint32_t a4 = __builtin_amdgcn_alignbyte(ah, al, ab & 3), b4 = __builtin_amdgcn_alignbyte(bh, bl, ab & 3),
+                           c4 = __builtin_amdgcn_alignbyte(ch, cl, ab & 3);
+            // bytes (0, 1), (2, 3), (4, -) of each row as u16 pairs
+            auto pr = [](uint32_t v) -> lk_s2 { return __builtin_bit_cast(lk_s2, v); };
+            const lk_s2 A01 = pr(__builtin_amdgcn_perm(0u, a4, 0x0c010c00u)), A23 = pr(__builtin_amdgcn_perm(0u, a4, 0x0c030c02u)), A4 = pr((ah >> k8) & 0xffu);
+            const lk_s2 B01 = pr(__builtin_amdgcn_perm(0u, b4, 0x0c010c00u)), B23 = pr(__builtin_amdgcn_perm(0u, b4, 0x0c030c02u)), B4 = pr((bh >> k8) & 0xffu);
+            const lk_s2 C01 = pr(__builtin_amdgcn_perm(0u, c4, 0x0c010c00u)), C23 = pr(__builtin_amdgcn_perm(0u, c4, 0x0c030c02u)), C4 = pr((ch >> k8) & 0xffu);
+            const lk_s2 k3 = { 3, 3 }, k10 = { 10, 10 };
+            // t0 = (a + c) 3 + 10 b (vertical [3 10 3]), t1 = c - a (vertical [-1 0 1]) for the five columns
+            const lk_s2 T001 = (A01 + C01) * k3 + B01 * k10, T023 = (A23 + C23) * k3 + B23 * k10, T04 = (A4 + C4) * k3 + B4 * k10;
+            const lk_s2 T101 = C01 - A01, T123 = C23 - A23, T14 = C4 - A4;
+            // dx_k = t0_{k+2} - t0_k; dy_k = (t1_{k+2} + t1_k) 3 + 10 t1_{k+1}
+            const lk_s2 DX01 = T023 - T001, DX2 = T04 - T023;
+            const lk_s2 M01 = pr(__builtin_amdgcn_alignbyte(__builtin_bit_cast(uint32_t, T123), __builtin_bit_cast(uint32_t, T101), 2));   // (t1_1, t1_2)
+            const lk_s2 M2 = pr(__builtin_amdgcn_alignbyte(__builtin_bit_cast(uint32_t, T14), __builtin_bit_cast(uint32_t, T123), 2));     // (t1_3, t1_4)
+            const lk_s2 DY01 = (T123 + T101) * k3 + M01 * k10, DY2 = (T14 + T123) * k3 + M2 * k10;
+            const uint32_t dx01 = __builtin_bit_cast(uint32_t, DX01), dy01 = __builtin_bit_cast(uint32_t, DY01);
+            const uint32_t o0 = __builtin_amdgcn_perm(dy01, dx01, 0x05040100u), o1 = __builtin_amdgcn_perm(dy01, dx01, 0x07060302u),
+                           o2 = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, DY2), __builtin_bit_cast(uint32_t, DX2), 0x05040100u);
             const bool rowin = (uint32_t)(ipy + sr) < (uint32_t)h;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int dx = t0[k + 2] - t0[k];
-                const int dy = (t1[k + 2] + t1[k]) * 3 + t1[k + 1] * 10;
-                // zero outside the image: a select on the packed pair, no divergent branch
-                const uint32_t inb = 0u - (uint32_t)(rowin & ((uint32_t)(ipx + sc + k) < (uint32_t)w));
-                sD[sr * 12 + sc + k] = (((uint32_t)dx & 0xffffu) | ((uint32_t)dy << 16)) & inb;
-            }
+            // zero outside the image: a select on the packed pair, no divergent branch
+            sD[sr * 12 + sc + 0] = o0 & (0u - (uint32_t)(rowin & ((uint32_t)(ipx + sc + 0) < (uint32_t)w)));
+            sD[sr * 12 + sc + 1] = o1 & (0u - (uint32_t)(rowin & ((uint32_t)(ipx + sc + 1) < (uint32_t)w)));
+            sD[sr * 12 + sc + 2] = o2 & (0u - (uint32_t)(rowin & ((uint32_t)(ipx + sc + 2) < (uint32_t)w)));
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -390,7 +394,17 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
         const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         const float dd = A11 - A22;
-        const float eigNum = A22 + A11 - sqrtf(dd * dd + 4.f * A12 * A12);
+        // The min-eigenvalue test is a comparison: the hardware square root (v_sqrt_f32, <= 1 ulp) decides unless the
+        // numerator lands within 4 ulp(sqrt) of the threshold; only then the correctly rounded sqrtf (16 instructions
+        // of fix-up) is evaluated — the decision is the oracle's bit for bit either way.
+        const float q2 = dd * dd + 4.f * A12 * A12;
+        float eigNum;
+        if (prm.eig_use_div) eigNum = A22 + A11 - sqrtf(q2);
+        else {
+            const float sq = __builtin_amdgcn_sqrtf(q2);
+            eigNum = A22 + A11 - sq;
+            if (fabsf(eigNum - prm.eig_num_thr) <= sq * 4.8e-7f + 1e-30f) eigNum = A22 + A11 - sqrtf(q2);
+        }
         const bool eigSmall = prm.eig_use_div ? (double)(eigNum / (float)(2 * LK_WIN * LK_WIN)) < prm.min_eig_thr : eigNum < prm.eig_num_thr;
         if (eigSmall || D < 1.1920928955078125e-07f) {
             if (level == 0) st = false;
