@@ -337,7 +337,7 @@ typedef struct svslam_dmap_job {
     double T_camr_w[7];    /* cam_right.pose * T_cw (src/camera.cpp:74)                                          */
     double T_wc[7];        /* inverse of pose (identity at init)                                                 */
     int    src_buf, dst_buf; /* filled by the library                                                            */
-    int    stamp, reserved0;
+    int    stamp, corners_dropped; /* stamp: filled by the library; corners_dropped: out, surplus corners not appended (max_pts) */
     /* out */
     int    ok;             /* init: enough stereo matches (otherwise nothing was created); keyframe: 1           */
     int    n_features, n_corners, n_right_ok, n_tri_in, n_tri_ok;

@@ -107,7 +107,7 @@ k_dmap_begin(DmJob *jobs, DMap m, RtStore rs)
     const int tid = threadIdx.x, s = jb.stream;
     if (tid == 0) {
         jb.ok = jb.is_init ? 0 : 1; jb.dead = 0; jb.flags = 0; jb.n_corners = jb.n_right_ok = jb.n_tri_in = jb.n_tri_ok = 0;
-        jb.ba_nkf = jb.ba_nlm = jb.ba_nobs = jb.ba_iters = 0; jb.n_features = jb.npts;
+        jb.ba_nkf = jb.ba_nlm = jb.ba_nobs = jb.ba_iters = 0; jb.n_features = jb.npts; jb.pad0 = 0;
     }
     if (jb.is_init) return;
     const size_t L = dm_l(m, s);
@@ -156,7 +156,11 @@ k_dmap_stereo_prep(DmJob *jobs, DMap m, DmParams prm, const float2 *corners, con
     const size_t F = dm_f(m, s, jb.kf_slot), L = dm_l(m, s);
     int take = ncorners[j];
     const int room = m.NF - jb.npts;
-    if (take > room) { if (tid == 0) jb.flags |= DM_FLAG_CORNERS_DROPPED; take = room > 0 ? room : 0; }
+    if (take > room) {                                   // capacity of the keyframe's feature list: surplus corners (the weakest) are dropped
+        const int kept = room > 0 ? room : 0;
+        if (tid == 0) { jb.flags |= DM_FLAG_CORNERS_DROPPED; jb.pad0 = take - kept; }
+        take = kept;
+    }
     for (int c = tid; c < take; c += DM_THREADS) {
         m.f_xy[F + jb.npts + c] = corners[(size_t)j * max_corners + c];
         m.f_lm[F + jb.npts + c] = -1; m.f_lmr[F + jb.npts + c] = -1; m.f_fl[F + jb.npts + c] = 0;

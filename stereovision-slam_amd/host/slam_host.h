@@ -716,7 +716,7 @@ private:
             cnt_.gftt_calls++; cnt_.gftt_rects += j.npts; cnt_.right_pts += j.n_features; cnt_.pyr_right++;
             st.c_corners += j.n_corners;
             if (init) cnt_.pyr_left++;
-            if (j.flags & 1) st.c_dropped++;
+            st.c_dropped += j.corners_dropped;
             st.dev_feat = j.n_features;
             if (init) {
                 if (!j.ok) continue;                                  // StereoInit failed (:227): try again with the next frame

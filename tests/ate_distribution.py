@@ -27,7 +27,7 @@ for p_ in (ROOT, os.path.join(ROOT, "tests")):  # (this file lives in tests/: it
 W, H = 620, 188
 
 
-def run(n_streams=48, n_frames=320, seed0=0x5EED1000, chunk=80, threads=None, device=0, twin_jacobians="numeric"):
+def run(n_streams=48, n_frames=320, seed0=0x5EED1000, chunk=80, threads=None, device=0, twin_jacobians="numeric", device_map=1):
     """returns dict(ate_hip, ate_twin, ate_between, path_len) as arrays over streams.  twin_jacobians: "numeric"
     (g2o's central differences, what the reference runs) or "analytic" (isolates the effect of that choice)"""
     import pipe_cpu
@@ -39,7 +39,8 @@ def run(n_streams=48, n_frames=320, seed0=0x5EED1000, chunk=80, threads=None, de
         os.environ.pop("SVS_ORACLE_BA_JAC", None)                 # twin: numeric Jacobians (reference-faithful)
     seeds = [seed0 + i for i in range(n_streams)]
     threads = threads or max(1, min(n_streams, len(os.sched_getaffinity(0))))
-    gpu = pl.Pipeline(pl.default_config(W, H, host_threads=min(4, threads)), nstreams=n_streams, device=device)
+    # (device_map: the map of every stream in HBM, the bench's default; bit-identical to the host-resident map)
+    gpu = pl.Pipeline(pl.default_config(W, H, host_threads=min(4, threads), device_map=device_map), nstreams=n_streams, device=device)
     ctx = svs.Context.borrow(gpu.kernel_ctx(), W, H)
     twins = [pipe_cpu.make(nstreams=1) for _ in seeds]
     img = W * H
