@@ -580,7 +580,11 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
     double *PTab = red + BA_WAVES;
     double *CTab = PTab + BA_PT * na;
     double *PTab2 = CTab + 2 * BA_CT;              // pose table of the trial state (errors of the trial, see the back-substitution)
-    double *part = PTab2 + BA_PT * na;             // [BA_ROWS][32] row partial sums (pose pass, single-view pass: 27 used)
+    // Hpp / bp of the TRIAL state (MODE 0: copied over Hpp / bp when the trial is accepted): in the reduced system's
+    // storage, which is dead between the back-substitution and the next trial's S initialisation
+    double *Hpp2 = S;
+    double *bp2 = Hpp2 + 36 * na;
+    double *part = PTab2 + BA_PT * na;             // [BA_ROWS][32] row partial sums (pose pass, single-view pass: 28 used)
     double *Wt = part + 32 * BA_ROWS;              // [tile_cap][18] blocks of the current tile
     double *Dl = Wt + 18 * tile_cap;               // [tile_cap][6]  (Hll + lambda I)^-1, symmetric
     double *Bl = Dl + 6 * tile_cap;                // [tile_cap][3]  bl
@@ -679,6 +683,73 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
         return block_sum(chi, red, tid);
     };
 
+    // ---- pose pass at a state (positions `psrc`, pose table `tab`): Hpp (block diagonal), bp -> `Hout`, `bout`, and the
+    // robust chi2 of the state (identical in every thread).  16-lane rows; pose a is shared by the rows a, a + na,
+    // a + 2 na ... (< BA_ROWS); 27 normal-equation sums + chi2 ride one recursive-halving butterfly per row, the rows of a
+    // pose are added in row order.  Round 3: the SAME pass evaluates an LM trial (it needs the projections anyway) — an
+    // accepted trial hands its Hpp / bp / pose table to the next iteration, which then starts at the single-view pass:
+    // one sweep over the edges per trial less (the separate error pass) and no per-edge residual array.
+    auto pose_pass = [&](const double *psrc, const double *tab, double *Hout, double *bout) -> double {
+        BA_PHASE_TID;
+        const int row = tid >> 4, rl = tid & 15;
+        const int rpp = BA_ROWS / na;                 // rows per pose (>= 1: na <= 32)
+        double acc[32];
+#pragma unroll
+        for (int t = 0; t < 32; ++t) acc[t] = 0;
+        const int a = row % na, sub = row / na;
+        if (sub < rpp) {
+            const int k = act_kf[a];
+            const int i0 = kf_estart[k] + sub * 16 + rl, i1 = kf_estart[k + 1], ist = 16 * rpp;
+            BaRec rc = recP[min(i0, nobs - 1)];            // software pipeline: record two edges ahead, position one ahead
+            BaRec rn = recP[min(i0 + ist, nobs - 1)];
+            double X[3];
+            { const double *Xp = psrc + 3 * (size_t)(rc.lmkc & BA_LM_MASK); X[0] = Xp[0]; X[1] = Xp[1]; X[2] = Xp[2]; }
+            for (int i = i0; i < i1; i += ist) {
+                const BaRec rnn = recP[min(i + 2 * ist, nobs - 1)];
+                const double *Xq = psrc + 3 * (size_t)(rn.lmkc & BA_LM_MASK);
+                const double Xn[3] = { Xq[0], Xq[1], Xq[2] };
+                const int kc = (unsigned)rc.lmkc >> 24;
+                const double *CT = CTab + BA_CT * (kc & 1);
+                BaProj o;
+                ba_project(tab + BA_PT * a, CT, X, rc.u, rc.v, o);
+                double r0, w;
+                d_huber(o.ex * o.ex + o.ey * o.ey, delta, r0, w);
+                acc[27] += r0;
+                double M[6], jp[12];
+                ba_jac_pose(CT, o, M, jp);
+                int t = 0;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    const double w0 = w * jp[r], w1 = w * jp[6 + r];
+#pragma unroll
+                    for (int c = r; c < 6; ++c) { acc[t] += w0 * jp[c] + w1 * jp[6 + c]; ++t; }
+                    acc[21 + r] -= w0 * o.ex + w1 * o.ey;
+                }
+                rc = rn; rn = rnn; X[0] = Xn[0]; X[1] = Xn[1]; X[2] = Xn[2];
+            }
+        }
+        const int code = ba_row_sum32(acc, lane);
+        __syncthreads();                              // `part` may still be read by the previous phase
+        reinterpret_cast<double2 *>(part + 32 * row)[code] = make_double2(acc[0], acc[1]);
+        __syncthreads();
+        for (int z = tid; z < 27 * na; z += BA_THREADS) {
+            const int a2 = z / 27, t = z - a2 * 27;
+            double v = 0;
+            for (int sb = 0; sb < rpp; ++sb) v += part[(sb * na + a2) * 32 + t];
+            if (t < 21) {
+                int r = 0, rem = t;
+                while (rem >= 6 - r) { rem -= 6 - r; ++r; }
+                const int c = r + rem;
+                Hout[36 * a2 + r * 6 + c] = v; Hout[36 * a2 + c * 6 + r] = v;
+            } else bout[6 * a2 + (t - 21)] = v;
+        }
+        double chi = 0;
+#pragma unroll
+        for (int r = 0; r < BA_ROWS; ++r) chi += part[r * 32 + 27];
+        __syncthreads();
+        return chi;
+    };
+
     double lambda = MODE == 1 ? sba.lambda : 0, ni = 2;
     int it_done = 0;
     const int npairs = na * (na + 1) / 2;
@@ -691,66 +762,15 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
     }
     if (MODE == 1 && sba.phase == 5) iters = 0;            // finalise: straight to the write-back
     const bool lin = MODE == 0 || sba.phase <= 2;          // this launch linearises (pose pass, Schur sweep)
+    // last state whose residuals were evaluated (g2o reports the edge chi2 of its last computeActiveErrors, the state of
+    // the last trial even when that trial was rejected): the per-edge chi2 are computed from it at the end (MODE 0)
+    const double *last_pts = cur, *last_poses = pcur;
+    bool have_lin = false;                             // MODE 0: Hpp / bp / PTab of `cur` are in place (left by the accepted trial)
     for (int it = 0; it < iters; ++it) {
-        pose_table();
-        // ---- pose pass: Hpp (block diagonal), bp -> LDS.  16-lane rows; pose a is shared by
-        // the rows a, a + na, a + 2 na ... (< BA_ROWS), partial sums combined in row order
-        if (lin) {
-            BA_PHASE_TID;
-            const int row = tid >> 4, rl = tid & 15;
-            const int rpp = BA_ROWS / na;                 // rows per pose (>= 1: na <= 32)
-            double acc[27];
-#pragma unroll
-            for (int t = 0; t < 27; ++t) acc[t] = 0;
-            const int a = row % na, sub = row / na;
-            if (sub < rpp) {
-                const int k = act_kf[a];
-                const int i0 = kf_estart[k] + sub * 16 + rl, i1 = kf_estart[k + 1], ist = 16 * rpp;
-                BaRec rc = recP[min(i0, nobs - 1)];            // software pipeline as in the error pass
-                BaRec rn = recP[min(i0 + ist, nobs - 1)];
-                double X[3];
-                { const double *Xp = cur + 3 * (size_t)(rc.lmkc & BA_LM_MASK); X[0] = Xp[0]; X[1] = Xp[1]; X[2] = Xp[2]; }
-                for (int i = i0; i < i1; i += ist) {
-                    const BaRec rnn = recP[min(i + 2 * ist, nobs - 1)];
-                    const double *Xq = cur + 3 * (size_t)(rn.lmkc & BA_LM_MASK);
-                    const double Xn[3] = { Xq[0], Xq[1], Xq[2] };
-                    const int kc = (unsigned)rc.lmkc >> 24;
-                    const double *CT = CTab + BA_CT * (kc & 1);
-                    BaProj o;
-                    ba_project(PTab + BA_PT * a, CT, X, rc.u, rc.v, o);
-                    double r0, w;
-                    d_huber(o.ex * o.ex + o.ey * o.ey, delta, r0, w);
-                    double M[6], jp[12];
-                    ba_jac_pose(CT, o, M, jp);
-                    int t = 0;
-#pragma unroll
-                    for (int r = 0; r < 6; ++r) {
-                        const double w0 = w * jp[r], w1 = w * jp[6 + r];
-#pragma unroll
-                        for (int c = r; c < 6; ++c) { acc[t] += w0 * jp[c] + w1 * jp[6 + c]; ++t; }
-                        acc[21 + r] -= w0 * o.ex + w1 * o.ey;
-                    }
-                    rc = rn; rn = rnn; X[0] = Xn[0]; X[1] = Xn[1]; X[2] = Xn[2];
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < 27; ++t) acc[t] = row_sum_f64(acc[t]);
-            if (rl == 0) {
-#pragma unroll
-                for (int t = 0; t < 27; ++t) part[row * 32 + t] = acc[t];
-            }
-            __syncthreads();
-            for (int z = tid; z < 27 * na; z += BA_THREADS) {
-                const int a2 = z / 27, t = z - a2 * 27;
-                double v = 0;
-                for (int sb = 0; sb < rpp; ++sb) v += part[(sb * na + a2) * 32 + t];
-                if (t < 21) {
-                    int r = 0, rem = t;
-                    while (rem >= 6 - r) { rem -= 6 - r; ++r; }
-                    const int c = r + rem;
-                    Hpp[36 * a2 + r * 6 + c] = v; Hpp[36 * a2 + c * 6 + r] = v;
-                } else bp[6 * a2 + (t - 21)] = v;
-            }
+        double chi_lin = 0;
+        if (!have_lin) {
+            pose_table();
+            if (lin) chi_lin = pose_pass(cur, PTab, Hpp, bp);
         }
         __syncthreads();
         BA_PROF(1);
@@ -779,7 +799,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
             lambda = 1e-5 * md; ni = 2;
         }
         double tempChi = 0;
-        bool have_chi = it > 0;       // after the first iteration currentChi carries over from the accepted trial
+        if (!have_lin && lin) currentChi = chi_lin;      // (afterwards currentChi carries over from the accepted trial)
         double rho = 0; int qmax = 0;
         do {
             // backup, S = blockdiag(Hpp) + lambda I, bs = bp
@@ -800,7 +820,6 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
             }
             __syncthreads();
             BA_PROF(2);
-            double chi_part = 0;
             // ---- single-view landmarks (most of a local window): one block each, so all they change is S(a, a)
             // and bs(a) of their pose.  No LDS tile: a lane linearises its landmark (one or two edges), forms W,
             // (Hll + lambda I)^-1 and Y = W Dinv in registers and adds Y W^T (21 sums) and Y bl (6) to its own
@@ -833,7 +852,6 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                             const int kc = (unsigned)rc.lmkc >> 24;
                             BaLin L;
                             ba_linearize(PT, CTab + BA_CT * (kc & 1), X, rc.u, rc.v, delta, L);
-                            if (!have_chi) { err[2 * i] = L.ex; err[2 * i + 1] = L.ey; chi_part += L.rho; }
                             const double wl0 = L.w * L.jl[0], wl1 = L.w * L.jl[1], wl2 = L.w * L.jl[2],
                                          wl3 = L.w * L.jl[3], wl4 = L.w * L.jl[4], wl5 = L.w * L.jl[5];
 #pragma unroll
@@ -914,7 +932,6 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                         const int kc = (unsigned)rc.lmkc >> 24;
                         BaLin L;
                         ba_linearize(PTab + BA_PT * (kc >> 1), CTab + BA_CT * (kc & 1), X, rc.u, rc.v, delta, L);
-                        if (!have_chi) { err[2 * i] = L.ex; err[2 * i + 1] = L.ey; chi_part += L.rho; }
                         const double wl0 = L.w * L.jl[0], wl1 = L.w * L.jl[1], wl2 = L.w * L.jl[2],
                                      wl3 = L.w * L.jl[3], wl4 = L.w * L.jl[4], wl5 = L.w * L.jl[5];
 #pragma unroll
@@ -994,7 +1011,6 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                 __syncthreads();
                 BA_PROF(9);
             }
-            if (!have_chi) { currentChi = block_sum(chi_part, red, tid); have_chi = true; }
             tempChi = currentChi;
             BA_PROF(3);
             if (MODE == 1 && sba.phase == 2) {                 // hand the partial sums to the host
@@ -1236,7 +1252,14 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
             __syncthreads();
             BA_PROF(5);
             // (a failed factorisation updates nothing: its errors are those of the unchanged state, like the oracle's)
-            tempChi = ok2 ? error_pass(trial, ptrial) : error_pass(cur, pcur);
+            if (MODE == 1) tempChi = ok2 ? error_pass(trial, ptrial) : error_pass(cur, pcur);
+            else if (ok2) {
+                // the trial state's chi2 from the pose pass of the trial state: its Hpp / bp / pose table are the next
+                // iteration's if the trial is accepted
+                pose_table_into(PTab2, ptrial);
+                tempChi = pose_pass(trial, PTab2, Hpp2, bp2);
+                last_pts = trial; last_poses = ptrial;
+            } else { last_pts = cur; last_poses = pcur; }
             BA_PROF(6);
             if (MODE == 1) {                                   // the host sums the partials and runs the rho test
                 if (tid == 0) { sio_sc[2] = (double)ok2; sio_sc[3] = scale; sio_sc[4] = scale_pose; sio_sc[5] = tempChi; }
@@ -1253,7 +1276,12 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                 alpha = fmin(alpha, 2. / 3.);
                 double sf = fmax(1. / 3., alpha);
                 lambda *= sf; ni = 2; currentChi = tempChi;
-                if (ok2) { double *t_ = cur; cur = trial; trial = t_; t_ = pcur; pcur = ptrial; ptrial = t_; }   // MODE 0 only gets here
+                if (ok2) {                                 // MODE 0 only gets here: the trial state becomes the current one
+                    double *t_ = cur; cur = trial; trial = t_; t_ = pcur; pcur = ptrial; ptrial = t_;
+                    t_ = PTab; PTab = PTab2; PTab2 = t_;
+                    for (int i = tid; i < 36 * na + np; i += BA_THREADS) Hpp[i] = Hpp2[i];   // bp follows Hpp, bp2 follows Hpp2
+                    have_lin = true;
+                }
             } else {
                 lambda *= ni; ni *= 2;                     // rejected: `cur` was never touched
                 if (!isfinite(lambda)) break;
@@ -1265,7 +1293,28 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
         if (qmax == 10 || rho == 0 || !isfinite(lambda)) break;
     }
     __syncthreads();
-    for (int i = tid; i < nobs; i += BA_THREADS) edge_chi2[lm_edges[i]] = err[2 * i] * err[2 * i] + err[2 * i + 1] * err[2 * i + 1];
+    if (MODE == 1) {
+        for (int i = tid; i < nobs; i += BA_THREADS) edge_chi2[lm_edges[i]] = err[2 * i] * err[2 * i] + err[2 * i + 1] * err[2 * i + 1];
+    } else {
+        // per-edge chi2 of the last evaluated state (see last_pts): one sweep at the end instead of a residual array
+        // rewritten by every trial
+        pose_table_into(PTab2, last_poses);
+        BA_PHASE_TID;
+        BaRec rc = recL[min(tid, nobs - 1)];
+        BaRec rn = recL[min(tid + BA_THREADS, nobs - 1)];
+        double X[3];
+        { const double *Xp = last_pts + 3 * (size_t)(rc.lmkc & BA_LM_MASK); X[0] = Xp[0]; X[1] = Xp[1]; X[2] = Xp[2]; }
+        for (int i = tid; i < nobs; i += BA_THREADS) {
+            const BaRec rnn = recL[min(i + 2 * BA_THREADS, nobs - 1)];
+            const double *Xq = last_pts + 3 * (size_t)(rn.lmkc & BA_LM_MASK);
+            const double Xn[3] = { Xq[0], Xq[1], Xq[2] };
+            const int kc = (unsigned)rc.lmkc >> 24;
+            BaProj o;
+            ba_project(PTab2 + BA_PT * (kc >> 1), CTab + BA_CT * (kc & 1), X, rc.u, rc.v, o);
+            edge_chi2[lm_edges[i]] = o.ex * o.ex + o.ey * o.ey;
+            rc = rn; rn = rnn; X[0] = Xn[0]; X[1] = Xn[1]; X[2] = Xn[2];
+        }
+    }
     for (int j = tid; j < nlm; j += BA_THREADS) {
         double *d3 = pts_io + 3 * (size_t)lm_orig[j];
         d3[0] = cur[3 * (size_t)j]; d3[1] = cur[3 * (size_t)j + 1]; d3[2] = cur[3 * (size_t)j + 2];
