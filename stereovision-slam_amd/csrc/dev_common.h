@@ -203,6 +203,16 @@ __device__ __forceinline__ void d_se3_mul(const double *A, const double *B, doub
 // sin and cos for the rotation steps of an LM update: |x| < 0.5 almost always, where the Taylor
 // sums below are exact to the last place or two (truncation x^19/19!, x^18/18! < 1e-21); the
 // library routine (argument reduction, several branches) is only the fallback.
+// 1 / x: hardware estimate + two Newton steps (<= 1 ulp of the correctly rounded quotient).  The IEEE division expands to
+// a dozen dependent instructions; the LM kernels have several on the serial critical path of every trial.  0, inf, NaN
+// and denormals (estimate inf) keep the raw estimate, i.e. what the division returns.
+__device__ __forceinline__ double d_rcp1(double x)
+{
+    const double r0 = __builtin_amdgcn_rcp(x);
+    double r = __builtin_fma(__builtin_fma(-x, r0, 1.0), r0, r0);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return (fabs(r0) < __builtin_inf() && r0 != 0.0) ? r : r0;
+}
 __device__ __forceinline__ void d_sincos_small(double x, double &s, double &c)
 {
     if (fabs(x) < 0.5) {
@@ -243,7 +253,7 @@ __device__ __forceinline__ void d_se3_exp(const double *xi, double *T)
         theta = sqrt(th2);
         double sh, ch;
         d_sincos_small(0.5 * theta, sh, ch);
-        imag = sh / theta;
+        imag = sh * d_rcp1(theta);
         real = ch;
     }
     T[0] = imag * om[0]; T[1] = imag * om[1]; T[2] = imag * om[2]; T[3] = real;
@@ -253,8 +263,8 @@ __device__ __forceinline__ void d_se3_exp(const double *xi, double *T)
     } else {
         double st, ct;
         d_sincos_small(theta, st, ct);
-        double a = (1.0 - ct) / th2;
-        double b = (theta - st) / (th2 * theta);
+        double a = (1.0 - ct) * d_rcp1(th2);
+        double b = (theta - st) * d_rcp1(th2 * theta);
         double O[9] = { 0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0 };
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -275,7 +285,15 @@ __device__ __forceinline__ void d_huber(double e2, double delta, double &rho0, d
 {
     double dsqr = delta * delta;
     if (e2 <= dsqr) { rho0 = e2; rho1 = 1.0; }
-    else { double sq = sqrt(e2); rho0 = 2 * sq * delta - dsqr; rho1 = delta / sq; }
+    else if (e2 < 1e300) {
+        // 1 / sqrt(e2): hardware estimate + two Newton steps, one correction of the root (e2 > delta^2: normal range)
+        double y = __builtin_amdgcn_rsq(e2);
+        y = y * (1.5 - 0.5 * e2 * y * y);
+        y = y * (1.5 - 0.5 * e2 * y * y);
+        double sq = e2 * y;
+        sq = __builtin_fma(__builtin_fma(-sq, sq, e2), 0.5 * y, sq);
+        rho0 = 2 * sq * delta - dsqr; rho1 = delta * y;
+    } else { double sq = sqrt(e2); rho0 = 2 * sq * delta - dsqr; rho1 = delta / sq; }
 }
 #pragma clang fp contract(off)
 

@@ -110,7 +110,12 @@ __device__ __forceinline__ bool d_ldlt6(const double *H, const double *b, double
         for (int j = 0; j < k; ++j) dk -= L[k][j] * L[k][j] * D[j];
         D[k] = dk;
         ok = ok && (dk > 0);
-        const double inv = 1.0 / dk;
+        // reciprocal of the pivot: hardware estimate + two Newton steps (<= 1 ulp from the quotient; the six divisions sit
+        // on the serial critical path of every LM trial).  A non-positive / denormal pivot gives inf or NaN here like the
+        // division would downstream: the trial is rejected by the finiteness test on its chi2 either way.
+        double inv = __builtin_amdgcn_rcp(dk);
+        inv = __builtin_fma(__builtin_fma(-dk, inv, 1.0), inv, inv);
+        inv = __builtin_fma(__builtin_fma(-dk, inv, 1.0), inv, inv);
         Dinv[k] = inv;
 #pragma unroll
         for (int i = k + 1; i < 6; ++i) {
@@ -150,7 +155,7 @@ __device__ __forceinline__ void po_error(const double *cam, const double *T, con
     d_se3_act(T, P, pc);
     double px = cam[0] * pc[0] + cam[2] * pc[2];
     double py = cam[1] * pc[1] + cam[3] * pc[2];
-    const double iz = 1.0 / pc[2];              // one reciprocal instead of two divisions (<= 1 ulp apart)
+    const double iz = d_rcp1(pc[2]);            // one reciprocal instead of two divisions (<= 1 ulp apart)
     e0 = u - px * iz;
     e1 = v - py * iz;
 }
@@ -244,6 +249,14 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
     PoseJob &jb = jobs[blockIdx.x];
     const int tid = threadIdx.x;
     const int n = jb.npts;
+#ifdef PO_PROF     // development: clock ticks (100 MHz) per phase as two extra trace records
+    long long po_t = wall_clock64(), po_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#define PO_TICK(i) do { long long t_ = wall_clock64(); po_acc[i] += t_ - po_t; po_t = t_; } while (0)
+#define PO_TICKV(i, val) do { asm volatile("" :: "v"(val)); PO_TICK(i); } while (0)      // the phase's result is there first
+#else
+#define PO_TICK(i) do { } while (0)
+#define PO_TICKV(i, val) do { } while (0)
+#endif
     const double cam[4] = { cam4[0], cam4[1], cam4[2], cam4[3] };
     double T0[7], T[7];
 #pragma unroll
@@ -283,6 +296,7 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
             for (int it = 0; it < iters; ++it) {
                 // errors + chi2 + normal equations at T: acc[0..20] upper triangle of H, [21..26] b, [27] chi2
                 double acc[32];
+                PO_TICK(5);
 #pragma unroll
                 for (int i = 0; i < 32; ++i) acc[i] = 0;
 #pragma unroll
@@ -292,14 +306,14 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
                     d_se3_act(T, P[s], pc);
                     double X = pc[0], Y = pc[1], Z = pc[2];
                     double px = cam[0] * X + cam[2] * Z, py = cam[1] * Y + cam[3] * Z;
-                    const double iz = 1.0 / Z;
+                    const double iz = d_rcp1(Z);
                     double ex = mu[s] - px * iz, ey = mv[s] - py * iz;
                     e0[s] = ex; e1[s] = ey;
                     double e2 = ex * ex + ey * ey, w = 1.0, rho = e2;
                     if (robust) d_huber(e2, 1.0, rho, w);
                     acc[27] += rho;
                     const double Ze = Z + 1e-18;                       // g2o_types.h:159 (== Z unless |Z| < ~0.01)
-                    double Zinv = Ze == Z ? iz : 1.0 / Ze, Zinv2 = Zinv * Zinv;
+                    double Zinv = Ze == Z ? iz : d_rcp1(Ze), Zinv2 = Zinv * Zinv;
                     double fx = cam[0], fy = cam[1];
                     double J0[6] = { -fx * Zinv, 0, fx * X * Zinv2, fx * X * Y * Zinv2, -fx - fx * X * X * Zinv2, fx * Y * Zinv };
                     double J1[6] = { 0, -fy * Zinv, fy * Y * Zinv2, fy + fy * Y * Y * Zinv2, -fy * X * Y * Zinv2, -fy * X * Zinv };
@@ -312,7 +326,9 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
 #pragma unroll
                     for (int a = 0; a < 6; ++a) acc[21 + a] -= w * (J0[a] * ex + J1[a] * ey);
                 }
+                PO_TICKV(0, acc[0] + acc[27]);
                 po_block_sum32<WAVES>(acc, s_red, tid);
+                PO_TICKV(1, acc[27] + acc[0]);
                 double currentChi = acc[27];
                 double H[36], b[6];
                 {
@@ -341,12 +357,15 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
                     for (int i = 0; i < 36; ++i) Hl[i] = H[i];
 #pragma unroll
                     for (int a = 0; a < 6; ++a) Hl[a * 7] += lambda;
+                    PO_TICK(5);
                     bool ok2 = d_ldlt6(Hl, b, x);
+                    PO_TICKV(2, x[0] + x[5]);
                     double dT[7], Tn[7];
                     d_se3_exp(x, dT);
                     d_se3_mul(dT, T, Tn);
 #pragma unroll
                     for (int i = 0; i < 7; ++i) T[i] = Tn[i];
+                    PO_TICKV(3, T[0] + T[6]);
                     double tchi = 0;
 #pragma unroll
                     for (int s = 0; s < SLOTS; ++s) {
@@ -356,8 +375,10 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
                         if (robust) d_huber(e2, 1.0, rr, w);
                         tchi += rr;
                     }
+                    PO_TICKV(4, tchi);
                     // two alternating buffers: a rejected trial writes again before the next barrier
                     double tempChi = po_block_sum1<WAVES>(tchi, s_one[one], tid);
+                    PO_TICKV(6, tempChi);
                     one ^= 1;
                     if (!ok2) tempChi = 1.7976931348623157e308;
                     rho = currentChi - tempChi;
@@ -365,7 +386,7 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
 #pragma unroll
                     for (int a = 0; a < 6; ++a) scale += x[a] * (lambda * x[a] + b[a]);
                     scale += 1e-3;
-                    rho /= scale;
+                    rho *= d_rcp1(scale);
                     if (trace && tid == 0) lm_trace_put(trace, blockIdx.x, 16 * r + it, lambda, currentChi, tempChi, rho, rho > 0 && isfinite(tempChi));
                     if (rho > 0 && isfinite(tempChi)) {
                         double t = 2 * rho - 1;
@@ -380,6 +401,7 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
                         if (!isfinite(lambda)) break;
                     }
                     ++qmax;
+                    PO_TICKV(7, lambda + rho);
                 } while (rho < 0 && qmax < 10);
                 if (qmax == 10 || rho == 0 || !isfinite(lambda)) break;
             }
@@ -406,7 +428,16 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
 #pragma unroll
         for (int i = 0; i < 7; ++i) jb.pose[i] = T[i];
         jb.n_inlier = n_edges - cnt_outlier;
+#ifdef PO_PROF
+        PO_TICK(5);
+        if (trace) {
+            lm_trace_put(trace, blockIdx.x, -1, (double)po_acc[0], (double)po_acc[1], (double)po_acc[2], (double)po_acc[3], false);
+            lm_trace_put(trace, blockIdx.x, -2, (double)po_acc[4], (double)po_acc[5], (double)po_acc[6], (double)po_acc[7], false);
+        }
+#endif
     }
+#undef PO_TICK
+#undef PO_TICKV
 }
 
 // ------------------------------------------------------------------ fused-track filter

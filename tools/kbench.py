@@ -148,6 +148,10 @@ if __name__ == "__main__":
         gfttbench(); sys.exit(0)
     if what == "ba1":        # the captured pipeline problem: alone and 256 at a time, with the phase profile
         ba(1, 0, 0, reps=2); ba(256, 0, 0, reps=2); sys.exit(0)
+    if what == "ba2":        # chip throughput of the BA kernel: more problems than CUs
+        for nj in (256, 512, 1024):
+            ba(nj, 0, 0, reps=2)
+        sys.exit(0)
     if what == "tput":       # chip-time per family at bench scale
         for nj in (1, 64, 256, 512):
             ba(nj, 0, 0, reps=2)
