@@ -313,3 +313,18 @@ __device__ __forceinline__ void lm_trace_put(double *trace_all, int job, double 
     r[0] = it; r[1] = lambda; r[2] = chi0; r[3] = chi1; r[4] = rho; r[5] = accepted ? 1.0 : 0.0;
     t[0] = (double)(n + 1);
 }
+// the records with lo <= iteration < hi once more, iteration + add (a pose-only round that repeats the previous one)
+__device__ __forceinline__ void lm_trace_replay(double *trace_all, int job, int lo, int hi, int add)
+{
+    double *t = trace_all + (size_t)job * LM_TRACE_STRIDE;
+    const int n = (int)t[0];
+    int m = n;
+    for (int i = 0; i < n && m < LM_TRACE_CAP; ++i) {
+        const double *r = t + 8 + LM_TRACE_REC * i;
+        if (r[0] < lo || r[0] >= hi) continue;
+        double *w = t + 8 + LM_TRACE_REC * m;
+        w[0] = r[0] + add; w[1] = r[1]; w[2] = r[2]; w[3] = r[3]; w[4] = r[4]; w[5] = r[5];
+        ++m;
+    }
+    t[0] = (double)m;
+}

@@ -284,7 +284,18 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
     for (int s = 0; s < SLOTS; ++s) n_edges += valid[s] ? 1 : 0;
     n_edges = po_block_sum_i32<WAVES>(n_edges, s_int, tid);
 
+    // A round restarts from T0 with the outlier flags of the previous classification and the robust flag: when that
+    // classification changed no flag and the robust flag is the same, the round repeats the previous one operation for
+    // operation (g2o recomputes lambda_0 from scratch in every optimize(), src/frontend.cpp:482-493) and ends in the
+    // same pose, the same residuals and the same classification — it is not executed again.  In steady tracking rounds
+    // 1 and 2 see the same outlier set, i.e. three rounds run instead of four; bit-identical results by construction.
+    bool same_as_prev = false;
     for (int r = 0; r < rounds; ++r) {
+        if (same_as_prev) {                    // (the flags stay unchanged again, so a further round repeats too)
+            if (trace && tid == 0) lm_trace_replay(trace, blockIdx.x, 16 * (r - 1), 16 * r, 16);
+            if (r == 2) { robust = false; same_as_prev = false; }
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < 7; ++i) T[i] = T0[i];
         int nact = 0;
@@ -413,10 +424,13 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
             if (!valid[s]) continue;
             if (outl[s]) po_error(cam, T, P[s], mu[s], mv[s], e0[s], e1[s]);
             double chi2 = e0[s] * e0[s] + e1[s] * e1[s];
-            outl[s] = chi2 > chi2_th;
-            co += outl[s] ? 1 : 0;
+            const bool now = chi2 > chi2_th;
+            co += (now ? 1 : 0) + (now != outl[s] ? 1 << 16 : 0);       // outliers | flags changed << 16 (<= 512 edges)
+            outl[s] = now;
         }
-        cnt_outlier = po_block_sum_i32<WAVES>(co, s_int, tid);
+        co = po_block_sum_i32<WAVES>(co, s_int, tid);
+        cnt_outlier = co & 0xffff;
+        same_as_prev = (co >> 16) == 0 && r != 2;                       // (round 3 drops the robust kernel: never a repeat)
         if (r == 2) robust = false;
     }
 #pragma unroll
