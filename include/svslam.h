@@ -344,6 +344,7 @@ typedef struct svslam_dmap_job {
     int    ba_nkf, ba_nlm, ba_nobs, ba_iters;
     int    flags;          /* 1 corners dropped (max_pts), 2 landmark slots exhausted, 4 BA skipped (max_obs)    */
     int    dead;
+    int    ev_ofs, ev_n;   /* the landmarks this job freed: records [ev_ofs, ev_ofs + ev_n) of svslam_dmap_evicted()    */
     double win_pose[12][7];/* poses of the BA problem's keyframes after the solve ...                            */
     int    win_slot[12];   /* ... and their slots                                                                */
 } svslam_dmap_job;
@@ -357,6 +358,12 @@ int svslam_dmap_keyframe_batch(svslam_ctx *ctx, int njobs, svslam_dmap_job *jobs
                                const void *const *left_imgs, const void *const *right_imgs, const int *strides,
                                int src_is_device, const double cam_l[4], const double ext_l[7],
                                const double cam_r[4], const double ext_r[7], const svslam_dmap_params *p);
+/* The landmarks the LAST svslam_dmap_keyframe_batch freed from the device map (no observation left, outside the window,
+ * not carried by tracking): id and last position.  Map::landmarks_ of the reference keeps every landmark for
+ * saveSLAMOutputInFile (src/map.cpp:39-51, src/visual_odometry.cpp:226-304); a caller that writes landmarks.pcd archives
+ * these.  *recs points into the context (valid until the next batch call); a job's records are unordered.             */
+typedef struct svslam_dmap_evicted_rec { int id; float pos[3]; } svslam_dmap_evicted_rec;
+int svslam_dmap_evicted(svslam_ctx *ctx, const svslam_dmap_evicted_rec **recs, int *n);
 /* test / writer hook: one stream's window (max_kf entries; kf_frame < 0 = empty slot) and landmark arena
  * (max_lm entries; lm_id < 0 = free slot; lm_state 1 = active, 2 = outside the window)                           */
 int svslam_dmap_read(svslam_ctx *ctx, int stream, long long *kf_frame, int *kf_id, double *kf_pose, int *kf_n,

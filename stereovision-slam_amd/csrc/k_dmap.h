@@ -63,12 +63,15 @@ struct DmJob {                // device copy of svslam_dmap_job + placement (hos
     int stamp, pad0;
     // outputs (device-written)
     int ok, n_features, n_corners, n_right_ok, n_tri_in, n_tri_ok, ba_nkf, ba_nlm, ba_nobs, ba_iters, flags, dead;
+    int ev_ofs, ev_n;         // the landmarks this call freed: records [ev_ofs, ev_ofs + ev_n) of the batch's evicted list
     double win_pose[12][7];   // poses of the BA problem's keyframes after the solve, by local index
     int win_slot[12];
 };
 #define DM_FLAG_CORNERS_DROPPED 1
 #define DM_FLAG_LM_FULL 2
 #define DM_FLAG_BA_SKIPPED 4
+
+struct DmEvicted { int id; float pos[3]; };      // == svslam_dmap_evicted_rec: a landmark leaving the device map (id, last position)
 
 struct DmParams {
     int num_features, num_features_init, num_active;
@@ -101,13 +104,15 @@ __device__ __forceinline__ int dm_exscan(int v, int *tmp, int tid, int *tot)
 
 // ---------------------------------------------------------------- keyframe insertion (tracked frames)
 __global__ void __launch_bounds__(DM_THREADS)
-k_dmap_begin(DmJob *jobs, DMap m, RtStore rs)
+k_dmap_begin(DmJob *jobs, DMap m, RtStore rs, DmEvicted *ev, int *ev_cursor, int ev_cap)
 {
+    __shared__ int tmp[DM_THREADS];
+    __shared__ int s_base, s_room, s_cnt;
     DmJob &jb = jobs[blockIdx.x];
     const int tid = threadIdx.x, s = jb.stream;
     if (tid == 0) {
         jb.ok = jb.is_init ? 0 : 1; jb.dead = 0; jb.flags = 0; jb.n_corners = jb.n_right_ok = jb.n_tri_in = jb.n_tri_ok = 0;
-        jb.ba_nkf = jb.ba_nlm = jb.ba_nobs = jb.ba_iters = 0; jb.n_features = jb.npts; jb.pad0 = 0;
+        jb.ba_nkf = jb.ba_nlm = jb.ba_nobs = jb.ba_iters = 0; jb.n_features = jb.npts; jb.pad0 = 0; jb.ev_ofs = jb.ev_n = 0;
     }
     if (jb.is_init) return;
     const size_t L = dm_l(m, s);
@@ -140,9 +145,33 @@ k_dmap_begin(DmJob *jobs, DMap m, RtStore rs)
     }
     __syncthreads();
     __threadfence_block();
-    // landmarks nothing can reach any more (no observation, outside the window, not carried by tracking) free their slot
+    // landmarks nothing can reach any more (no observation, outside the window, not carried by tracking) free their slot.
+    // The reference keeps every landmark for saveSLAMOutputInFile (src/visual_odometry.cpp:226-304): id and last position
+    // of each go to the batch's evicted list first (one reservation per job; what a full list cannot take stays where it is until
+    // the stream's next keyframe — nothing is lost, the slots just stay taken that long).
+    int mine = 0;
     for (int l = tid; l < m.NL; l += DM_THREADS)
-        if (m.lm_st[L + l] == 2 && m.lm_obs[L + l] == 0 && m.lm_stamp[L + l] != jb.stamp) { m.lm_st[L + l] = 0; m.lm_id[L + l] = -1; }
+        mine += (m.lm_st[L + l] == 2 && m.lm_obs[L + l] == 0 && m.lm_stamp[L + l] != jb.stamp) ? 1 : 0;
+    int tot;
+    (void)dm_exscan(mine, tmp, tid, &tot);
+    if (tid == 0) {
+        const int base = tot > 0 ? atomicAdd(ev_cursor, tot) : 0;
+        const int room = min(tot, max(0, ev_cap - base));
+        if (room < tot) atomicSub(ev_cursor, tot - room);
+        s_base = base; s_room = room; s_cnt = 0;
+        jb.ev_ofs = base; jb.ev_n = room;
+    }
+    __syncthreads();
+    if (s_room == 0) return;
+    for (int l = tid; l < m.NL; l += DM_THREADS)
+        if (m.lm_st[L + l] == 2 && m.lm_obs[L + l] == 0 && m.lm_stamp[L + l] != jb.stamp) {
+            const int k = atomicAdd(&s_cnt, 1);
+            if (k >= s_room) continue;                     // no room left in the list: this one waits for the next keyframe
+            DmEvicted &e = ev[s_base + k];
+            e.id = m.lm_id[L + l];
+            e.pos[0] = (float)m.lm_pos[3 * (L + l)]; e.pos[1] = (float)m.lm_pos[3 * (L + l) + 1]; e.pos[2] = (float)m.lm_pos[3 * (L + l) + 2];
+            m.lm_st[L + l] = 0; m.lm_id[L + l] = -1;
+        }
 }
 
 // ---------------------------------------------------------------- corners -> features, stereo LK inputs

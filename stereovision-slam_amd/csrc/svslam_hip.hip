@@ -33,6 +33,7 @@
 #include "k_dmap.h"
 
 #define SVSLAM_DMAP_CHUNK 512     /* keyframe jobs per svslam_dmap_keyframe_batch call the staging arena is sized for */
+#define SVSLAM_DMAP_EVICT_PER_JOB 512   /* evicted-landmark records per job of a call (shared by the call's jobs; the surplus waits) */
 
 namespace {
 
@@ -92,6 +93,7 @@ struct svslam_ctx {
     // resident feature lists (svslam_rtrack_*): two alternating buffers per stream
     RtStore rt = {};
     std::vector<int> rt_which, rt_count;
+    std::vector<DmEvicted> evicted;      // landmarks the last svslam_dmap_keyframe_batch freed (svslam_dmap_evicted)
     DMap dm = {};                 // device-resident maps (limits.device_map)
     void *dm_all = nullptr;
     int dm_stamp = 0;
@@ -447,7 +449,8 @@ int svslam_create(const svslam_limits *lim, svslam_ctx **out)
         const size_t MO = lim->max_obs, NL = lim->max_lm, NF = lim->max_pts, MK = lim->max_kf;
         const int tc = std::max(ba_tile_cap(lim->max_kf), 64);
         const size_t aux = ba_aux_layout((int)MK, (int)NL, (int)MO, (int)MO, (int)MK, 0, ba_tile_bound((int)NL, (int)MO, (int)MK, tc)).total + ba_pitem_bound((int)MO, (int)MK);
-        const size_t per_dm = sizeof(DmJob) + NF * 80 + NL * 32 + MO * 64 + aux * 4 + MK * 56 + (size_t)lim->max_corners * 8 + 8192;
+        const size_t per_dm = sizeof(DmJob) + NF * 80 + NL * 32 + MO * 64 + aux * 4 + MK * 56 + (size_t)lim->max_corners * 8 + 8192 +
+                              sizeof(DmEvicted) * SVSLAM_DMAP_EVICT_PER_JOB;
         const size_t chunk = std::min<size_t>(SVSLAM_DMAP_CHUNK, (size_t)std::max(1, lim->max_streams));
         c->ar.cap = std::max(chunk * per_dm, std::max(per_job_pts * J, std::min<size_t>(J, 64) * per_job)) + (4 << 20);
     }
@@ -1387,6 +1390,8 @@ int svslam_dmap_keyframe_batch(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, 
     if (njobs <= 0) return 0;
     if (!c->dm_all) return fail(c, "dmap: context created without device_map");
     static_assert(sizeof(DmJob) == sizeof(svslam_dmap_job), "job layout");
+    static_assert(sizeof(DmEvicted) == sizeof(svslam_dmap_evicted_rec), "evicted record layout");
+    c->evicted.clear();
     const DMap &m = c->dm;
     if (2 * njobs > c->lim.max_jobs) return fail(c, "dmap: %d jobs need max_jobs >= %d", njobs, 2 * njobs);
     if (njobs > SVSLAM_DMAP_CHUNK) return fail(c, "dmap: at most %d jobs per call", SVSLAM_DMAP_CHUNK);
@@ -1427,6 +1432,8 @@ int svslam_dmap_keyframe_batch(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, 
     size_t opk = c->ar.take(sizeof(unsigned int) * E), ouv = c->ar.take(sizeof(float2) * E), oref = c->ar.take(sizeof(int) * E);
     size_t olms = c->ar.take(sizeof(int) * NL * n), ochi = c->ar.take(sizeof(double) * E), oflag = c->ar.take(sizeof(int) * 4);
     size_t orecs = c->ar.take(sizeof(BaRec) * 2 * E), oaux = c->ar.take(sizeof(int) * aux_stride * n);
+    const int ev_cap = njobs * SVSLAM_DMAP_EVICT_PER_JOB;
+    size_t oev = c->ar.take(sizeof(DmEvicted) * (size_t)ev_cap);
     if (c->ar.off > c->ar.cap) return fail(c, "dmap: staging arena too small (%zu > %zu bytes); fewer jobs per call", c->ar.off, c->ar.cap);
     DmJob *hj = hp<DmJob>(c, ojobs);
     GfttJob *gj = hp<GfttJob>(c, ogj);
@@ -1452,7 +1459,7 @@ int svslam_dmap_keyframe_batch(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, 
     if (h2d(c, base, in_end)) return -1;
     HIPCHK(c, hipMemsetAsync(dp<void>(c, oflag), 0, sizeof(int) * 4, c->stream));
     DmJob *dj = dp<DmJob>(c, ojobs);
-    hipLaunchKernelGGL(k_dmap_begin, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, c->rt);
+    hipLaunchKernelGGL(k_dmap_begin, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, c->rt, dp<DmEvicted>(c, oev), dp<int>(c, oflag) + 1, ev_cap);
     if (launch_gftt(c, njobs, dp<GfttJob>(c, ogj), m.f_xy, MC, 0.01, 20.0, dp<float2>(c, ocor), dp<int>(c, oncor))) return -1;   // src/frontend.cpp:24
     hipLaunchKernelGGL(k_dmap_stereo_prep, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, prm, dp<float2>(c, ocor), dp<int>(c, oncor), MC,
                        dp<LkJob>(c, olk), dp<float2>(c, oprev), dp<float2>(c, onext));
@@ -1486,8 +1493,21 @@ int svslam_dmap_keyframe_batch(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, 
     if (d2h_sync(c, ojobs, ojobs + sizeof(DmJob) * n)) return -1;
     if (d2h_sync(c, oflag, oflag + sizeof(int) * 4)) return -1;
     if (const int fl = hp<int>(c, oflag)[0]) return fail(c, "dmap: the BA structure build overflowed a capacity (code %d)", fl);
+    if (const int nev = hp<int>(c, oflag)[1]) {                // the landmarks this call freed (svslam_dmap_evicted)
+        if (nev < 0 || nev > ev_cap) return fail(c, "dmap: evicted-list cursor %d out of [0,%d]", nev, ev_cap);
+        if (d2h_sync(c, oev, oev + sizeof(DmEvicted) * (size_t)nev)) return -1;
+        c->evicted.assign(hp<DmEvicted>(c, oev), hp<DmEvicted>(c, oev) + nev);
+    }
     memcpy(jobs, hj, sizeof(DmJob) * n);
     for (int i = 0; i < njobs; ++i) c->rt_count[(size_t)jobs[i].stream] = jobs[i].n_features;
+    return 0;
+}
+
+int svslam_dmap_evicted(svslam_ctx *c, const svslam_dmap_evicted_rec **recs, int *n)
+{
+    if (!c->dm_all) return fail(c, "dmap_evicted: context created without device_map");
+    *recs = reinterpret_cast<const svslam_dmap_evicted_rec *>(c->evicted.data());
+    *n = (int)c->evicted.size();
     return 0;
 }
 

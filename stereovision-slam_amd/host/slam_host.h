@@ -186,6 +186,9 @@ public:
     size_t num_landmarks() const { return (size_t)next_id_; }                 // Map::landmarks_.size()
     size_t num_resident_landmarks() const { return pool_.size() - free_.size(); }
     void set_keep_archive(bool on) { keep_archive_ = on; }
+    // device-map mode: a landmark the provider freed from its map (K::dmap_evicted) joins the same 16-byte archive
+    void ArchiveEvicted(int id, const float *pos) { if (keep_archive_) archive_.push_back(ArchivedLandmark{ (uint32_t)id, { pos[0], pos[1], pos[2] } }); }
+    size_t num_archived() const { return archive_.size(); }
     // every landmark ever created, id-ascending (live ones with their current position, evicted ones as archived)
     std::vector<LandmarkRecord> AllLandmarks() const
     {
@@ -325,7 +328,7 @@ private:
     std::vector<MapPoint *> free_, limbo_;    // limbo_: unobserved and outside the window, possibly still tracked
     std::vector<MapPoint *> slots_;           // id - base_id_ -> MapPoint (nullptr: evicted)
     long base_id_ = 0, next_id_ = 0;
-    std::vector<ArchivedLandmark> archive_;
+    std::deque<ArchivedLandmark> archive_;    // (a deque: grows by 512-byte blocks, no doubling reallocation)
     bool keep_archive_ = true;
     std::vector<Frame *> retired_;            // left the window, feature lists not yet released
     Frame *current_frame_ = nullptr;
@@ -526,14 +529,13 @@ public:
         if (!pcd) return false;
         std::vector<LandmarkRecord> all = st.map.AllLandmarks();
         if (device_map()) {
-            // the map lives in the provider's memory: the landmarks it still holds (those that left the window AND
-            // tracking were freed there; this mode keeps no archive of them), id-ascending
+            // the map lives in the provider's memory: the archive of what it freed (above) + the landmarks it still holds,
+            // id-ascending
             const int NL = cfg_.max_lm;
             std::vector<int> id((size_t)NL), obs((size_t)NL);
             std::vector<double> pos(3 * (size_t)NL);
             std::vector<uint8_t> stt((size_t)NL);
             check(k_.dmap_read(s, nullptr, nullptr, nullptr, nullptr, id.data(), pos.data(), obs.data(), stt.data()), "dmap_read");
-            all.clear();
             for (int l = 0; l < NL; ++l)
                 if (id[(size_t)l] >= 0) all.push_back(LandmarkRecord{ id[(size_t)l], { pos[3 * (size_t)l], pos[3 * (size_t)l + 1], pos[3 * (size_t)l + 2] }, obs[(size_t)l], stt[(size_t)l] == 1 });
             std::sort(all.begin(), all.end(), [](const LandmarkRecord &a, const LandmarkRecord &b) { return a.id < b.id; });
@@ -706,6 +708,14 @@ private:
             KTimer kt_(cnt_);
             check(k_.dmap_keyframe(m, jobs_dm_.data() + c0, dm_left_.data() + c0, dm_right_.data() + c0, strides_.data() + c0, is_device,
                                    cam_l_, cfg_.cam_l.pose.v, cam_r_, cfg_.cam_r.pose.v, &prm), "dmap_keyframe");
+            // Map::landmarks_ keeps every landmark (src/map.cpp:39-51): what the provider freed goes to the stream's archive
+            const svslam_dmap_evicted_rec *ev = nullptr; int nev = 0;
+            check(k_.dmap_evicted(&ev, &nev), "dmap_evicted");
+            for (int i = c0; i < c0 + m && nev > 0; ++i) {
+                const svslam_dmap_job &j = jobs_dm_[i];
+                Map &mp = streams_[DS[i]]->map;
+                for (int e = j.ev_ofs; e < j.ev_ofs + j.ev_n && e < nev; ++e) mp.ArchiveEvicted(ev[e].id, ev[e].pos);
+            }
         }
         t_h = now_ns();
         for (int i = 0; i < n; ++i) {

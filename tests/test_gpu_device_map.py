@@ -26,7 +26,7 @@ def _run(svs, pl, cfg, seeds, N, frames):
 
 
 @pytest.mark.parametrize("shape", ["config-00", "seq05-k7"])
-def test_device_map_equals_host_map_bit_for_bit(svs, shape):
+def test_device_map_equals_host_map_bit_for_bit(svs, shape, tmp_path):
     pl = importlib.import_module("stereovision-slam_amd.pipeline")
     if shape == "config-00":
         w, h, cam, nkf, seeds, N = W, H, svs.KITTI00_HALF_CAM, 10, [51, 52, 53, 54, 55], 160
@@ -38,6 +38,10 @@ def test_device_map_equals_host_map_bit_for_bit(svs, shape):
         cfg = pl.default_config(w, h, cam=cam, num_active_keyframes=nkf, device_map=mode, host_threads=2)
         pipe, out, cnt = _run(svs, pl, cfg, seeds, N, frames)
         res[mode] = (out, cnt)
+        # saveSLAMOutputInFile (src/visual_odometry.cpp:198-310): every landmark ever created, also the ones the map let go
+        for s in range(len(seeds)):
+            d = tmp_path / ("mode%d_s%d" % (mode, s)); d.mkdir()
+            pipe.save_outputs(s, str(d))
         if mode == 1:
             ctx = svs.Context.borrow(pipe.kernel_ctx(), w, h)
             for s in range(len(seeds)):
@@ -58,6 +62,12 @@ def test_device_map_equals_host_map_bit_for_bit(svs, shape):
               "track_pts", "pose_edges", "corners_dropped", "ba_skipped"):
         assert ca[k] == cb[k], (shape, k, ca[k], cb[k])
     assert cb["keyframes"] >= len(seeds) * (nkf + 6)         # the window slid: keyframes were retired, landmarks evicted
+    for s in range(len(seeds)):
+        for name in ("landmarks.pcd", "keyframes.txt"):
+            fa = (tmp_path / ("mode0_s%d" % s) / name).read_bytes(); fb = (tmp_path / ("mode1_s%d" % s) / name).read_bytes()
+            assert fa == fb, (shape, s, name, len(fa), len(fb))
+        npts = int((tmp_path / ("mode1_s%d" % s) / "landmarks.pcd").read_text().split("POINTS ")[1].split()[0])
+        assert npts > 2000                                    # far more than the device map holds at the end: the archive is in
     assert (a["status"] != 3).all()
 
 
