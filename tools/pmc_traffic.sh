@@ -30,7 +30,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
 # that bench.py reports (units_whole_process); KB -> bytes (x1024, the counter's documented unit)
 try:
     u = json.loads(open("gpurun_out/pmc_FETCH_SIZE_bench.json").read().strip().splitlines()[-1])["units_whole_process"]
-    fam = {"local_ba": (["k_local_ba_t<0>", "k_ba_build"], "job", u["ba_calls"]),
+    fam = {"local_ba": (["k_local_ba_t<0>", "k_ba_build", "k_dmap_ba_gather", "k_dmap_ba_scatter"], "job", u["ba_calls"]),
            "lk": (["k_lk"], "point", u["track_pts"] + u["right_pts"]),
            "pose_only": (["k_pose_only<1>", "k_pose_only<0>"], "job", u["frames"]),
            "pyramid": (["k_pyr_fused<false>", "k_pyr_fused<true>"], "image", u["pyr_left"] + u["pyr_right"]),
