@@ -83,6 +83,29 @@ def po_case(seed):
     return cm.EXT_L.copy(), P, uv.astype(np.float32)
 
 
+def po_tracking_case(seed, bad=0.03):
+    """a pose-only job shaped like steady tracking: the prior a frame's motion away, half-pixel noise, a few gross outliers"""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(90, 200))
+    P = np.stack([rng.uniform(-8, 8, n), rng.uniform(-2, 1.5, n), rng.uniform(4.0, 40.0, n)], 1)
+    T_true = cm.random_pose(rng, 0.9, 0.02)
+    uv, _ = cm.project(cm.CAM, T_true, cm.EXT_L, P)
+    uv += rng.normal(0, 0.5, uv.shape)
+    b = rng.random(n) < bad
+    uv[b] += rng.normal(0, 30, (int(b.sum()), 2))
+    return cm.EXT_L.copy(), P, uv.astype(np.float32)
+
+
+def po_rounds(tr):
+    """pose-only trace split by round, the iteration made round-relative"""
+    out = []
+    for r in range(4):
+        t = tr[(tr[:, 0] // 16) == r].copy()
+        t[:, 0] -= 16 * r
+        out.append(t)
+    return out
+
+
 def significant(tr):
     return (np.abs(tr[:, 2] - tr[:, 3]) > 1e-6 * np.abs(tr[:, 2])) & (np.abs(tr[:, 4]) > 1e-3)
 

@@ -137,3 +137,35 @@ def test_pose_only_follows_the_oracle_through_rejected_trials(svs, orc, low_late
         assert np.allclose(T[4:], T_ref[4:], atol=1e-6) and np.allclose(T[:4], T_ref[:4], atol=1e-7), (seed, np.abs(T - T_ref).max())
     assert total >= 30
     c.close()
+
+
+@pytest.mark.parametrize("low_latency", [0, 1])
+def test_pose_only_rounds_that_repeat_are_skipped_without_a_trace_of_it(svs, orc, low_latency):
+    """k_pose_only does not execute a round whose outlier flags and robust flag equal the previous round's (it would
+    repeat it operation for operation; tests/test_lm_rejection_cases.py checks that premise on the oracle, which runs
+    every round).  Tracking-shaped jobs: where the oracle's round 2 is bitwise its round 1 the device's replayed
+    trace must be too, where the flags changed the device runs the round — and poses, outlier sets and inlier counts
+    equal the oracle's either way."""
+    c = svs.Context(cm.W, cm.H, max_slots=1, max_jobs=32)
+    c.lm_trace(True)
+    c.low_latency(bool(low_latency))
+    seeds = list(range(12)) + [100 + s for s in lc.PO_REJECT[:4]]
+    jobs = [lc.po_tracking_case(s) if s < 100 else lc.po_case(s - 100) for s in seeds]
+    res = c.pose_only(jobs, cm.CAM)
+    repeated = ran = 0
+    for i, ((T, outl, ninl), (T0, P, uv), seed) in enumerate(zip(res, jobs, seeds)):
+        T_ref, outl_ref, ninl_ref, ref = orc.pose_only_trace(cm.CAM, T0, P, uv)
+        assert np.array_equal(outl, outl_ref) and ninl == ninl_ref, seed
+        assert np.allclose(T[4:], T_ref[4:], atol=1e-6) and np.allclose(T[:4], T_ref[:4], atol=1e-7), (seed, np.abs(T - T_ref).max())
+        d = lc.po_rounds(c.lm_trace(job=i)); r = lc.po_rounds(ref)
+        for k in (0, 1):
+            ref_same = r[k].shape == r[k + 1].shape and np.array_equal(r[k], r[k + 1])
+            dev_same = d[k].shape == d[k + 1].shape and np.array_equal(d[k], d[k + 1])
+            if ref_same:
+                assert dev_same, (seed, k)
+                repeated += 1
+            elif len(r[k + 1]) and lc.sig_prefix(r[k + 1]) > 0 and not dev_same:
+                ran += 1
+        assert len(d[3]) > 0                                   # the round without the robust kernel always runs
+    assert repeated >= 6 and ran >= 6, (repeated, ran)
+    c.close()

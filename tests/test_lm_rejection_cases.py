@@ -83,3 +83,23 @@ def test_independent_lm_follows_the_oracle_through_rejected_trials(orc, seed, it
     it, lam = sba.shared_map_ba(eng, sdist.Rank(0, 0, 1), len(poses), iters=iters, trace=tr)
     n, nrej = lc.assert_traces_agree(np.array(tr), ref[4], need_rejected=1, what="numpy LM seed %d" % seed)
     assert nrej >= 1 and it == ref[3]
+
+
+def test_a_pose_only_round_with_unchanged_outlier_flags_repeats_the_previous_one_bit_for_bit(orc):
+    """The premise of k_pose_only's round skip, checked on the restatement that really executes all four rounds
+    (src/frontend.cpp:482-527: every round restarts from the frame's pose, optimize() recomputes lambda_0): in steady
+    tracking the classification after round 1 confirms the flags round 1 ran with, and round 2 is round 1 again —
+    every trial, every lambda, every chi2 identical to the last bit.  Round 0 (no outliers yet) and round 3 (no robust
+    kernel) differ from their neighbours."""
+    repeats = 0
+    for seed in range(12):
+        T0, P, uv = lc.po_tracking_case(seed)
+        T, outl, ninl, tr = orc.pose_only_trace(cm.CAM, T0, P, uv)
+        r0, r1, r2, r3 = lc.po_rounds(tr)
+        if outl.sum() == 0:
+            continue
+        assert not (r0.shape == r1.shape and np.array_equal(r0, r1)), seed     # round 1 dropped round 0's outliers
+        assert not (r2.shape == r3.shape and np.array_equal(r2, r3)), seed     # round 3 runs without the Huber kernel
+        if r1.shape == r2.shape and np.array_equal(r1, r2):
+            repeats += 1
+    assert repeats >= 6, repeats
