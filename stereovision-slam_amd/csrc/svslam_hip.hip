@@ -1432,7 +1432,9 @@ int svslam_dmap_keyframe_batch(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, 
     size_t opk = c->ar.take(sizeof(unsigned int) * E), ouv = c->ar.take(sizeof(float2) * E), oref = c->ar.take(sizeof(int) * E);
     size_t olms = c->ar.take(sizeof(int) * NL * n), ochi = c->ar.take(sizeof(double) * E), oflag = c->ar.take(sizeof(int) * 4);
     size_t orecs = c->ar.take(sizeof(BaRec) * 2 * E), oaux = c->ar.take(sizeof(int) * aux_stride * n);
-    const int ev_cap = njobs * SVSLAM_DMAP_EVICT_PER_JOB;
+    // (test hook SVSLAM_DMAP_EVICT_CAP: a smaller list for the whole call, to exercise the "waits for the next keyframe" path)
+    static const int ev_cap_env = []{ const char *e = std::getenv("SVSLAM_DMAP_EVICT_CAP"); return e ? atoi(e) : 0; }();
+    const int ev_cap = ev_cap_env > 0 ? std::min(ev_cap_env, njobs * SVSLAM_DMAP_EVICT_PER_JOB) : njobs * SVSLAM_DMAP_EVICT_PER_JOB;
     size_t oev = c->ar.take(sizeof(DmEvicted) * (size_t)ev_cap);
     if (c->ar.off > c->ar.cap) return fail(c, "dmap: staging arena too small (%zu > %zu bytes); fewer jobs per call", c->ar.off, c->ar.cap);
     DmJob *hj = hp<DmJob>(c, ojobs);

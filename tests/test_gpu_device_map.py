@@ -111,3 +111,33 @@ def test_device_map_failed_init_and_pause(svs):
     for k in ("status", "is_keyframe", "n_features", "n_inliers", "keyframe_id"):
         assert np.array_equal(a[k], b[k]), k
     assert np.array_equal(a["pose"], b["pose"])
+
+
+def test_device_map_archive_loses_nothing_when_the_evicted_list_is_too_short(svs, tmp_path):
+    """svslam_dmap_evicted's list shared by a call's jobs holds 512 records per job; here the whole call gets 40
+    (test hook SVSLAM_DMAP_EVICT_CAP, read once per process -> a subprocess): what does not fit stays in the device map
+    until the stream's next keyframe, and landmarks.pcd still lists every landmark, byte-identical to the host map's."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import importlib, sys
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        svs = importlib.import_module("stereovision-slam_amd")
+        pl = importlib.import_module("stereovision-slam_amd.pipeline")
+        seeds, N = [81, 82, 83], 140
+        frames = [[svs.synth_pair(sd, f) for f in range(N)] for sd in seeds]
+        for mode in (0, 1):
+            pipe = pl.Pipeline(pl.default_config(620, 188, device_map=mode, host_threads=2), nstreams=len(seeds))
+            for f in range(N):
+                pipe.step([frames[s][f][0] for s in range(len(seeds))], [frames[s][f][1] for s in range(len(seeds))])
+            for s in range(len(seeds)):
+                d = "%%s/m%%d_s%%d" %% (sys.argv[1], mode, s)
+                import os; os.makedirs(d)
+                pipe.save_outputs(s, d)
+            pipe.close()
+        """) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SVSLAM_DMAP_EVICT_CAP="40")
+    r = subprocess.run([sys.executable, "-c", code, str(tmp_path)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for s in range(3):
+        a = (tmp_path / ("m0_s%d" % s) / "landmarks.pcd").read_bytes(); b = (tmp_path / ("m1_s%d" % s) / "landmarks.pcd").read_bytes()
+        assert a == b and len(a) > 50000, (s, len(a), len(b))
