@@ -337,6 +337,8 @@ def main():
     #      hands over): k_pyr_fused reads them across PCIe itself, nothing is staged or copied by the CPU
     host_input = None
     Kh = max(0, min(args.host_input_steps, FB))
+    if world > 1:
+        Kh = 0          # a one-GPU figure (PCIe of one device; 2 x 14 GB of pinned host memory per rank): not taken at N > 1
     if Kh > 0:
         try:
             svs.synth_render_streams_device(seeds, frame_pos, Kh, SW, SH, d_left, d_right, device=local_rank, cam=cam_r)
