@@ -224,7 +224,9 @@ k_pyr_down_fast(const PyrJob *jobs, uint8_t *pyr, PyrGeom g, int l)
 // (weights (1,4,6,4)*k_row on four bytes, k_row on the fifth), accumulated across the five rows.
 // Strips overlap only in what they READ.  Host side (pyr_fused_plan): strip height in coarsest-level
 // rows, LDS offsets and pitches.
-#define PF_THREADS 1024
+#ifndef PF_THREADS
+#define PF_THREADS 1024      // A/B knob (512: 2 workgroups per CU, easier to place beside other kernels)
+#endif
 #define PF_PAD 16                   // == SVS_BORDER: LDS rows and slot rows share one layout
 #define PF_MAXR 3                   // 16-byte source loads a thread keeps in flight
 struct PyrFusedPlan {
