@@ -151,8 +151,13 @@ class Pipeline:
             raise RuntimeError("svs_pipe_step failed: " + self.L.svs_pipe_last_error().decode())
         return out
 
-    def run_device(self, left_base, right_base, stream_stride, frame_stride, first_frame, nframes, want_results=True):
-        out = np.zeros((nframes, self.n), RESULT_DTYPE) if want_results else None
+    def run_device(self, left_base, right_base, stream_stride, frame_stride, first_frame, nframes, want_results=True, out=None):
+        """out: a caller-owned [nframes, n] RESULT_DTYPE array to fill (e.g. allocated and touched ahead of a measurement)"""
+        if out is not None:
+            assert out.shape == (nframes, self.n) and out.dtype == RESULT_DTYPE and out.flags.c_contiguous
+            want_results = True
+        elif want_results:
+            out = np.zeros((nframes, self.n), RESULT_DTYPE)
         rc = self.L.svs_pipe_run_device(self.h, C.c_void_p(left_base), C.c_void_p(right_base), stream_stride,
                                         frame_stride, first_frame, nframes,
                                         out.ctypes.data_as(C.c_void_p) if want_results else None)
