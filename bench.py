@@ -121,6 +121,10 @@ def main():
                     help="--backend-mode 2: frames a local BA may stay in flight before its result is applied (1 = one frame, "
                          "round 2; 6 hides a lone camera's 1.3-ms BA behind the next frames' tracking)")
     ap.add_argument("--cpu-frames", type=int, default=1200, help="timed frames per CPU-baseline thread (after its pre-roll)")
+    ap.add_argument("--ring-frames", type=int, default=0,
+                    help="frames per stream kept in HBM (0 = warmup + steps: one timed block).  Smaller than warmup + steps: "
+                         "the timed region runs in blocks, every block bracketed by barrier + synchronize, the frames of the "
+                         "next block rendered in between OUTSIDE the timing — for long runs (--steps 10000)")
     ap.add_argument("--preroll", type=int, default=-1,
                     help="untimed steps before the warm-up so that the timed region is the steady state (every stream's "
                          "active window holds num_active_keyframes keyframes); -1 = automatic: blocks of warmup+steps "
@@ -163,7 +167,7 @@ def main():
     # block by block (pre-roll blocks first, then the block that holds the warm-up and the timed steps),
     # always outside the timed region: keep it under ~190 GB.
     SW, SH = (1241, 376) if args.full_res else (W, H)     # stored frame size
-    FB = Wm + K
+    FB = Wm + K if args.ring_frames <= 0 else max(Wm + 1, min(Wm + K, args.ring_frames))
     budget = 225e9                                   # of the MI355X's 288 GB; the pyramids and work buffers need ~1 MB per stream
     if torch.cuda.is_available():
         budget = min(budget, 0.8 * torch.cuda.mem_get_info(local_rank)[0])
@@ -295,24 +299,49 @@ def main():
     res_bufs = [np.zeros((K, Sg), pl.RESULT_DTYPE) for _ in range(G)]
     for b_ in res_bufs:
         b_.view(np.uint8).fill(0)
-    barrier()
+    # the K timed steps: one block when the ring holds warmup + steps frames (the default), else block by block — each
+    # block between barrier + synchronize on both sides, the next block's frames rendered outside the timing
+    blocks, first_, left_ = [], Wm, K
+    while left_ > 0:
+        n_ = min(FB - first_, left_)
+        blocks.append((first_, n_))
+        left_ -= n_
+        first_ = 0
     import resource
-    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     rss0 = int(open("/proc/self/statm").read().split()[1]) * os.sysconf("SC_PAGE_SIZE")
-    tc0 = thread_cpu_seconds()
-    t0 = time.perf_counter()
-    res_g = run_all(Wm, K, True, out_bufs=res_bufs)
-    if torch.cuda.is_available():
-        torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    t_timed = cpu_timed = 0.0
+    minflt_timed = 0
+    tc_acc = {}
+    done_ = 0
+    for bi, (first_, n_) in enumerate(blocks):
+        if bi > 0:
+            render_block(pre + FB + (bi - 1) * FB)
+        barrier()
+        ru0 = resource.getrusage(resource.RUSAGE_SELF)
+        tc0 = thread_cpu_seconds()
+        t0 = time.perf_counter()
+        run_all(first_, n_, True, out_bufs=[b_[done_:done_ + n_] for b_ in res_bufs])
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ru1 = resource.getrusage(resource.RUSAGE_SELF)
+        tc1 = thread_cpu_seconds()
+        barrier()
+        t_timed += t1 - t0
+        cpu_timed += (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
+        minflt_timed += ru1.ru_minflt - ru0.ru_minflt
+        for k in tc1:
+            tc_acc[k] = tc_acc.get(k, 0.0) + tc1[k] - tc0.get(k, 0.0)
+        done_ += n_
+    res_g = res_bufs
     rss1 = int(open("/proc/self/statm").read().split()[1]) * os.sysconf("SC_PAGE_SIZE")
-    tc1 = thread_cpu_seconds()
-    cpu_by_thread = {k: round((tc1[k] - tc0.get(k, 0.0)) / max(t1 - t0, 1e-9), 2) for k in tc1
-                     if tc1[k] - tc0.get(k, 0.0) > 0.005 * (t1 - t0)}
-    cpu_busy = ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / max(t1 - t0, 1e-9)
-    barrier()
-    elapsed = rk.max_over_ranks(t1 - t0)
+    cpu_by_thread = {k: round(v / max(t_timed, 1e-9), 2) for k, v in tc_acc.items() if v > 0.005 * t_timed}
+    cpu_busy = cpu_timed / max(t_timed, 1e-9)
+    t0, t1 = 0.0, t_timed                                # (the code below uses t1 - t0)
+    elapsed = rk.max_over_ranks(t_timed)
+    if len(blocks) > 1:                                  # the extra legs assume a ring of warmup + steps frames
+        args.spread_windows = 0
+        args.host_input_steps = 0
     c1 = counters_sum()
     cnt = {k: c1[k] - c0[k] for k in c1}
     fam_t = {}
@@ -321,7 +350,7 @@ def main():
         fam_t[f] = (sum(p[0] for p in parts), sum(p[1] for p in parts), sum(p[2] for p in parts))
     for c in ctxs:
         c.timing(False)
-    frame_pos = pre + Wm + K                      # next frame of every stream
+    frame_pos = pre + FB + (len(blocks) - 1) * FB  # next frame of every stream (a multi-block run leaves part of the last ring unused)
 
     # ---- value_spread: further windows of K steps, same process, same operating point (the 0.6-s
     #      window of the driver's 20 steps scatters by +-10 % from run to run; here is the scatter inside one run)
@@ -441,6 +470,8 @@ def main():
                                    "keyframes)" % ("completes before the next frame" if args.backend_mode == 1 else
                                                    "runs beside the next frame like the reference's backend thread, "
                                                    "lands one frame late, all of it inside the timed region"),
+                       **({"timed_blocks": "%d blocks of <= %d steps, each between barrier + synchronize; the next block's frames are "
+                                           "rendered into the HBM ring in between, outside the timing" % (len(blocks), FB)} if len(blocks) > 1 else {}),
                        "map": "host (Frontend/Map/Backend bookkeeping on the CPU)" if cfg.device_map == 0 else
                               "device-resident (svslam_dmap_*: window, features, landmarks, observation counts in HBM; the host keeps ids and poses of the window)",
                        "preroll_steps": pre, "preroll_last_block_ba_keyframes_mean": round(preroll_kf, 2),
@@ -487,7 +518,7 @@ def main():
                                  "stream_wait": round(hostns[2] / 1e6 / K / G, 3), "event_collect": round(hostns[5] / 1e6 / K / G, 3), "ba_host_prep": round(hostns[4] / 1e6 / K / G, 3),
                                  "cpus_busy": round(cpu_busy, 2), "cpus_allowed": effective_cpus(),
                                  "pinned_to_gpu_numa_cpus": len(pinned),
-                                 "minor_page_faults_per_step": round((ru1.ru_minflt - ru0.ru_minflt) / K, 1),
+                                 "minor_page_faults_per_step": round(minflt_timed / K, 1),
                                  "rss_growth_bytes_per_frame": round((rss1 - rss0) / max(S * K, 1), 1),
                                  "rss_gb": round(rss1 / 1e9, 2),
                                  "cpus_busy_by_thread_name": cpu_by_thread,
