@@ -237,8 +237,13 @@ __device__ __forceinline__ int po_block_sum_i32(int x, int *buf, int tid)
 // by every wave).  The two shapes sum in different orders, so they agree to rounding, not bit for bit.
 // status_in (optional): edges whose status_in==0 are not part of the problem
 // (used by the fused tracking path: LK failures / points without a map point).
+#ifdef PO_NUM_VGPR          // A/B knob: cap of the kernel's unified registers (amdgpu_num_vgpr takes half of it on gfx90a+)
+#define PO_VGPR_ATTR __attribute__((amdgpu_num_vgpr((PO_NUM_VGPR) / 2)))
+#else
+#define PO_VGPR_ATTR
+#endif
 template <int WAVES>
-__global__ void __launch_bounds__(64 * WAVES)
+__global__ void __launch_bounds__(64 * WAVES) PO_VGPR_ATTR
 k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *uv,
             const uint8_t *edge_valid, uint8_t *outlier, double chi2_th, int rounds, int iters, double *trace)
 {
@@ -262,27 +267,47 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
 #pragma unroll
     for (int i = 0; i < 7; ++i) { T0[i] = jb.pose[i]; T[i] = T0[i]; }
 
-    double P[SLOTS][3], mu[SLOTS], mv[SLOTS];
-    double e0[SLOTS], e1[SLOTS];
-    bool valid[SLOTS], outl[SLOTS];
+    // Per-edge state.  The first RS slots of a lane (edges e = s NT + tid, s < RS: 192 edges of a one-wave job, more than a
+    // tracking frame has) keep position and pixel in registers; the slots beyond re-read them from memory in every pass (a
+    // frame with more edges pays L2 loads, every other frame gets 80 registers back: with the residuals below, 335 -> under
+    // 256 unified registers, i.e. TWO waves per SIMD — the wave is a chain of dependent f64 instructions at ~8 cycles each and
+    // a second wave on the SIMD fills the gaps: 2048 jobs 357 -> 2xx us).  Valid / outlier flags are one bit per slot.
+    // The residuals of the last evaluated trial, which the classification reads (g2o keeps the errors of its last
+    // computeActiveErrors(), also those of a rejected trial), are not kept per edge: the pose of that trial is (Te), and the
+    // classification re-evaluates po_error there — the same function on the same inputs, bit-identical.
+    constexpr int RS = SLOTS < 3 ? SLOTS : 3;
+    double P[RS][3], mu[RS], mv[RS];
+    unsigned vmask = 0, omask = 0;
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
-        int e = s * NT + tid;
-        valid[s] = e < n;
-        outl[s] = false; e0[s] = 0; e1[s] = 0;
-        if (valid[s]) {
-            int pt = jb.pt_ofs + e;
-            if (edge_valid && !edge_valid[pt]) valid[s] = false;
-            P[s][0] = xyz[3 * pt]; P[s][1] = xyz[3 * pt + 1]; P[s][2] = xyz[3 * pt + 2];
-            float2 m = uv[pt];
-            mu[s] = (double)m.x; mv[s] = (double)m.y;
-        } else { P[s][0] = P[s][1] = 0; P[s][2] = 1; mu[s] = mv[s] = 0; }
+        const int e = s * NT + tid;
+        bool v = e < n;
+        if (v && edge_valid && !edge_valid[jb.pt_ofs + e]) v = false;
+        vmask |= (v ? 1u : 0u) << s;
+        if (s < RS) {
+            if (e < n) {
+                const int pt = jb.pt_ofs + e;
+                P[s][0] = xyz[3 * pt]; P[s][1] = xyz[3 * pt + 1]; P[s][2] = xyz[3 * pt + 2];
+                const float2 m = uv[pt];
+                mu[s] = (double)m.x; mv[s] = (double)m.y;
+            } else { P[s][0] = P[s][1] = 0; P[s][2] = 1; mu[s] = mv[s] = 0; }
+        }
     }
+    // position and pixel of the lane's edge in slot s (s a compile-time constant in the unrolled loops; only called for valid edges)
+    auto edge = [&](int s, double *Pq, double &u_, double &v_) {
+        if (s < RS) { Pq[0] = P[s < RS ? s : 0][0]; Pq[1] = P[s < RS ? s : 0][1]; Pq[2] = P[s < RS ? s : 0][2]; u_ = mu[s < RS ? s : 0]; v_ = mv[s < RS ? s : 0]; }
+        else {
+            const int pt = jb.pt_ofs + s * NT + tid;
+            Pq[0] = xyz[3 * pt]; Pq[1] = xyz[3 * pt + 1]; Pq[2] = xyz[3 * pt + 2];
+            const float2 m = uv[pt];
+            u_ = (double)m.x; v_ = (double)m.y;
+        }
+    };
+    double Te[7] = { 0, 0, 0, 1, 0, 0, 0 };        // pose of the last evaluated LM trial
+    bool have_eval = false;
     bool robust = true;
     int cnt_outlier = 0, n_edges = 0, one = 0;
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) n_edges += valid[s] ? 1 : 0;
-    n_edges = po_block_sum_i32<WAVES>(n_edges, s_int, tid);
+    n_edges = po_block_sum_i32<WAVES>(__builtin_popcount(vmask), s_int, tid);
 
     // A round restarts from T0 with the outlier flags of the previous classification and the robust flag: when that
     // classification changed no flag and the robust flag is the same, the round repeats the previous one operation for
@@ -299,9 +324,7 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
 #pragma unroll
         for (int i = 0; i < 7; ++i) T[i] = T0[i];
         int nact = 0;
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s) nact += (valid[s] && !outl[s]) ? 1 : 0;
-        nact = po_block_sum_i32<WAVES>(nact, s_int, tid);
+        nact = po_block_sum_i32<WAVES>(__builtin_popcount(vmask & ~omask), s_int, tid);
         if (nact > 0) {
             double lambda = 0, ni = 2;
             for (int it = 0; it < iters; ++it) {
@@ -312,14 +335,15 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
                 for (int i = 0; i < 32; ++i) acc[i] = 0;
 #pragma unroll
                 for (int s = 0; s < SLOTS; ++s) {
-                    if (!(valid[s] && !outl[s])) continue;
+                    if (!(((vmask & ~omask) >> s) & 1)) continue;
+                    double Pq[3], mu_, mv_;
+                    edge(s, Pq, mu_, mv_);
                     double pc[3];
-                    d_se3_act(T, P[s], pc);
+                    d_se3_act(T, Pq, pc);
                     double X = pc[0], Y = pc[1], Z = pc[2];
                     double px = cam[0] * X + cam[2] * Z, py = cam[1] * Y + cam[3] * Z;
                     const double iz = d_rcp1(Z);
-                    double ex = mu[s] - px * iz, ey = mv[s] - py * iz;
-                    e0[s] = ex; e1[s] = ey;
+                    double ex = mu_ - px * iz, ey = mv_ - py * iz;
                     double e2 = ex * ex + ey * ey, w = 1.0, rho = e2;
                     if (robust) d_huber(e2, 1.0, rho, w);
                     acc[27] += rho;
@@ -375,14 +399,17 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
                     d_se3_exp(x, dT);
                     d_se3_mul(dT, T, Tn);
 #pragma unroll
-                    for (int i = 0; i < 7; ++i) T[i] = Tn[i];
+                    for (int i = 0; i < 7; ++i) { T[i] = Tn[i]; Te[i] = Tn[i]; }
+                    have_eval = true;
                     PO_TICKV(3, T[0] + T[6]);
                     double tchi = 0;
 #pragma unroll
                     for (int s = 0; s < SLOTS; ++s) {
-                        if (!(valid[s] && !outl[s])) continue;
-                        po_error(cam, T, P[s], mu[s], mv[s], e0[s], e1[s]);
-                        double e2 = e0[s] * e0[s] + e1[s] * e1[s], w, rr = e2;
+                        if (!(((vmask & ~omask) >> s) & 1)) continue;
+                        double Pq[3], mu_, mv_, ea, eb;
+                        edge(s, Pq, mu_, mv_);
+                        po_error(cam, T, Pq, mu_, mv_, ea, eb);
+                        double e2 = ea * ea + eb * eb, w, rr = e2;
                         if (robust) d_huber(e2, 1.0, rr, w);
                         tchi += rr;
                     }
@@ -421,12 +448,17 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
         int co = 0;
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
-            if (!valid[s]) continue;
-            if (outl[s]) po_error(cam, T, P[s], mu[s], mv[s], e0[s], e1[s]);
-            double chi2 = e0[s] * e0[s] + e1[s] * e1[s];
+            if (!((vmask >> s) & 1)) continue;
+            const bool was = (omask >> s) & 1;
+            double Pq[3], mu_, mv_, ea = 0, eb = 0;
+            edge(s, Pq, mu_, mv_);
+            // an outlier of this round: its error at the round's result; an active edge: at the last evaluated trial
+            if (was) po_error(cam, T, Pq, mu_, mv_, ea, eb);
+            else if (have_eval) po_error(cam, Te, Pq, mu_, mv_, ea, eb);
+            double chi2 = ea * ea + eb * eb;
             const bool now = chi2 > chi2_th;
-            co += (now ? 1 : 0) + (now != outl[s] ? 1 << 16 : 0);       // outliers | flags changed << 16 (<= 512 edges)
-            outl[s] = now;
+            co += (now ? 1 : 0) + (now != was ? 1 << 16 : 0);           // outliers | flags changed << 16 (<= 512 edges)
+            omask = (omask & ~(1u << s)) | ((now ? 1u : 0u) << s);
         }
         co = po_block_sum_i32<WAVES>(co, s_int, tid);
         cnt_outlier = co & 0xffff;
@@ -436,7 +468,7 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
         int e = s * NT + tid;
-        if (e < n) outlier[jb.pt_ofs + e] = (valid[s] && outl[s]) ? 1 : 0;
+        if (e < n) outlier[jb.pt_ofs + e] = ((vmask & omask) >> s) & 1;
     }
     if (tid == 0) {
 #pragma unroll

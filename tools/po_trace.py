@@ -7,7 +7,7 @@ import common as cm
 svs = importlib.import_module("stereovision-slam_amd")
 
 l0, r0 = svs.synth_pair(3, 0); l1, _ = svs.synth_pair(3, 1)
-c = svs.Context(cm.W, cm.H, max_slots=3, max_jobs=1024, max_pts=256, max_corners=256, max_kf=0, max_lm=0, max_obs=0)
+c = svs.Context(cm.W, cm.H, max_slots=3, max_jobs=4096, max_pts=256, max_corners=256, max_kf=0, max_lm=0, max_obs=0)
 c.pyramid([0, 1, 2], [l0, r0, l1])
 pts = c.gftt([(0, None)], max_corners=150, min_dist=8.0)[0]
 q, st, _ = c.lk([(0, 1, pts, pts)])[0]
@@ -33,7 +33,7 @@ for r in range(4):
     for row in t:
         print("    it %2d lambda %.3e chi %.6f -> %.6f rho %.3e %s" % (int(row[0]) - 16 * r, row[1], row[2], row[3], row[4], "ok" if row[5] else "REJ"))
 c.timing(True)
-for nj in (1, 256, 1024):
+for nj in (1, 256, 1024, 2048, 4096):
     for rep in range(3):
         c.pose_only([(cm.EXT_L, xyz[m], q1[m])] * nj, cm.CAM)
     ms, n, _ = c.timing_get("pose_only")
