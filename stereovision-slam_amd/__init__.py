@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "svslam_device_count", "svslam_dmap_keyframe_batch", "svslam_dmap_read", "svslam_dmap_evicted", "svslam_sba_comm_unique_id", "svslam_sba_comm_init", "svslam_sba_comm_destroy", "svslam_sba_solve",
     "svslam_dev_alloc", "svslam_dev_free", "svslam_dev_upload", "svslam_dev_download", "svslam_sync",
     "svslam_timing_enable", "svslam_timing_reset", "svslam_timing_get", "svslam_ba_profile",
-    "svslam_set_host_threads", "svslam_debug_host_ns", "svslam_debug_clock_mhz", "svslam_lm_trace",
+    "svslam_set_host_threads", "svslam_debug_host_ns", "svslam_debug_ll_shards", "svslam_debug_clock_mhz", "svslam_lm_trace",
 ]
 
 FAMILIES = {"pyramid": 0, "lk": 1, "gftt": 2, "triangulate": 3, "pose_only": 4, "local_ba": 5}
@@ -190,6 +190,21 @@ class Context:
         self._chk(self.L.svslam_sync(self.h), "sync")
 
     # ---- timing ----------------------------------------------------------
+    def host_counters(self):
+        """test hook (svslam_debug_host_ns): 8 host-side counters since the last call; [6] = local-BA problems the
+        low-latency solver took"""
+        o = (C.c_longlong * 8)()
+        self._chk(self.L.svslam_debug_host_ns(self.h, o), "debug_host_ns")
+        return [int(v) for v in o]
+
+    def ll_shards(self, nproblems=1):
+        """test hook (svslam_debug_ll_shards): [nproblems, W, 8] ints of the last low-latency local-BA call — landmarks,
+        edges, blocks, tiles, landmarks in tiles, active poses, shard mask, iterations"""
+        w = C.c_int(0)
+        out = np.zeros((nproblems * 16, 8), np.int32)
+        self._chk(self.L.svslam_debug_ll_shards(self.h, nproblems, _p(out), C.byref(w)), "debug_ll_shards")
+        return out[:nproblems * w.value].reshape(nproblems, w.value, 8).copy()
+
     def low_latency(self, on=True):
         """latency shape of the serial kernels (svslam_set_low_latency): a few jobs per launch"""
         self._chk(self.L.svslam_set_low_latency(self.h, 1 if on else 0), "set_low_latency")

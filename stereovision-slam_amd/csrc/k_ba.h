@@ -72,12 +72,16 @@ struct BaDev {               // device-side job descriptor (built on the host)
     int nmv;                 // landmarks [0, nmv) (internal numbering) go through the LDS tiles; the single-view
                              // landmarks behind them are grouped by pose (sv_start) and folded in by the row pass
     int reserved;
+    int lm_base;             // low-latency shards (k_ba_split): the packed edges name landmarks of the PARENT problem;
+                             // this shard owns [lm_base, lm_base + nlm) of them
+    int shmask;              // low-latency shards: bit v set = shard v of the problem has edges (takes part in the exchanges)
 };
 
 struct BaWork {              // per-job HBM scratch, strided by the context limits
     int max_kf = 0, max_lm = 0, max_obs = 0;
     double *err = nullptr;   // [2*max_obs]  residuals of the last evaluation, landmark-major edge order
     double *poses_b = nullptr; // [7*max_kf]
+    double *poses_a = nullptr; // [7*max_kf]  low-latency shards: the shard's own copy of the current poses
     double *pts_b = nullptr;   // [3*max_lm]
     double *pts_i = nullptr;   // [3*max_lm]  landmark positions in the internal numbering
     void *all = nullptr;
@@ -88,12 +92,13 @@ static inline hipError_t ba_work_alloc(BaWork &w, int jobs, int max_kf, int max_
     w.max_kf = max_kf; w.max_lm = max_lm; w.max_obs = max_obs;
     if (max_kf <= 0 || max_lm <= 0 || max_obs <= 0) return hipSuccess;
     size_t J = jobs;
-    size_t nd = J * ((size_t)max_obs * 2 + (size_t)max_kf * 7 + (size_t)max_lm * 6);
+    size_t nd = J * ((size_t)max_obs * 2 + (size_t)max_kf * 14 + (size_t)max_lm * 6);
     hipError_t e = hipMalloc(&w.all, nd * sizeof(double));
     if (e != hipSuccess) return e;
     double *p = static_cast<double *>(w.all);
     w.err = p; p += J * 2 * max_obs;
     w.poses_b = p; p += J * 7 * max_kf;
+    w.poses_a = p; p += J * 7 * max_kf;
     w.pts_b = p; p += J * 3 * max_lm;
     w.pts_i = p; p += J * 3 * max_lm;
     return hipSuccess;
@@ -324,7 +329,7 @@ struct BaHostStruct {        // scratch reused across jobs
         cp(L.pcs, pcs, (size_t)ntile * ((size_t)na * (na + 1) / 2) + 1); cp(L.pitem, pitem, ncontrib);
         d.kf_ofs = j.kf_ofs; d.nkf = j.nkf; d.lm_ofs = j.lm_ofs; d.nlm = j.nlm; d.obs_ofs = j.obs_ofs; d.nobs = j.nobs;
         d.nblk = nblk; d.na = na; d.ncontrib = ncontrib; d.ntile = ntile; d.iters_done = 0; d.rec_ofs = 0;
-        d.lay_nblk = nblk; d.lay_na = na; d.lay_ntile = ntile; d.nmv = nmv; d.reserved = 0;
+        d.lay_nblk = nblk; d.lay_na = na; d.lay_ntile = ntile; d.nmv = nmv; d.reserved = 0; d.lm_base = 0; d.shmask = 0;
     }
 };
 
@@ -550,11 +555,73 @@ __device__ __forceinline__ void ba_schur_task(int a, int b2, int rg, int c0, int
 //   phase 4  reject: restore the backup      phase 5  finalise: per-edge chi2, positions in caller numbering
 // io layout per job (doubles): S[np*np] | bs[np] | bp[np] | hdiag[np] | scalars[8]
 //   scalars: 0 chi2, 1 landmark diagonal max, 2 cholesky ok, 3 scale (landmarks), 4 scale (poses), 5 chi2 of the trial
-struct SbaArgs { int phase, first; double lambda; double *io; double *trace; int add_lambda; };   // trace: svslam_lm_trace test hook (MODE 0);
+struct SbaArgs { int phase, first; double lambda; double *io; double *trace; int add_lambda;      // trace: svslam_lm_trace test hook (MODE 0 / 2);
                                                                    // add_lambda: phase 3 adds lambda I to the reduced system itself (svslam_sba_solve)
+                 double *xch; unsigned int *cnt; BaDev *parents; size_t xch_stride; };   // MODE 2 (low latency): exchange area, arrival counters, the problems
 #define SBA_IO_DOUBLES(np) ((size_t)(np) * (np) + 3 * (size_t)(np) + 8)
 
-template <int MODE>
+// Low-latency BA (MODE 2): ONE problem over LLW workgroups.  The phase cut is the shared-map one (MODE 1) — a shard holds all K
+// poses and a contiguous range of the landmarks with their edges (k_ba_split deals them by cost, k_ba_build builds every
+// shard's structure with all keyframes active) — but the whole LM loop stays in one launch and what ranks all-reduce over RCCL
+// the shards exchange through L2 / HBM inside the launch:
+//   sync 0 (once)     diag(Hpp) partials, largest landmark diagonal, chi2 of the start state -> lambda_0, currentChi
+//   sync A (per trial) the shard's partial reduced system: lower triangle of S = Hpp_w - sum_own W Dinv W^T, bs, bp; every shard
+//                     then adds the partials IN SHARD ORDER (bit-identical sums everywhere), adds lambda I, factors and solves
+//                     redundantly — no second hop to broadcast the 6K unknowns
+//   sync B (per trial) chi2 of the trial state and the landmark part of the rho denominator
+// Protocol (MI355X_MICROARCH.md, inter-workgroup visibility; cdna_hip_programming.md Guideline 16, R1 in its counter form):
+// payloads are written with agent-scope relaxed atomic stores (write-through `sc1`), every storing wave drains vmcnt, one lane
+// adds 1 to the problem's monotonic arrival counter and polls it relaxed; payloads are read with agent-scope relaxed atomic
+// loads (`sc1`: served past the CU's L1), so no release / acquire fence is needed.  A buffer written before sync X is next
+// written after the following sync Y, which nobody passes before everyone has read: A and B protect each other's buffers.
+// All shards of a problem must be resident (the host keeps problems x LLW far below the CU count); a shard that waits longer
+// than ~1 s sets the problem's abort word, every shard then returns with iters_done = -1.
+#define LL_SLAB(np) ((size_t)(np) * (np) + 2 * (size_t)(np))      // lower triangle of S in an np x np frame | bs | bp
+#define LL_X0(np) ((size_t)(np) + 2)                              // diag(Hpp) | landmark diagonal max | chi2
+#define LL_XB 4                                                   // chi2 of the trial | rho denominator (landmarks)
+__host__ __device__ inline size_t ll_xch_doubles(int np, int llw) { return (size_t)llw * (LL_SLAB(np) + LL_X0(np) + LL_XB); }
+#define LL_CNT_WORDS 4
+#define LL_MAX_W 16
+// A shard's edge records (both orders) and landmark positions (current and trial state) stay in LDS for the whole LM loop
+// when they fit these capacities (a shard of a K = 10 window over 8 workgroups: ~500 edges, ~220 landmarks); a larger shard
+// reads them from global memory like the batch kernel.  Then nothing inside an LM trial but the exchanges and a few index
+// arrays leaves the CU.
+#ifndef LL_ECAP
+#define LL_ECAP 704
+#endif
+#ifndef LL_LCAP
+#define LL_LCAP 448
+#endif
+typedef __attribute__((ext_vector_type(4))) unsigned int ll_u4;
+#define LL_SC1 16                                                 // aux bit of the raw buffer builtins: sc1 (agent scope: past L1, write-through)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ll_rsrc(double *base, size_t doubles)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(doubles * sizeof(double)), 0x00020000);
+}
+__device__ __forceinline__ void ll_st2(__amdgpu_buffer_rsrc_t r, size_t idx, double a, double b)      // doubles idx, idx + 1 (idx even)
+{
+    ll_u4 v;
+    v.x = (unsigned)__double2loint(a); v.y = (unsigned)__double2hiint(a); v.z = (unsigned)__double2loint(b); v.w = (unsigned)__double2hiint(b);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)(idx * sizeof(double)), 0, LL_SC1);
+}
+__device__ __forceinline__ ll_u4 ll_ld2(__amdgpu_buffer_rsrc_t r, size_t idx)
+{
+    return __builtin_amdgcn_raw_buffer_load_b128(r, (int)(idx * sizeof(double)), 0, LL_SC1);
+}
+__device__ __forceinline__ double ll_lo(ll_u4 v) { return __hiloint2double((int)v.y, (int)v.x); }
+__device__ __forceinline__ double ll_hi(ll_u4 v) { return __hiloint2double((int)v.w, (int)v.z); }
+__device__ __forceinline__ void ll_st(double *p, double v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ll_ld(const double *p)
+{
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT));
+}
+
+template <int MODE, int LLW>
 __global__ void __launch_bounds__(BA_THREADS, BA_MIN_WAVES_PER_SIMD)
 k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all, const BaRec *recs_all,
              const int *aux_all, BaWork wk, double delta, int iters, double *edge_chi2_all, long long *prof_all,
@@ -576,7 +643,8 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
     double *xp = bs + np;
     double *Hpp = xp + np;
     double *bp = Hpp + 36 * na;
-    double *red = bp + np;
+    double *bpt = bp + np;                         // MODE 2: bp summed over the shards (bp itself stays this shard's partial)
+    double *red = bpt + np;
     double *PTab = red + BA_WAVES;
     double *CTab = PTab + BA_PT * na;
     double *PTab2 = CTab + 2 * BA_CT;              // pose table of the trial state (errors of the trial, see the back-substitution)
@@ -591,6 +659,10 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
     int *Pcs = reinterpret_cast<int *>(Bl + 3 * tile_cap);   // [npairs + 1] item ranges of the current tile
     int *Pit = Pcs + (BA_MAX_NP / 6) * (BA_MAX_NP / 6 + 1) / 2 + 1;   // [BA_PIT_CAP] its items
     int *iflag = Pit + BA_PIT_CAP;
+    // MODE 2 only (ba_lds_bytes_ll): pose of each block of the tile, the shard's records, its positions
+    int *ll_ba = iflag + 16;                                                     // [tile_cap]
+    BaRec *ll_rec = reinterpret_cast<BaRec *>(ll_ba + ((tile_cap + 3) & ~3));   // [2 LL_ECAP]
+    double *ll_pts = reinterpret_cast<double *>(ll_rec + 2 * LL_ECAP);          // [2][3 LL_LCAP]
 
     const BaCams &cams = *camsp;
     double *poses = poses_all + (size_t)jd.kf_ofs * 7;
@@ -598,6 +670,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
     double *edge_chi2 = edge_chi2_all + jd.obs_ofs;
     const BaRec *recL = recs_all + jd.rec_ofs;       // landmark-major
     const BaRec *recP = recL + nobs;                   // pose-major
+    const bool ll_res = MODE == 2 && nobs <= LL_ECAP && nlm <= LL_LCAP;          // the shard lives in LDS
     const int *aux = aux_all + jd.aux_ofs;
     const int ntile = jd.ntile;
     const BaAuxLayout AL = ba_aux_layout(nkf, nlm, nobs, jd.lay_nblk, jd.lay_na, jd.ncontrib, jd.lay_ntile);
@@ -611,6 +684,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
     const size_t J = job;
     double *err = wk.err + J * 2 * wk.max_obs;
     double *poses_b = wk.poses_b + J * 7 * wk.max_kf;
+    double *poses_a = wk.poses_a + J * 7 * wk.max_kf;
     double *pts_b = wk.pts_b + J * 3 * wk.max_lm;
     double *pts = wk.pts_i + J * 3 * wk.max_lm;            // internal numbering (see BaHostStruct::build)
     const int *lm_orig = aux + AL.lm_orig;
@@ -618,15 +692,58 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
     // accepted trial swaps the roles, a rejected one costs nothing — no backup copy per trial (round 2: 41 KB of
     // positions copied, and copied back on rejection).  MODE 1 spans launches, so it updates in place and keeps the
     // backup copies (cur == trial).
-    double *cur = pts, *trial = MODE == 0 ? pts_b : pts;
-    double *pcur = poses, *ptrial = MODE == 0 ? poses_b : poses;
-    if (MODE == 0 || sba.first)
+    // (MODE 2: the shards of a problem share `poses`; each keeps both of its pose buffers in its own workspace)
+    double *cur = pts, *trial = MODE != 1 ? pts_b : pts;
+    double *pcur = MODE == 2 ? poses_a : poses, *ptrial = MODE != 1 ? poses_b : poses;
+    if (MODE == 2 && ll_res) {
+        for (int i = tid; i < 2 * nobs; i += BA_THREADS) ll_rec[i] = recL[i];
+        for (int j = tid; j < nlm; j += BA_THREADS) {
+            const double *s3 = pts_io + 3 * (size_t)lm_orig[j];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { ll_pts[3 * j + c] = s3[c]; ll_pts[3 * LL_LCAP + 3 * j + c] = s3[c]; }
+        }
+        recL = ll_rec; recP = ll_rec + nobs;
+        cur = ll_pts; trial = ll_pts + 3 * LL_LCAP;
+    } else if (MODE != 1 || sba.first)
         for (int j = tid; j < nlm; j += BA_THREADS) {
             const double *s3 = pts_io + 3 * (size_t)lm_orig[j];
             pts[3 * (size_t)j] = s3[0]; pts[3 * (size_t)j + 1] = s3[1]; pts[3 * (size_t)j + 2] = s3[2];
-            if (MODE == 0) { pts_b[3 * (size_t)j] = s3[0]; pts_b[3 * (size_t)j + 1] = s3[1]; pts_b[3 * (size_t)j + 2] = s3[2]; }   // edge-less landmarks never move
+            if (MODE != 1) { pts_b[3 * (size_t)j] = s3[0]; pts_b[3 * (size_t)j + 1] = s3[1]; pts_b[3 * (size_t)j + 2] = s3[2]; }   // edge-less landmarks never move
         }
-    if (MODE == 0) for (int i = tid; i < 7 * nkf; i += BA_THREADS) poses_b[i] = poses[i];   // keyframes without edges never move
+    if (MODE != 1) for (int i = tid; i < 7 * nkf; i += BA_THREADS) { const double v = poses[i]; poses_b[i] = v; if (MODE == 2) poses_a[i] = v; }   // keyframes without edges never move
+    // ---- MODE 2: this shard's place in its problem, the exchange area, the arrival counter
+    const int ll_prob = MODE == 2 ? job / LLW : 0, ll_w = MODE == 2 ? job % LLW : 0;
+    const unsigned ll_mask = MODE == 2 ? (unsigned)jd.shmask : 0u;
+    const bool ll_leader = MODE == 2 && (ll_mask & ((1u << ll_w) - 1u)) == 0u;       // lowest shard with edges: writes the poses back
+    double *ll_xs = MODE == 2 ? sba.xch + (size_t)ll_prob * sba.xch_stride : nullptr;  // [LLW][LL_SLAB]
+    double *ll_x0 = MODE == 2 ? ll_xs + (size_t)LLW * LL_SLAB(np) : nullptr;           // [LLW][LL_X0]
+    double *ll_xb = MODE == 2 ? ll_x0 + (size_t)LLW * LL_X0(np) : nullptr;             // [LLW][LL_XB]
+    unsigned int *ll_cnt = MODE == 2 ? sba.cnt + (size_t)LL_CNT_WORDS * ll_prob : nullptr;
+    unsigned ll_ep = 0, ll_epb = 0;
+    const unsigned ll_n = __popc(ll_mask);
+    auto ll_sync = [&]() -> bool {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // every storing wave: its write-through stores have left
+        __syncthreads();
+        ++ll_ep;
+        if (tid0 == 0) {
+            __hip_atomic_fetch_add(ll_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = ll_n * ll_ep;
+            unsigned spins = 0;
+            int good = 1;
+            while (__hip_atomic_load(ll_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(2);
+                if ((++spins & 1023u) == 0 &&
+                    (spins > (1u << 21) || __hip_atomic_load(ll_cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                    __hip_atomic_store(ll_cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    good = 0;
+                    break;
+                }
+            }
+            iflag[1] = good;
+        }
+        __syncthreads();
+        return iflag[1] != 0;
+    };
     double *sio = MODE == 1 ? sba.io + (size_t)job * SBA_IO_DOUBLES(np) : nullptr;
     double *sio_S = sio, *sio_bs = sio + (size_t)np * np, *sio_bp = sio_bs + np, *sio_hd = sio_bp + np, *sio_sc = sio_hd + np;
 
@@ -761,7 +878,8 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
         return;
     }
     if (MODE == 1 && sba.phase == 5) iters = 0;            // finalise: straight to the write-back
-    const bool lin = MODE == 0 || sba.phase <= 2;          // this launch linearises (pose pass, Schur sweep)
+    const bool lin = MODE != 1 || sba.phase <= 2;          // this launch linearises (pose pass, Schur sweep)
+    bool ll_failed = false;                                // MODE 2: an exchange timed out
     // last state whose residuals were evaluated (g2o reports the edge chi2 of its last computeActiveErrors, the state of
     // the last trial even when that trial was rejected): the per-edge chi2 are computed from it at the end (MODE 0)
     const double *last_pts = cur, *last_poses = pcur;
@@ -774,12 +892,13 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
         }
         __syncthreads();
         BA_PROF(1);
-        if (it == 0 && (MODE == 0 || sba.phase == 1)) {
+        if (it == 0 && (MODE != 1 || sba.phase == 1)) {
             BA_PHASE_TID;
             // lambda_0 = 1e-5 * max diagonal of the Hessian: the landmark diagonals need one cheap sweep
             double md = 0;
             if (MODE == 0) for (int i = tid; i < np; i += BA_THREADS) md = fmax(md, fabs(Hpp[36 * (i / 6) + (i % 6) * 7]));
-            else for (int i = tid; i < np; i += BA_THREADS) sio_hd[i] = Hpp[36 * (i / 6) + (i % 6) * 7];   // summed over the ranks first
+            else if (MODE == 1) for (int i = tid; i < np; i += BA_THREADS) sio_hd[i] = Hpp[36 * (i / 6) + (i % 6) * 7];   // summed over the ranks first
+            else for (int i = tid; i < np; i += BA_THREADS) ll_st(ll_x0 + (size_t)ll_w * LL_X0(np) + i, Hpp[36 * (i / 6) + (i % 6) * 7]);   // ... over the shards
             for (int j = tid; j < nlm; j += BA_THREADS) {
                 const double X[3] = { cur[3 * (size_t)j], cur[3 * (size_t)j + 1], cur[3 * (size_t)j + 2] };
                 double h0 = 0, h3 = 0, h5 = 0;
@@ -796,6 +915,22 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
             }
             md = block_max(md, red, tid);
             if (MODE == 1) { if (tid == 0) sio_sc[1] = md; return; }
+            if (MODE == 2) {
+                // sync 0: the pose diagonals are sums over the shards, the landmark maximum a maximum, chi2 a sum
+                if (tid == 0) { ll_st(ll_x0 + (size_t)ll_w * LL_X0(np) + np, md); ll_st(ll_x0 + (size_t)ll_w * LL_X0(np) + np + 1, chi_lin); }
+                if (!ll_sync()) { ll_failed = true; break; }
+                double m2 = 0, chs = 0;
+#pragma unroll
+                for (int v = 0; v < LLW; ++v) { m2 = fmax(m2, ll_ld(ll_x0 + (size_t)v * LL_X0(np) + np)); chs += ll_ld(ll_x0 + (size_t)v * LL_X0(np) + np + 1); }
+                for (int i = tid; i < np; i += BA_THREADS) {
+                    double hd = 0;
+#pragma unroll
+                    for (int v = 0; v < LLW; ++v) hd += ll_ld(ll_x0 + (size_t)v * LL_X0(np) + i);
+                    m2 = fmax(m2, fabs(hd));
+                }
+                md = block_max(m2, red, tid);
+                chi_lin = chs;
+            }
             lambda = 1e-5 * md; ni = 2;
         }
         double tempChi = 0;
@@ -946,6 +1081,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                         h[3] += wl1 * L.jl[1] + wl4 * L.jl[4]; h[4] += wl1 * L.jl[2] + wl4 * L.jl[5]; h[5] += wl2 * L.jl[2] + wl5 * L.jl[5];
                     }
                     double *wd = Wt + 18 * bq;
+                    if (MODE == 2) ll_ba[bq] = (int)((unsigned)recL[e0].lmkc >> 25);      // the block's pose (back-substitution from the stored blocks)
 #pragma unroll
                     for (int t = 0; t < 18; ++t) wd[t] = wacc[t];
                     double *dd = Dl + 6 * bq;
@@ -1024,6 +1160,51 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                     S[(size_t)(i / np) * ld + (i % np)] = sio_S[i] + ((sba.add_lambda && i / np == i % np) ? sba.lambda : 0.0);
                 for (int i = tid; i < np; i += BA_THREADS) { bs[i] = sio_bs[i]; bp[i] = sio_bp[i]; }
                 __syncthreads();
+            }
+            if (MODE == 2) {
+                // sync A: publish this shard's partial system, then every shard adds all partials in shard order
+                // (shards without edges were zeroed by k_ba_split), lambda I goes on once
+                // (16-byte write-through stores / past-L1 loads through a buffer descriptor: pairs of columns 2p, 2p + 1 <= r + 1
+                // of row r — S is kept symmetric in LDS, so the pair that straddles the diagonal is valid too)
+                BA_PHASE_TID;
+                const __amdgpu_buffer_rsrc_t rs_all = ll_rsrc(ll_xs, (size_t)LLW * LL_SLAB(np));
+                const size_t mine = (size_t)ll_w * LL_SLAB(np);
+                const int hp_ = np >> 1;
+                for (int it2 = tid; it2 < np * hp_; it2 += BA_THREADS) {
+                    const int r = it2 / hp_, pc = 2 * (it2 - r * hp_);
+                    if (pc <= r) ll_st2(rs_all, mine + (size_t)r * np + pc, S[(size_t)r * ld + pc], S[(size_t)r * ld + pc + 1]);
+                }
+                for (int it2 = tid; it2 < np; it2 += BA_THREADS) {          // bs | bp behind the matrix, in pairs
+                    const double *src = it2 < hp_ ? bs + 2 * it2 : bp + 2 * (it2 - hp_);
+                    ll_st2(rs_all, mine + (size_t)np * np + 2 * it2, src[0], src[1]);
+                }
+                if (!ll_sync()) { ll_failed = true; break; }
+                for (int it2 = tid; it2 < np * hp_; it2 += BA_THREADS) {
+                    const int r = it2 / hp_, pc = 2 * (it2 - r * hp_);
+                    if (pc > r) continue;
+                    ll_u4 part[LLW];
+#pragma unroll
+                    for (int v = 0; v < LLW; ++v) part[v] = ll_ld2(rs_all, (size_t)v * LL_SLAB(np) + (size_t)r * np + pc);
+                    double s0 = ll_lo(part[0]), s1 = ll_hi(part[0]);
+#pragma unroll
+                    for (int v = 1; v < LLW; ++v) { s0 += ll_lo(part[v]); s1 += ll_hi(part[v]); }
+                    if (pc == r) s0 += lambda;
+                    if (pc + 1 == r) s1 += lambda;
+                    S[(size_t)r * ld + pc] = s0; S[(size_t)pc * ld + r] = s0;
+                    if (pc + 1 <= r) { S[(size_t)r * ld + pc + 1] = s1; S[(size_t)(pc + 1) * ld + r] = s1; }
+                }
+                for (int it2 = tid; it2 < np; it2 += BA_THREADS) {
+                    ll_u4 part[LLW];
+#pragma unroll
+                    for (int v = 0; v < LLW; ++v) part[v] = ll_ld2(rs_all, (size_t)v * LL_SLAB(np) + (size_t)np * np + 2 * it2);
+                    double s0 = ll_lo(part[0]), s1 = ll_hi(part[0]);
+#pragma unroll
+                    for (int v = 1; v < LLW; ++v) { s0 += ll_lo(part[v]); s1 += ll_hi(part[v]); }
+                    double *dst = it2 < hp_ ? bs + 2 * it2 : bpt + 2 * (it2 - hp_);
+                    dst[0] = s0; dst[1] = s1;
+                }
+                __syncthreads();
+                BA_PROF(3);
             }
             // ---- blocked (6x6 = one pose) right-looking Cholesky S = L L^T in LDS on the whole
             // workgroup; the right-hand side rides along as row np, so L y = bs comes out of the
@@ -1186,7 +1367,30 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
             BA_PROF(4);
             const int ok2 = iflag[0];
             double scale_part = 0, scale_pose_part = 0;
-            if (ok2) {
+            // MODE 2, the whole shard in ONE tile: W, (Hll + lambda I)^-1 and bl of every landmark are still in LDS
+            const bool ll_stored = MODE == 2 && ntile == 1 && jd.nmv == nlm;
+            if (ok2 && ll_stored) {
+                BA_PHASE_TID;
+                for (int j = tid; j < nlm; j += BA_THREADS) {
+                    const int b0 = lm_bstart[j], b1 = lm_bstart[j + 1];
+                    if (b1 <= b0) continue;
+                    double g0 = 0, g1 = 0, g2 = 0;
+                    for (int b = b0; b < b1; ++b) {
+                        const double *w18 = Wt + 18 * b, *x6 = xp + 6 * ll_ba[b];
+#pragma unroll
+                        for (int r = 0; r < 6; ++r) { g0 += w18[3 * r] * x6[r]; g1 += w18[3 * r + 1] * x6[r]; g2 += w18[3 * r + 2] * x6[r]; }
+                    }
+                    const double *Di = Dl + 6 * j;
+                    const double bl0 = Bl[3 * j], bl1 = Bl[3 * j + 1], bl2 = Bl[3 * j + 2];
+                    const double c0 = bl0 - g0, c1 = bl1 - g1, c2 = bl2 - g2;
+                    const double x0 = Di[0] * c0 + Di[1] * c1 + Di[2] * c2, x1 = Di[1] * c0 + Di[3] * c1 + Di[4] * c2,
+                                 x2 = Di[2] * c0 + Di[4] * c1 + Di[5] * c2;
+                    trial[3 * (size_t)j] = cur[3 * (size_t)j] + x0; trial[3 * (size_t)j + 1] = cur[3 * (size_t)j + 1] + x1;
+                    trial[3 * (size_t)j + 2] = cur[3 * (size_t)j + 2] + x2;
+                    scale_part += x0 * (lambda * x0 + bl0) + x1 * (lambda * x1 + bl1) + x2 * (lambda * x2 + bl2);
+                }
+            }
+            if (ok2 && !ll_stored) {
                 BA_PHASE_TID;
                 // back-substitution with the Jacobians recomputed (the pose table still holds the
                 // linearisation point): dl = Dinv (bl - sum W^T dp) = -Dinv sum Jl^T w (r + Jp dp)
@@ -1231,6 +1435,9 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                     }
                     e0 = ne0; e1 = ne1; X[0] = Xn[0]; X[1] = Xn[1]; X[2] = Xn[2];
                 }
+            }
+            if (ok2) {
+                BA_PHASE_TID;
                 for (int a = tid; a < na; a += BA_THREADS) {
                     const int k = act_kf[a];
                     double dT[7], Tn[7], x6[6];
@@ -1239,7 +1446,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                         x6[t] = xp[6 * a + t];
                         // shared map: every rank computes the same pose part; the host counts it once
                         if (MODE == 0) scale_part += x6[t] * (lambda * x6[t] + bp[6 * a + t]);
-                        else scale_pose_part += x6[t] * (lambda * x6[t] + bp[6 * a + t]);
+                        else scale_pose_part += x6[t] * (lambda * x6[t] + (MODE == 2 ? bpt : bp)[6 * a + t]);   // MODE 2: every shard computes the same
                     }
                     d_se3_exp(x6, dT);
                     d_se3_mul(dT, pcur + 7 * k, Tn);
@@ -1248,7 +1455,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                 }
             }
             double scale = block_sum(scale_part, red, tid);
-            const double scale_pose = MODE == 1 ? block_sum(scale_pose_part, red, tid) : 0.0;
+            const double scale_pose = MODE != 0 ? block_sum(scale_pose_part, red, tid) : 0.0;
             __syncthreads();
             BA_PROF(5);
             // (a failed factorisation updates nothing: its errors are those of the unchanged state, like the oracle's)
@@ -1265,11 +1472,54 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                 if (tid == 0) { sio_sc[2] = (double)ok2; sio_sc[3] = scale; sio_sc[4] = scale_pose; sio_sc[5] = tempChi; }
                 return;
             }
+            if (MODE == 2) {
+                // sync B: chi2 of the trial state and the landmark part of the rho denominator, summed in shard order
+                // (a failed factorisation still meets here: the exchange also keeps the slabs safe from the next trial)
+                // The data is the flag (Guideline 16, R2): each double travels as two 8-byte granules { epoch tag, 32 bits },
+                // one aligned store each; wave 0 sweeps the 4 LLW granules until every tag is this exchange's epoch (the
+                // granules were zeroed by k_ba_split, epochs count from 1).  No counter, no drain, one hop.
+                BA_PHASE_TID;
+                ++ll_epb;
+                unsigned long long *gran = reinterpret_cast<unsigned long long *>(ll_xb);
+                if (tid < 4) {
+                    const double val = tid < 2 ? (ok2 ? tempChi : 0.0) : scale;
+                    const unsigned half = (tid & 1) ? (unsigned)__double2hiint(val) : (unsigned)__double2loint(val);
+                    __hip_atomic_store(gran + 4 * ll_w + tid, ((unsigned long long)ll_epb << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (wv == 0) {
+                    const bool mineg = lane < 4 * LLW && ((ll_mask >> (lane >> 2)) & 1u);
+                    unsigned long long x = 0;
+                    unsigned spins = 0;
+                    int good = 1;
+                    for (;;) {
+                        if (mineg) x = __hip_atomic_load(gran + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (__all(!mineg || (unsigned)(x >> 32) == ll_epb)) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        if ((++spins & 1023u) == 0 &&
+                            (spins > (1u << 21) || __hip_atomic_load(ll_cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                            __hip_atomic_store(ll_cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            good = 0;
+                            break;
+                        }
+                    }
+                    const int half = mineg ? (int)(unsigned)x : 0;          // shards without edges count as 0.0
+                    double cs = 0, ss = 0;
+#pragma unroll
+                    for (int v = 0; v < LLW; ++v) {
+                        cs += __hiloint2double(__builtin_amdgcn_readlane(half, 4 * v + 1), __builtin_amdgcn_readlane(half, 4 * v));
+                        ss += __hiloint2double(__builtin_amdgcn_readlane(half, 4 * v + 3), __builtin_amdgcn_readlane(half, 4 * v + 2));
+                    }
+                    if (lane == 0) { red[0] = cs; red[1] = ss; iflag[1] = good; }
+                }
+                __syncthreads();
+                if (!iflag[1]) { ll_failed = true; break; }
+                tempChi = red[0]; scale = red[1] + scale_pose;
+            }
             if (!ok2) tempChi = 1.7976931348623157e308;
             rho = currentChi - tempChi;
             scale += 1e-3;
             rho /= scale;
-            if (sba.trace && tid == 0) lm_trace_put(sba.trace, job, it, lambda, currentChi, tempChi, rho, rho > 0 && isfinite(tempChi));
+            if (sba.trace && tid == 0 && (MODE != 2 || ll_leader)) lm_trace_put(sba.trace, MODE == 2 ? ll_prob : job, it, lambda, currentChi, tempChi, rho, rho > 0 && isfinite(tempChi));
             if (rho > 0 && isfinite(tempChi)) {
                 double t = 2 * rho - 1;
                 double alpha = 1. - t * t * t;
@@ -1289,10 +1539,15 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
             ++qmax;
             if (prof && tid == 0) prof[BA_PROF_N - 1] += 1;
         } while (rho < 0 && qmax < 10);
+        if (ll_failed) break;
         ++it_done;
         if (qmax == 10 || rho == 0 || !isfinite(lambda)) break;
     }
     __syncthreads();
+    if (MODE == 2 && ll_failed) {                          // a shard never arrived: nothing is written back
+        if (tid == 0) { jd.iters_done = -1; if (ll_leader) sba.parents[ll_prob].iters_done = -1; }
+        return;
+    }
     if (MODE == 1) {
         for (int i = tid; i < nobs; i += BA_THREADS) edge_chi2[lm_edges[i]] = err[2 * i] * err[2 * i] + err[2 * i + 1] * err[2 * i + 1];
     } else {
@@ -1319,14 +1574,14 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
         double *d3 = pts_io + 3 * (size_t)lm_orig[j];
         d3[0] = cur[3 * (size_t)j]; d3[1] = cur[3 * (size_t)j + 1]; d3[2] = cur[3 * (size_t)j + 2];
     }
-    if (pcur != poses) for (int i = tid; i < 7 * nkf; i += BA_THREADS) poses[i] = pcur[i];
-    if (tid == 0) jd.iters_done = it_done;
+    if (pcur != poses && (MODE != 2 || ll_leader)) for (int i = tid; i < 7 * nkf; i += BA_THREADS) poses[i] = pcur[i];
+    if (tid == 0) { jd.iters_done = it_done; if (MODE == 2 && ll_leader) sba.parents[ll_prob].iters_done = it_done; }
 }
 
 static inline size_t ba_lds_fixed_bytes(int max_kf)
 {
     size_t np = 6 * (size_t)max_kf;
-    return ((np + 1) * (np + 1) + 3 * np + 36 * (size_t)max_kf + BA_WAVES + 2 * BA_PT * (size_t)max_kf + 2 * BA_CT +
+    return ((np + 1) * (np + 1) + 4 * np + 36 * (size_t)max_kf + BA_WAVES + 2 * BA_PT * (size_t)max_kf + 2 * BA_CT +
             32 * BA_ROWS) * sizeof(double) +
            ((BA_MAX_NP / 6) * (BA_MAX_NP / 6 + 1) / 2 + 1 + BA_PIT_CAP) * sizeof(int) + 64;
 }
@@ -1340,4 +1595,15 @@ static inline int ba_tile_cap(int max_kf)
     return (int)(t > BA_TILE_MAX ? BA_TILE_MAX : t);
 }
 static inline size_t ba_lds_bytes(int max_kf) { return ba_lds_fixed_bytes(max_kf) + 27 * sizeof(double) * (size_t)ba_tile_cap(max_kf); }
+// low-latency shards (MODE 2): the resident records / positions take their share, a block also notes its pose
+static inline size_t ba_lds_fixed_bytes_ll(int max_kf) { return ba_lds_fixed_bytes(max_kf) + 2 * LL_ECAP * sizeof(BaRec) + 6 * LL_LCAP * sizeof(double) + 64; }
+static inline int ba_tile_cap_ll(int max_kf)
+{
+    const size_t lim = BA_LDS_LIMIT, fixed = ba_lds_fixed_bytes_ll(max_kf), per = 27 * sizeof(double) + sizeof(int);
+    if (fixed + per * 64 > lim) return 0;
+    size_t t = (lim - fixed) / per;
+    t = t / 16 * 16;
+    return (int)(t > BA_TILE_MAX ? BA_TILE_MAX : t);
+}
+static inline size_t ba_lds_bytes_ll(int max_kf) { return ba_lds_fixed_bytes_ll(max_kf) + (27 * sizeof(double) + sizeof(int)) * (size_t)ba_tile_cap_ll(max_kf); }
 #pragma clang fp contract(off)

@@ -66,7 +66,7 @@ static inline size_t bb_lds_bytes(int max_nlm, int max_nobs = 0)
 __global__ void __launch_bounds__(BB_THREADS)
 k_ba_build(BaDev *jobs, const unsigned int *obs_packed, const float2 *obs_uv,
            const int *srt_all, BaRec *recs_all, int *aux_all, int tile_cap, int max_nlm, int *err_flag, int all_active,
-           int edge_cache)
+           int edge_cache, int no_group)
 {
     extern __shared__ __attribute__((aligned(16))) int bb_lds[];
     BaDev &jd = jobs[blockIdx.x];
@@ -77,6 +77,7 @@ k_ba_build(BaDev *jobs, const unsigned int *obs_packed, const float2 *obs_uv,
     const unsigned int *opk = obs_packed + jd.obs_ofs;
     const int *srt = srt_all + jd.obs_ofs;
     const bool ident = jd.reserved != 0;
+    const unsigned int lm_base = (unsigned int)jd.lm_base;      // a low-latency shard: landmarks [lm_base, lm_base + nlm) of its parent
     const float2 *ouv = obs_uv + jd.obs_ofs;
     BaRec *recL = recs_all + jd.rec_ofs, *recP = recL + nobs;
     int *aux = aux_all + jd.aux_ofs;
@@ -113,14 +114,14 @@ k_ba_build(BaDev *jobs, const unsigned int *obs_packed, const float2 *obs_uv,
             for (int u = 0; u < 4; ++u) { const int i = i0 + u * BB_THREADS; e4[u] = i < nobs ? (ident ? i : srt[i]) : 0; }
             unsigned int v4[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v4[u] = opk[e4[u]];
+            for (int u = 0; u < 4; ++u) v4[u] = opk[e4[u]] - lm_base;
 #pragma unroll
             for (int u = 0; u < 4; ++u) { const int i = i0 + u * BB_THREADS; if (i < nobs) ed[i] = v4[u]; }
         }
     }
     auto edge = [&](int i) -> unsigned int {
         if (edge_cache) return ed[i];
-        return opk[ident ? i : srt[i]];
+        return opk[ident ? i : srt[i]] - lm_base;
     };
 
     for (int l = tid; l <= nlm; l += BB_THREADS) { cnt[l] = 0; }
@@ -168,7 +169,8 @@ k_ba_build(BaDev *jobs, const unsigned int *obs_packed, const float2 *obs_uv,
     // ---- 3. landmarks renumbered by descending block count, the single-view ones grouped by their keyframe, the
     //         ones without edges last (BaHostStruct::build has the same key), stable: flattened [key][thread]
     //         counting sort.  sv_start[k] = first landmark of keyframe k's single-view group; nmv = sv_start[0].
-    const bool grouped = maxc >= 1 && maxc + nkf <= BB_MAXKEYS;
+    // (no_group: a low-latency shard keeps every landmark in its LDS tile, whose blocks the back-substitution reuses)
+    const bool grouped = !no_group && maxc >= 1 && maxc + nkf <= BB_MAXKEYS;
     const int nkeys = grouped ? maxc + nkf : maxc + 1;
     const int lper = (nlm + BB_THREADS - 1) / BB_THREADS;
     {
@@ -320,4 +322,114 @@ k_ba_build(BaDev *jobs, const unsigned int *obs_packed, const float2 *obs_uv,
         g_pcs[nlist] = small[3];
         jd.nblk = nblk; jd.na = na; jd.ncontrib = small[3]; jd.ntile = ntile; jd.nmv = nmv;
     }
+}
+
+// ---------------------------------------------------------------- low-latency BA: one problem -> LLW shards
+// Deals the landmarks of a problem (edges landmark-major, the order the backend gathers them in) to `llw` shards of
+// CONTIGUOUS landmark ranges with about equal cost (a landmark with e edges costs e (4 + e): linearisation + block pairs),
+// so a shard is a sub-range of the parent's landmark, position and edge arrays and k_ba_build / k_local_ba_t<2> work on it
+// in place: results land where the parent's caller expects them.  Every shard gets all keyframes (k_ba_build all_active).
+// One workgroup per problem.  Shards without edges are masked out (BaDev::shmask) and their exchange slots zeroed.
+__global__ void __launch_bounds__(BB_THREADS)
+k_ba_split(const BaDev *parents, BaDev *shards, const unsigned int *obs_packed, int llw, int tile_cap, int max_nlm,
+           double *xch, size_t xch_stride, unsigned int *cnt)
+{
+    extern __shared__ __attribute__((aligned(16))) int sp_lds[];
+    const BaDev &pd = parents[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int nkf = pd.nkf, nlm = pd.nlm, nobs = pd.nobs, np = 6 * nkf;
+    BaDev *sh = shards + (size_t)blockIdx.x * llw;
+    int *estart = sp_lds;                     // [nlm + 1] first edge of landmark l
+    long long *cost = reinterpret_cast<long long *>(sp_lds + ((max_nlm + 2 + 1) & ~1));   // [nlm + 1] exclusive prefix of the cost
+    long long *tmpl = cost + max_nlm + 2;     // [BB_THREADS]
+    int *cut = reinterpret_cast<int *>(tmpl + BB_THREADS);    // [llw + 1] first landmark of shard w
+    if (tid < LL_CNT_WORDS) cnt[(size_t)LL_CNT_WORDS * blockIdx.x + tid] = 0u;    // arrival counter + abort word of this call
+    const bool empty = nobs <= 0 || nlm <= 0 || nkf <= 0 || pd.reserved == 0;        // (unsorted edges: the host does not come here)
+    if (empty) {
+        for (int w = tid; w < llw; w += BB_THREADS) {
+            BaDev d = pd;
+            d.nlm = 0; d.nobs = 0; d.nblk = d.na = d.ncontrib = d.ntile = d.nmv = 0; d.shmask = 0; d.lm_base = 0; d.iters_done = 0;
+            sh[w] = d;
+        }
+        return;
+    }
+    const unsigned int *opk = obs_packed + pd.obs_ofs;
+    for (int i = tid; i < nobs; i += BB_THREADS) {
+        const int l = (int)(opk[i] & 0xffffu);
+        const int lp = i > 0 ? (int)(opk[i - 1] & 0xffffu) : -1;
+        if (l != lp) for (int q = lp + 1; q <= l; ++q) estart[q] = i;
+        if (i == nobs - 1) for (int q = l + 1; q <= nlm; ++q) estart[q] = nobs;
+    }
+    __syncthreads();
+    // exclusive prefix of the landmark costs
+    const int per = (nlm + BB_THREADS - 1) / BB_THREADS;
+    const int l0 = min(tid * per, nlm), l1 = min(l0 + per, nlm);
+    long long sum = 0;
+    for (int l = l0; l < l1; ++l) { const long long e = estart[l + 1] - estart[l]; sum += e * (4 + e); }
+    tmpl[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < BB_THREADS; d <<= 1) {
+        const long long add = tid >= d ? tmpl[tid - d] : 0;
+        __syncthreads();
+        tmpl[tid] += add;
+        __syncthreads();
+    }
+    const long long total = tmpl[BB_THREADS - 1];
+    {
+        long long run = tmpl[tid] - sum;
+        for (int l = l0; l < l1; ++l) { const long long e = estart[l + 1] - estart[l]; cost[l] = run; run += e * (4 + e); }
+        if (tid == 0) cost[nlm] = total;
+    }
+    if (tid <= llw) cut[tid] = tid == llw ? nlm : -1;
+    __syncthreads();
+    // shard of landmark l = floor(cost_before(l) * llw / total); cut[w] = first landmark of shard w (monotone)
+    auto shard_of = [&](int l) -> int { const int w = (int)((cost[l] * llw) / (total > 0 ? total : 1)); return w < llw ? w : llw - 1; };
+    for (int l = tid; l < nlm; l += BB_THREADS) {
+        const int w = shard_of(l), wp = l > 0 ? shard_of(l - 1) : -1;
+        for (int q = wp + 1; q <= w; ++q) cut[q] = l;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = llw - 1; w >= 0; --w) if (cut[w] < 0) cut[w] = cut[w + 1];      // shards nothing fell into: empty ranges
+        unsigned mask = 0;
+        for (int w = 0; w < llw; ++w) if (estart[cut[w + 1]] > estart[cut[w]]) mask |= 1u << w;
+        size_t aux = (size_t)pd.aux_ofs;
+        for (int w = 0; w < llw; ++w) {
+            const int a = cut[w], b = cut[w + 1], e0 = estart[a], e1 = estart[b];
+            BaDev d = pd;
+            d.lm_ofs = pd.lm_ofs + a; d.nlm = b - a; d.obs_ofs = pd.obs_ofs + e0; d.nobs = e1 - e0; d.lm_base = a; d.shmask = (int)mask;
+            d.nblk = d.na = d.ncontrib = d.ntile = d.nmv = 0; d.iters_done = 0; d.reserved = 1;
+            d.rec_ofs = pd.rec_ofs + 2 * e0;
+            d.lay_nblk = d.nobs; d.lay_na = nkf; d.lay_ntile = ba_tile_bound(d.nlm, d.nobs, nkf, tile_cap);
+            d.aux_ofs = (int)aux;
+            aux += ba_aux_layout(nkf, d.nlm, d.nobs, d.lay_nblk, d.lay_na, 0, d.lay_ntile).total + ba_pitem_bound(d.nobs, nkf);
+            sh[w] = d;
+        }
+        tmpl[0] = (long long)mask;
+    }
+    __syncthreads();
+    // shards without edges never publish: their slots of the exchange area read as zero
+    const unsigned mask = (unsigned)tmpl[0];
+    double *xs = xch + (size_t)blockIdx.x * xch_stride;
+    for (int w = 0; w < llw; ++w) {
+        if ((mask >> w) & 1u) continue;
+        double *slab = xs + (size_t)w * LL_SLAB(np), *x0 = xs + (size_t)llw * LL_SLAB(np) + (size_t)w * LL_X0(np);
+        for (size_t i = tid; i < LL_SLAB(np); i += BB_THREADS) slab[i] = 0.0;
+        for (size_t i = tid; i < LL_X0(np); i += BB_THREADS) x0[i] = 0.0;
+    }
+    // the granules of the rho exchange are tagged with epochs that count from 1 in every launch: all of them start at 0
+    {
+        double *xb = xs + (size_t)llw * (LL_SLAB(np) + LL_X0(np));
+        for (int i = tid; i < llw * LL_XB; i += BB_THREADS) xb[i] = 0.0;
+    }
+}
+// extra aux ints a parent's reservation needs so that its llw shards fit (per-shard constants of ba_aux_layout, two tiles of
+// slack per shard in ba_tile_bound, one pair-item of slack)
+__host__ __device__ inline size_t ba_split_aux_extra(int nkf, int llw)
+{
+    return (size_t)llw * (16 + 4 * (size_t)nkf + 3 * ((size_t)nkf * (nkf + 1) / 2 + 1) + 4);
+}
+static inline size_t ba_split_lds_bytes(int max_nlm, int llw)
+{
+    return sizeof(int) * (size_t)((max_nlm + 2 + 1) & ~1) + sizeof(long long) * ((size_t)max_nlm + 2 + BB_THREADS) + sizeof(int) * (size_t)(llw + 2) + 64;
 }

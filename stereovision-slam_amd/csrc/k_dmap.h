@@ -338,7 +338,7 @@ k_dmap_ba_gather(DmJob *jobs, DMap m, DmParams prm, BaDev *badev, double *poses,
     if (tid == 0) {
         bd.kf_ofs = j * max_kf; bd.lm_ofs = j * NL; bd.obs_ofs = j * prm.max_obs; bd.rec_ofs = 2 * j * prm.max_obs;
         bd.nkf = bd.nlm = bd.nobs = 0; bd.nblk = bd.na = bd.ncontrib = bd.ntile = 0; bd.iters_done = 0; bd.nmv = 0; bd.reserved = 1;
-        bd.aux_ofs = (int)(aux_stride * j); bd.lay_nblk = bd.lay_na = bd.lay_ntile = 0;
+        bd.aux_ofs = (int)(aux_stride * j); bd.lay_nblk = bd.lay_na = bd.lay_ntile = 0; bd.lm_base = 0; bd.shmask = 0;
     }
     if (jb.dead) return;
     // active keyframes in id order (Map::active_keyframes_ is id-ordered): <= KW of them
@@ -474,6 +474,7 @@ k_dmap_ba_scatter(DmJob *jobs, DMap m, DmParams prm, const BaDev *badev, const d
     const BaDev &bd = badev[blockIdx.x];
     const int tid = threadIdx.x, s = jb.stream, j = blockIdx.x;
     if (jb.dead || bd.nobs <= 0) return;
+    if (bd.iters_done < 0) { if (tid == 0) jb.ba_iters = -1; return; }      // the low-latency solver gave up: nothing to apply (the host fails the call)
     const size_t EO = (size_t)j * prm.max_obs, L = dm_l(m, s);
     const int nobs = bd.nobs;
     // threshold doubling until more than half of the edges are inliers (:167-193)

@@ -34,6 +34,7 @@
 
 #define SVSLAM_DMAP_CHUNK 512     /* keyframe jobs per svslam_dmap_keyframe_batch call the staging arena is sized for */
 #define SVSLAM_DMAP_EVICT_PER_JOB 512   /* evicted-landmark records per job of a call (shared by the call's jobs; the surplus waits) */
+#define SVSLAM_LL_MAX_PROBLEMS 8        /* local-BA problems per call that the low-latency path (one problem over several workgroups) takes */
 
 namespace {
 
@@ -81,6 +82,8 @@ struct svslam_ctx {
     BaWork bw;
     std::unique_ptr<svs::ThreadPool> pool;   // host-side per-problem preparation
     long long *d_ba_prof = nullptr;
+    // low-latency local BA (svslam_set_low_latency): a problem is dealt over ll.w workgroups (k_ba_split, k_local_ba_t<2>)
+    struct { int w = 0; BaDev *shards = nullptr; double *xch = nullptr; unsigned int *cnt = nullptr; size_t xch_stride = 0; BaWork bw; } ll;
     double *d_lm_trace = nullptr;            // svslam_lm_trace test hook: [max_jobs][LM_TRACE_STRIDE]
     // host-side wall time (ns): 0 h2d enqueue, 1 d2h enqueue, 2 stream wait, 3 launches, 4 staging memcpy/prep
     long long host_ns[8] = { 0 };
@@ -191,6 +194,42 @@ void tm_collect(svslam_ctx *c)
         }
     }
     c->nev = 0;
+}
+
+// The local-BA solver of a batch whose structure the device builds: the batch kernel (one workgroup per problem), or — in
+// low-latency mode, for a few problems with landmark-major edges — every problem dealt over ll.w workgroups.
+template <int W> void launch_ba_ll_t(svslam_ctx *c, int nshards, BaDev *shards, const BaCams *cams, double *poses, double *pts, const BaRec *recs,
+                                      const int *aux, double delta, int iters, double *chi, int tile_cap, BaDev *parents)
+{
+    hipLaunchKernelGGL((k_local_ba_t<2, W>), dim3(nshards), dim3(BA_THREADS), ba_lds_bytes_ll(c->lim.max_kf), c->stream, shards, cams, poses, pts,
+                       recs, aux, c->ll.bw, delta, iters, chi, c->d_ba_prof, tile_cap,
+                       SbaArgs{ 0, 0, 0.0, nullptr, c->d_lm_trace, 0, c->ll.xch, c->ll.cnt, parents, c->ll.xch_stride });
+}
+bool ba_ll_usable(const svslam_ctx *c, int njobs) { return c->low_latency && c->ll.w > 0 && njobs <= SVSLAM_LL_MAX_PROBLEMS; }
+void launch_ba_solver(svslam_ctx *c, int njobs, bool ll, BaDev *jobs, const BaCams *cams, double *poses, double *pts, const unsigned int *packed,
+                      const float2 *uv, const int *srt, BaRec *recs, int *aux, double *chi, int *flag, int max_nlm, int max_nobs,
+                      double delta, int iters, bool split_timing)
+{
+    const int tile_cap = ll ? ba_tile_cap_ll(c->lim.max_kf) : ba_tile_cap(c->lim.max_kf);
+    const int ec = bb_edge_cache_fits(max_nlm, max_nobs) ? 1 : 0;
+    if (!ll) {
+        hipLaunchKernelGGL(k_ba_build, dim3(njobs), dim3(BB_THREADS), bb_lds_bytes(max_nlm, max_nobs), c->stream, jobs, packed, uv, srt, recs, aux,
+                           tile_cap, max_nlm, flag, 0, ec, 0);
+        if (split_timing) { tm_end(c); tm_begin(c, FAM_DBG3, njobs); }
+        hipLaunchKernelGGL((k_local_ba_t<0, 1>), dim3(njobs), dim3(BA_THREADS), ba_lds_bytes(c->lim.max_kf), c->stream, jobs, cams, poses, pts, recs, aux,
+                           c->bw, delta, iters, chi, c->d_ba_prof, tile_cap, SbaArgs{ 0, 0, 0.0, nullptr, c->d_lm_trace, 0, nullptr, nullptr, nullptr, 0 });
+        return;
+    }
+    const int W = c->ll.w;
+    c->host_ns[6] += njobs;                    // svslam_debug_host_ns slot 6: problems the low-latency solver took
+    hipLaunchKernelGGL(k_ba_split, dim3(njobs), dim3(BB_THREADS), ba_split_lds_bytes(max_nlm, W), c->stream, jobs, c->ll.shards, packed, W, tile_cap,
+                       max_nlm, c->ll.xch, c->ll.xch_stride, c->ll.cnt);
+    hipLaunchKernelGGL(k_ba_build, dim3(njobs * W), dim3(BB_THREADS), bb_lds_bytes(max_nlm, max_nobs), c->stream, c->ll.shards, packed, uv, srt, recs, aux,
+                       tile_cap, max_nlm, flag, 1 /* every keyframe active in every shard */, ec, 1 /* every landmark in the tile */);
+    if (split_timing) { tm_end(c); tm_begin(c, FAM_DBG3, njobs); }
+    if (W == 4) launch_ba_ll_t<4>(c, njobs * W, c->ll.shards, cams, poses, pts, recs, aux, delta, iters, chi, tile_cap, jobs);
+    else if (W == 16) launch_ba_ll_t<16>(c, njobs * W, c->ll.shards, cams, poses, pts, recs, aux, delta, iters, chi, tile_cap, jobs);
+    else launch_ba_ll_t<8>(c, njobs * W, c->ll.shards, cams, poses, pts, recs, aux, delta, iters, chi, tile_cap, jobs);
 }
 
 inline long long now_ns()
@@ -438,6 +477,7 @@ int svslam_create(const svslam_limits *lim, svslam_ctx **out)
     // (per edge: raw <= 21 B, chi2 8 B, two records 32 B, edge + block lists 16 B, pair items <= 2 (K + 1) B)
     per_job_ba += 4 * (size_t)(ba_tile_bound(lim->max_lm, lim->max_obs, lim->max_kf, std::max(ba_tile_cap(lim->max_kf), 64)) + 2) *
                   ((size_t)lim->max_kf * (lim->max_kf + 1) / 2 + 1);          // per-tile pair ranges at their upper bound
+    per_job_ba += 4 * ba_split_aux_extra(lim->max_kf, LL_MAX_W);                  // low-latency shards of a problem (k_ba_split)
     size_t per_job = std::max(per_job_pts, per_job_ba) + (size_t)lim->max_corners * 8 + 4096;
     c->ar.cap = per_job * J + (1 << 20);
     if (lim->device_map) {
@@ -449,7 +489,7 @@ int svslam_create(const svslam_limits *lim, svslam_ctx **out)
         const size_t MO = lim->max_obs, NL = lim->max_lm, NF = lim->max_pts, MK = lim->max_kf;
         const int tc = std::max(ba_tile_cap(lim->max_kf), 64);
         const size_t aux = ba_aux_layout((int)MK, (int)NL, (int)MO, (int)MO, (int)MK, 0, ba_tile_bound((int)NL, (int)MO, (int)MK, tc)).total + ba_pitem_bound((int)MO, (int)MK);
-        const size_t per_dm = sizeof(DmJob) + NF * 80 + NL * 32 + MO * 64 + aux * 4 + MK * 56 + (size_t)lim->max_corners * 8 + 8192 +
+        const size_t per_dm = sizeof(DmJob) + NF * 80 + NL * 32 + MO * 64 + (aux + ba_split_aux_extra((int)MK, LL_MAX_W)) * 4 + MK * 56 + (size_t)lim->max_corners * 8 + 8192 +
                               sizeof(DmEvicted) * SVSLAM_DMAP_EVICT_PER_JOB;
         const size_t chunk = std::min<size_t>(SVSLAM_DMAP_CHUNK, (size_t)std::max(1, lim->max_streams));
         c->ar.cap = std::max(chunk * per_dm, std::max(per_job_pts * J, std::min<size_t>(J, 64) * per_job)) + (4 << 20);
@@ -476,10 +516,12 @@ int svslam_create(const svslam_limits *lim, svslam_ctx **out)
         if (ba_tile_cap(lim->max_kf) < std::max(lim->max_kf, 64) || ba_lds_bytes(lim->max_kf) > 160 * 1024) return fail(c, "max_kf %d: reduced system does not fit LDS", lim->max_kf);
         if (ba_work_alloc(c->bw, lim->max_jobs, lim->max_kf, lim->max_lm, lim->max_obs) != hipSuccess)
             return fail(c, "BA workspace allocation failed");
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_local_ba_t<0>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ba_lds_bytes(lim->max_kf)));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_local_ba_t<1>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ba_lds_bytes(lim->max_kf)));
+        for (const void *f : { reinterpret_cast<const void *>(k_local_ba_t<0, 1>), reinterpret_cast<const void *>(k_local_ba_t<1, 1>) })
+            HIPCHK(c, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ba_lds_bytes(lim->max_kf)));
+        if (ba_tile_cap_ll(lim->max_kf) >= std::max(lim->max_kf, 64))
+            for (const void *f : { reinterpret_cast<const void *>(k_local_ba_t<2, 4>), reinterpret_cast<const void *>(k_local_ba_t<2, 8>),
+                                   reinterpret_cast<const void *>(k_local_ba_t<2, 16>) })
+                HIPCHK(c, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ba_lds_bytes_ll(lim->max_kf)));
         if (bb_lds_bytes(lim->max_lm) > 160 * 1024 || lim->max_kf > 32)
             return fail(c, "max_lm %d / max_kf %d: problem structure does not fit LDS", lim->max_lm, lim->max_kf);
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_build),
@@ -558,6 +600,10 @@ void svslam_destroy(svslam_ctx *c)
     }
     (void)hipFree(c->gw.keys); (void)hipFree(c->gw.counters);
     ba_work_free(c->bw);
+    ba_work_free(c->ll.bw);
+    if (c->ll.shards) (void)hipFree(c->ll.shards);
+    if (c->ll.xch) (void)hipFree(c->ll.xch);
+    if (c->ll.cnt) (void)hipFree(c->ll.cnt);
     if (c->d_ba_prof) (void)hipFree(c->d_ba_prof);
     if (c->d_lm_trace) (void)hipFree(c->d_lm_trace);
     (void)svslam_sba_comm_destroy(c);
@@ -612,6 +658,27 @@ int svslam_set_low_latency(svslam_ctx *c, int on)
     // a caller that waits for one camera's frame wants the result, not its core back: block in the
     // runtime instead of sleep-polling the event (SVSLAM_WAIT=poll|spin still overrides)
     if (!std::getenv("SVSLAM_WAIT")) c->wait_poll = !c->low_latency;
+    // one local-BA problem over several workgroups (k_local_ba_t<2>): shard descriptors, exchange area, arrival counters and
+    // the per-shard solver scratch, once.  SVSLAM_LL_SHARDS = 4 | 8 (default) | 16; 0 keeps one workgroup per problem.
+    if (c->low_latency && !c->ll.shards && c->lim.max_kf > 0 && !c->ba_host_build && ba_tile_cap_ll(c->lim.max_kf) >= std::max(c->lim.max_kf, 64)) {
+        const char *e = std::getenv("SVSLAM_LL_SHARDS");
+        int w = e ? atoi(e) : 8;
+        if (w != 0 && w != 4 && w != 8 && w != 16) return fail(c, "SVSLAM_LL_SHARDS=%d (4, 8, 16 or 0)", w);
+        if (w > 0) {
+            const size_t nsh = (size_t)SVSLAM_LL_MAX_PROBLEMS * w;
+            c->ll.xch_stride = ll_xch_doubles(6 * c->lim.max_kf, w);
+            HIPCHK(c, hipMalloc(&c->ll.shards, sizeof(BaDev) * nsh));
+            HIPCHK(c, hipMalloc(&c->ll.xch, sizeof(double) * c->ll.xch_stride * SVSLAM_LL_MAX_PROBLEMS));
+            HIPCHK(c, hipMalloc(&c->ll.cnt, sizeof(unsigned int) * LL_CNT_WORDS * SVSLAM_LL_MAX_PROBLEMS));
+            HIPCHK(c, hipMemset(c->ll.xch, 0, sizeof(double) * c->ll.xch_stride * SVSLAM_LL_MAX_PROBLEMS));
+            HIPCHK(c, hipMemset(c->ll.cnt, 0, sizeof(unsigned int) * LL_CNT_WORDS * SVSLAM_LL_MAX_PROBLEMS));
+            if (ba_work_alloc(c->ll.bw, (int)nsh, c->lim.max_kf, c->lim.max_lm, c->lim.max_obs) != hipSuccess)
+                return fail(c, "low-latency BA workspace allocation failed");
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_split), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)ba_split_lds_bytes(c->lim.max_lm, LL_MAX_W)));
+            c->ll.w = w;
+        }
+    }
     return 0;
 }
 
@@ -920,7 +987,8 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
     c->ar.reset();
     static_assert(sizeof(BaJob) == sizeof(svslam_ba_job), "job layout");
     const size_t TO = (size_t)std::max(total_obs, 1);
-    const int tile_cap = ba_tile_cap(c->lim.max_kf);
+    const bool use_ll = !c->ba_host_build && ba_ll_usable(c, njobs);
+    const int tile_cap = use_ll ? ba_tile_cap_ll(c->lim.max_kf) : ba_tile_cap(c->lim.max_kf);     // (reservations: the smaller tiles need more room)
     // arena: cams | jobs | poses | points | [raw edges + order (device build)] | chi2 + flag (out) |
     //        records | aux  (records and aux are device-only when the device builds the structure)
     size_t ocams = c->ar.take(sizeof(BaCams));
@@ -946,6 +1014,7 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
     hp<int>(c, oflag)[0] = 0;
     size_t aux_total = 0;
     int max_nlm = 1, max_nobs = 1;
+    bool all_sorted = true;
     if (c->ba_host_build) {
         // Host-side structure of every problem (edge records, blocks, pose-pair lists), built by the
         // pool with one scratch structure per thread (stays cache-hot) and written straight into the
@@ -1020,8 +1089,10 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
             d.nblk = d.na = d.ncontrib = d.ntile = 0; d.iters_done = 0; d.nmv = 0;
             d.rec_ofs = 2 * j.obs_ofs;
             d.lay_nblk = j.nobs; d.lay_na = j.nkf; d.lay_ntile = ba_tile_bound(j.nlm, j.nobs, j.nkf, tile_cap);
-            d.aux_ofs = (int)at;
+            d.aux_ofs = (int)at; d.lm_base = 0; d.shmask = 0;
             at += ba_aux_layout(j.nkf, j.nlm, j.nobs, d.lay_nblk, d.lay_na, 0, d.lay_ntile).total + ba_pitem_bound(j.nobs, j.nkf);
+            if (use_ll) at += ba_split_aux_extra(j.nkf, c->ll.w);
+            if (!d.reserved) all_sorted = false;
             max_nlm = std::max(max_nlm, j.nlm); max_nobs = std::max(max_nobs, j.nobs);
         }
         aux_total = at;
@@ -1036,19 +1107,17 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
     if (h2d(c, 0, in_end)) return -1;
     if (h2d(c, oflag, oflag + sizeof(int) * 4)) return -1;
     if (c->ba_host_build) { if (h2d(c, orecs, c->ar.off)) return -1; }
-    tm_begin(c, c->timing_split ? FAM_DBG2 : FAM_BA, njobs);
-    if (!c->ba_host_build) {
-        hipLaunchKernelGGL(k_ba_build, dim3(njobs), dim3(BB_THREADS), bb_lds_bytes(max_nlm, max_nobs), c->stream, dp<BaDev>(c, ojobs),
-                           dp<unsigned int>(c, opk_o), dp<float2>(c, ouv_o), dp<int>(c, osrt_o),
-                           dp<BaRec>(c, orecs), dp<int>(c, oaux), tile_cap, max_nlm, dp<int>(c, oflag), 0,
-                           bb_edge_cache_fits(max_nlm, max_nobs) ? 1 : 0);
-        if (c->timing_split) { tm_end(c); tm_begin(c, FAM_DBG3, njobs); }
-    }
     if (c->d_lm_trace) HIPCHK(c, hipMemsetAsync(c->d_lm_trace, 0, sizeof(double) * LM_TRACE_STRIDE * (size_t)njobs, c->stream));
-    hipLaunchKernelGGL(k_local_ba_t<0>, dim3(njobs), dim3(BA_THREADS), ba_lds_bytes(c->lim.max_kf), c->stream,
-                       dp<BaDev>(c, ojobs), dp<BaCams>(c, ocams), dp<double>(c, oposes), dp<double>(c, opts),
-                       dp<BaRec>(c, orecs), dp<int>(c, oaux), c->bw, huber_delta, iters, dp<double>(c, ochi), c->d_ba_prof,
-                       tile_cap, SbaArgs{ 0, 0, 0.0, nullptr, c->d_lm_trace, 0 });
+    tm_begin(c, c->timing_split ? FAM_DBG2 : FAM_BA, njobs);
+    if (!c->ba_host_build)
+        launch_ba_solver(c, njobs, use_ll && all_sorted, dp<BaDev>(c, ojobs), dp<BaCams>(c, ocams), dp<double>(c, oposes), dp<double>(c, opts),
+                         dp<unsigned int>(c, opk_o), dp<float2>(c, ouv_o), dp<int>(c, osrt_o), dp<BaRec>(c, orecs), dp<int>(c, oaux),
+                         dp<double>(c, ochi), dp<int>(c, oflag), max_nlm, max_nobs, huber_delta, iters, c->timing_split);
+    else
+        hipLaunchKernelGGL((k_local_ba_t<0, 1>), dim3(njobs), dim3(BA_THREADS), ba_lds_bytes(c->lim.max_kf), c->stream,
+                           dp<BaDev>(c, ojobs), dp<BaCams>(c, ocams), dp<double>(c, oposes), dp<double>(c, opts),
+                           dp<BaRec>(c, orecs), dp<int>(c, oaux), c->bw, huber_delta, iters, dp<double>(c, ochi), c->d_ba_prof,
+                           tile_cap, SbaArgs{ 0, 0, 0.0, nullptr, c->d_lm_trace, 0, nullptr, nullptr, nullptr, 0 });
     tm_end(c);
     HIPCHK(c, hipGetLastError());
     c->ba_pending.oflag = oflag;
@@ -1071,7 +1140,10 @@ int svslam_local_ba_collect(svslam_ctx *c, int njobs, svslam_ba_job *jobs, int t
     if (const int fl = hp<int>(c, c->ba_pending.oflag)[0])
         return fail(c, "local_ba: the device structure build overflowed a capacity (code %d)", fl);
     const BaDev *dj = hp<BaDev>(c, c->ba_pending.ojobs);
-    for (int i = 0; i < njobs; ++i) jobs[i].iters_done = dj[i].iters_done;
+    for (int i = 0; i < njobs; ++i) {
+        if (dj[i].iters_done < 0) return fail(c, "local_ba: job %d: a workgroup of the low-latency solver never arrived (GPU oversubscribed?)", i);
+        jobs[i].iters_done = dj[i].iters_done;
+    }
     if (total_kf > 0) memcpy(poses, hp<void>(c, c->ba_pending.oposes), sizeof(double) * 7 * total_kf);
     if (total_lm > 0) memcpy(pts, hp<void>(c, c->ba_pending.opts), sizeof(double) * 3 * total_lm);
     if (total_obs > 0) memcpy(edge_chi2, hp<void>(c, c->ba_pending.ochi), sizeof(double) * total_obs);
@@ -1137,7 +1209,7 @@ int svslam_sba_open(svslam_ctx *c, const double cam_l[4], const double ext_l[7],
     d.kf_ofs = 0; d.nkf = nkf; d.lm_ofs = 0; d.nlm = nlm; d.obs_ofs = 0; d.nobs = nobs;
     d.nblk = d.na = d.ncontrib = d.ntile = 0; d.iters_done = 0; d.rec_ofs = 0; d.nmv = 0; d.reserved = sorted ? 1 : 0;
     d.lay_nblk = nobs; d.lay_na = nkf; d.lay_ntile = ba_tile_bound(nlm, nobs, nkf, tile_cap);
-    d.aux_ofs = 0;
+    d.aux_ofs = 0; d.lm_base = 0; d.shmask = 0;
     (void)c->ar.take(sizeof(int) * (ba_aux_layout(nkf, nlm, nobs, d.lay_nblk, d.lay_na, 0, d.lay_ntile).total + ba_pitem_bound(nobs, nkf)));
     if (c->ar.off > c->ar.cap) return fail(c, "sba_open: staging arena too small");
     memcpy(hp<void>(c, ouv_o), obs_uv, sizeof(float) * 2 * TO);
@@ -1149,7 +1221,7 @@ int svslam_sba_open(svslam_ctx *c, const double cam_l[4], const double ext_l[7],
     hipLaunchKernelGGL(k_ba_build, dim3(1), dim3(BB_THREADS), bb_lds_bytes(nlm, nobs), c->stream, dp<BaDev>(c, ojobs), dp<unsigned int>(c, opk_o),
                        dp<float2>(c, ouv_o), dp<int>(c, osrt_o), dp<BaRec>(c, orecs),
                        dp<int>(c, oaux), tile_cap, nlm, dp<int>(c, oflag), 1 /* every keyframe active on every rank */,
-                       bb_edge_cache_fits(nlm, nobs) ? 1 : 0);
+                       bb_edge_cache_fits(nlm, nobs) ? 1 : 0, 0);
     HIPCHK(c, hipGetLastError());
     if (d2h_sync(c, oflag, oflag + sizeof(int) * 4)) return -1;
     if (hp<int>(c, oflag)[0]) return fail(c, "sba_open: the structure build overflowed a capacity");
@@ -1163,9 +1235,9 @@ int svslam_sba_open(svslam_ctx *c, const double cam_l[4], const double ext_l[7],
 //        4 reject (restore), 5 finalise.  io: svslam_sba_io_doubles(nkf) doubles, in for phase 3, out for 1-3.
 static int sba_launch(svslam_ctx *c, int phase, double lambda, int add_lambda)
 {
-    SbaArgs a{ phase, c->sba.launches == 0 ? 1 : 0, lambda, dp<double>(c, c->sba.oio), nullptr, add_lambda };
+    SbaArgs a{ phase, c->sba.launches == 0 ? 1 : 0, lambda, dp<double>(c, c->sba.oio), nullptr, add_lambda, nullptr, nullptr, nullptr, 0 };
     tm_begin(c, FAM_BA, 1);
-    hipLaunchKernelGGL(k_local_ba_t<1>, dim3(1), dim3(BA_THREADS), ba_lds_bytes(c->lim.max_kf), c->stream, dp<BaDev>(c, c->sba.ojobs),
+    hipLaunchKernelGGL((k_local_ba_t<1, 1>), dim3(1), dim3(BA_THREADS), ba_lds_bytes(c->lim.max_kf), c->stream, dp<BaDev>(c, c->sba.ojobs),
                        dp<BaCams>(c, c->sba.ocams), dp<double>(c, c->sba.oposes), dp<double>(c, c->sba.opts), dp<BaRec>(c, c->sba.orecs),
                        dp<int>(c, c->sba.oaux), c->bw, c->sba.delta, 1, dp<double>(c, c->sba.ochi), (long long *)nullptr,
                        ba_tile_cap(c->lim.max_kf), a);
@@ -1414,8 +1486,10 @@ int svslam_dmap_keyframe_batch(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, 
                            dec ? c->src_h : c->geom.h[0], false)) return -1;
     }
     const int NF = m.NF, NL = m.NL, MO = c->lim.max_obs, MK = c->lim.max_kf, MC = p->num_features;
-    const int tile_cap = ba_tile_cap(MK);
-    const size_t aux_stride = ba_aux_layout(MK, NL, MO, MO, MK, 0, ba_tile_bound(NL, MO, MK, tile_cap)).total + ba_pitem_bound(MO, MK);
+    const bool use_ll = ba_ll_usable(c, njobs);
+    const int tile_cap = use_ll ? ba_tile_cap_ll(MK) : ba_tile_cap(MK);
+    const size_t aux_stride = ba_aux_layout(MK, NL, MO, MO, MK, 0, ba_tile_bound(NL, MO, MK, tile_cap)).total + ba_pitem_bound(MO, MK) +
+                              (use_ll ? ba_split_aux_extra(MK, c->ll.w) : 0);
     const size_t n = njobs, P = n * NF, E = n * MO;
     const size_t base = c->ar.off;
     size_t ojobs = c->ar.take(sizeof(DmJob) * n);
@@ -1478,18 +1552,19 @@ int svslam_dmap_keyframe_batch(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, 
                        dp<double>(c, oxyz), dp<uint8_t>(c, ook));
     tm_end(c);
     hipLaunchKernelGGL(k_dmap_commit, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, dp<double>(c, oxyz), dp<uint8_t>(c, ook), dp<int>(c, otidx), dp<int>(c, oslot));
-    tm_begin(c, FAM_BA, njobs);
-    hipLaunchKernelGGL(k_dmap_ba_gather, dim3(njobs), dim3(DMG_THREADS), dmg_lds_bytes(NL), c->stream, dj, m, prm, dp<BaDev>(c, obd), dp<double>(c, oposes),
-                       dp<double>(c, opts), dp<unsigned int>(c, opk), dp<float2>(c, ouv), dp<int>(c, oref), dp<int>(c, olms), MK, tile_cap, aux_stride);
-    hipLaunchKernelGGL(k_ba_build, dim3(njobs), dim3(BB_THREADS), bb_lds_bytes(NL, MO), c->stream, dp<BaDev>(c, obd), dp<unsigned int>(c, opk), dp<float2>(c, ouv),
-                       dp<int>(c, oref) /* order: identity, not read */, dp<BaRec>(c, orecs), dp<int>(c, oaux), tile_cap, NL, dp<int>(c, oflag), 0,
-                       bb_edge_cache_fits(NL, MO) ? 1 : 0);
-    hipLaunchKernelGGL(k_local_ba_t<0>, dim3(njobs), dim3(BA_THREADS), ba_lds_bytes(MK), c->stream, dp<BaDev>(c, obd), dp<BaCams>(c, ocams), dp<double>(c, oposes),
-                       dp<double>(c, opts), dp<BaRec>(c, orecs), dp<int>(c, oaux), c->bw, p->chi2_th, p->ba_iters, dp<double>(c, ochi), (long long *)nullptr,
-                       tile_cap, SbaArgs{ 0, 0, 0.0, nullptr, nullptr, 0 });
-    hipLaunchKernelGGL(k_dmap_ba_scatter, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, prm, dp<BaDev>(c, obd), dp<double>(c, oposes), dp<double>(c, opts),
-                       dp<double>(c, ochi), dp<int>(c, oref), dp<int>(c, olms), MK);
-    tm_end(c);
+    // Backend::UpdateMap (src/backend.cpp:14-18) only runs with a backend: a paused / absent one (ba_iters <= 0) means no
+    // Optimize, so no outlier classification and no observation removed either — like the host-map path
+    if (p->ba_iters > 0) {
+        tm_begin(c, FAM_BA, njobs);
+        hipLaunchKernelGGL(k_dmap_ba_gather, dim3(njobs), dim3(DMG_THREADS), dmg_lds_bytes(NL), c->stream, dj, m, prm, dp<BaDev>(c, obd), dp<double>(c, oposes),
+                           dp<double>(c, opts), dp<unsigned int>(c, opk), dp<float2>(c, ouv), dp<int>(c, oref), dp<int>(c, olms), MK, tile_cap, aux_stride);
+        launch_ba_solver(c, njobs, use_ll, dp<BaDev>(c, obd), dp<BaCams>(c, ocams), dp<double>(c, oposes), dp<double>(c, opts), dp<unsigned int>(c, opk),
+                         dp<float2>(c, ouv), dp<int>(c, oref) /* order: identity, not read */, dp<BaRec>(c, orecs), dp<int>(c, oaux), dp<double>(c, ochi),
+                         dp<int>(c, oflag), NL, MO, p->chi2_th, p->ba_iters, false);
+        hipLaunchKernelGGL(k_dmap_ba_scatter, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, prm, dp<BaDev>(c, obd), dp<double>(c, oposes), dp<double>(c, opts),
+                           dp<double>(c, ochi), dp<int>(c, oref), dp<int>(c, olms), MK);
+        tm_end(c);
+    }
     hipLaunchKernelGGL(k_dmap_refresh, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, c->rt);
     HIPCHK(c, hipGetLastError());
     if (d2h_sync(c, ojobs, ojobs + sizeof(DmJob) * n)) return -1;
@@ -1502,6 +1577,8 @@ int svslam_dmap_keyframe_batch(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, 
     }
     memcpy(jobs, hj, sizeof(DmJob) * n);
     for (int i = 0; i < njobs; ++i) c->rt_count[(size_t)jobs[i].stream] = jobs[i].n_features;
+    for (int i = 0; i < njobs; ++i)
+        if (jobs[i].ba_iters < 0) return fail(c, "dmap: job %d: a workgroup of the low-latency BA solver never arrived (GPU oversubscribed?)", i);
     return 0;
 }
 
@@ -1541,10 +1618,27 @@ int svslam_set_host_threads(svslam_ctx *c, int n)
 }
 
 // test hook: host-side wall time per category since the last call (ns):
-// 0 h2d enqueue, 1 d2h enqueue, 2 stream wait, 5 event collection
+// 0 h2d enqueue, 1 d2h enqueue, 2 stream wait, 5 event collection; slot 6 is a count: local-BA problems solved by the
+// low-latency path (one problem over several workgroups)
 int svslam_debug_host_ns(svslam_ctx *c, long long *out8)
 {
     for (int i = 0; i < 8; ++i) { out8[i] = c->host_ns[i]; c->host_ns[i] = 0; }
+    return 0;
+}
+
+// test hook: the shard descriptors of the last low-latency local-BA call (k_ba_split / k_ba_build): 8 ints per shard —
+// landmarks, edges, blocks, tiles, landmarks in tiles, active poses, mask of shards with edges, iterations
+int svslam_debug_ll_shards(svslam_ctx *c, int nproblems, int *out8, int *shards_per_problem)
+{
+    if (shards_per_problem) *shards_per_problem = c->ll.w;
+    if (!c->ll.shards || nproblems < 1 || nproblems > SVSLAM_LL_MAX_PROBLEMS) return fail(c, "debug_ll_shards: no low-latency solver / bad count");
+    std::vector<BaDev> h((size_t)nproblems * c->ll.w);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(h.data(), c->ll.shards, sizeof(BaDev) * h.size(), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < h.size(); ++i) {
+        int *o = out8 + 8 * i;
+        o[0] = h[i].nlm; o[1] = h[i].nobs; o[2] = h[i].nblk; o[3] = h[i].ntile; o[4] = h[i].nmv; o[5] = h[i].na; o[6] = h[i].shmask; o[7] = h[i].iters_done;
+    }
     return 0;
 }
 

@@ -15,9 +15,14 @@ import common as cm
 svs = importlib.import_module("stereovision-slam_amd")
 
 
-def ba(nj=1, nkf=10, nlm=700, reps=3):
+def ba(nj=1, nkf=10, nlm=700, reps=3, ll=0):
     rng = np.random.default_rng(1)
+    if ll:
+        os.environ["SVSLAM_LL_SHARDS"] = str(ll)
     c = svs.Context(cm.W, cm.H, max_slots=1, max_jobs=max(nj, 1), max_kf=max(nkf, 10) + 1, max_lm=4096, max_obs=16384)
+    if ll:
+        c.low_latency(True)
+        print("low-latency solver, %d shards per problem" % ll)
     if nkf == 0:
         # a local-BA problem captured from the pipeline itself (stream seed 3, full 10-keyframe window:
         # 1725 landmarks of which 78% are seen from one keyframe only, 4011 edges), replicated
@@ -39,6 +44,8 @@ def ba(nj=1, nkf=10, nlm=700, reps=3):
         ms, n, _ = c.timing_get("local_ba")
         prof = c.ba_profile(True, read=True)
         c.timing(True)
+        if ll and r == 0:
+            print("  shards (landmarks, edges, blocks, tiles, landmarks in tiles):", c.ll_shards(1)[0][:, :5].tolist())
         names = ["edge+J", "lm+pose", "dinv/Y/Sinit", "schur", "chol", "backsub", "errors"]
         tot = sum(prof[:7])
         print("  rep %d: %.3f ms/launch; trials %d; phase us (100MHz ticks/100): " % (r, ms / max(n, 1), prof[11]) +
@@ -146,6 +153,12 @@ if __name__ == "__main__":
         lkbench(); sys.exit(0)
     if what == "gftt":
         gfttbench(); sys.exit(0)
+    if what == "ball":       # the captured pipeline problem on the low-latency solver (one problem over 4 / 8 / 16 workgroups)
+        for w in (4, 8, 16):
+            ba(1, 0, 0, reps=3, ll=w)
+        ba(4, 0, 0, reps=2, ll=8)
+        ba(1, 0, 0, reps=2)
+        sys.exit(0)
     if what == "ba1":        # the captured pipeline problem: alone and 256 at a time, with the phase profile
         ba(1, 0, 0, reps=2); ba(256, 0, 0, reps=2); sys.exit(0)
     if what == "ba2":        # chip throughput of the BA kernel: more problems than CUs
