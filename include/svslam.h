@@ -375,7 +375,7 @@ int svslam_set_host_threads(svslam_ctx *ctx, int n);
 /* test hooks */
 int svslam_debug_host_ns(svslam_ctx *ctx, long long *out8);
 /* test hook: shard descriptors of the last low-latency local-BA call, 8 ints per shard (landmarks, edges, blocks, tiles,
- * landmarks in tiles, active poses, mask of shards with edges, iterations) for `nproblems` problems */
+ * solver: 2 = resident kernel / 1 = streaming kernel, active poses, mask of shards with edges, iterations) for `nproblems` problems */
 int svslam_debug_ll_shards(svslam_ctx *ctx, int nproblems, int *out8, int *shards_per_problem);
 int svslam_debug_clock_mhz(svslam_ctx *ctx, int blocks, double ms, double *mhz);
 

@@ -199,7 +199,7 @@ class Context:
 
     def ll_shards(self, nproblems=1):
         """test hook (svslam_debug_ll_shards): [nproblems, W, 8] ints of the last low-latency local-BA call — landmarks,
-        edges, blocks, tiles, landmarks in tiles, active poses, shard mask, iterations"""
+        edges, blocks, tiles, solver (2 resident / 1 streaming), active poses, shard mask, iterations"""
         w = C.c_int(0)
         out = np.zeros((nproblems * 16, 8), np.int32)
         self._chk(self.L.svslam_debug_ll_shards(self.h, nproblems, _p(out), C.byref(w)), "debug_ll_shards")

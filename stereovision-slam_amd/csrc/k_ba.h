@@ -544,6 +544,243 @@ __device__ __forceinline__ void ba_schur_task(int a, int b2, int rg, int c0, int
     }
 }
 
+// ---- the reduced camera system: factor and solve, shared by the batch kernel and the low-latency kernels.
+// S (np x np, row stride ld, plus one spare row np for the right-hand side) holds the system with lambda on its
+// diagonal, bs the right-hand side; on return xp holds the solution and the result says whether S was positive definite.
+// Whole workgroup; ends with a barrier.
+// prof: optional phase clocks (slot 7 = the factorisation part).
+//
+// Blocked (6x6 = one pose) right-looking Cholesky S = L L^T in LDS; the right-hand side rides along as row np, so L y = bs
+// comes out of the same sweep.  The kernel is bound by the f64 instructions of its busiest wave (one f64 instruction per
+// 3.2 ns for a wave alone on its SIMD, 4.9 ns when the SIMD's other wave is busy too: profiles/r3_ubench_valu_issue_rates.txt),
+// and the factorisation of a diagonal block is a chain of ~100 of them.  So (round 4):
+//   * ONE wave factors the diagonal block and solves the panel below it (every thread used to factor the block redundantly —
+//     the second wave of each SIMD only slowed the first), the other seven take the trailing update;
+//   * look-ahead: wave 0 updates block column k + 1 with column k first and goes straight on to factor / solve column k + 1
+//     while the others update the columns behind it — one barrier per block column instead of two, the chain of column k + 1
+//     hidden behind the trailing update of column k;
+//   * the back-substitution L^T x = y by blocks: wave 1 inverts every diagonal factor on the side (linv), the solve then takes
+//     a 6-term product per block instead of six dependent readlane -> multiply -> FMA steps (60 -> 10 serial steps at K = 10).
+__device__ __forceinline__ int ba_chol_solve(double *S, const int ld, const int np, const int na, const double *bs, double *xp,
+                                             int *iflag, const int tid0, long long *prof, const long long tprev)
+{
+    // The inverse of diagonal factor kb is kept inside S, in a 6x6 block above the diagonal that the factorisation never
+    // touches (the Cholesky reads and writes the lower triangle only): right of its own diagonal block, or — for the last
+    // block — at the top of its block column.  (na >= 3, else the scalar back-substitution below runs.)
+    auto linv_at = [&](const int kb) -> double * { return kb + 1 < na ? S + (size_t)(6 * kb) * ld + 6 * kb + 6 : S + 6 * kb; };
+    double *rhs = S + (size_t)np * ld;             // extra row: bs on entry, y on exit
+    double *invd = xp;                             // 1 / L_kk (xp is free until the back-substitution)
+    // wave 0: factor diagonal block kb, solve the panel below it (rows up to the right-hand side's), leave the factor's rows,
+    // the inverse pivots and the verdict in LDS
+    auto factor_panel = [&](const int kb, const int lane) {
+        const int c0 = 6 * kb;
+        double Ld[6][6], inv[6];
+        int ok = 1;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c <= r; ++c) Ld[r][c] = S[(size_t)(c0 + r) * ld + c0 + c];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            double d = Ld[c][c];
+#pragma unroll
+            for (int m = 0; m < c; ++m) d -= Ld[c][m] * Ld[c][m];
+            if (!(d > 0)) ok = 0;
+            // rsqrt: hardware estimate + 2 Newton steps
+            double y = __builtin_amdgcn_rsq(d);
+            y = y * (1.5 - 0.5 * d * y * y);
+            y = y * (1.5 - 0.5 * d * y * y);
+            inv[c] = y;
+            Ld[c][c] = d * y;
+#pragma unroll
+            for (int r = c + 1; r < 6; ++r) {
+                double v = Ld[r][c];
+#pragma unroll
+                for (int m = 0; m < c; ++m) v -= Ld[r][m] * Ld[c][m];
+                Ld[r][c] = v * y;
+            }
+        }
+        if (lane == 0) iflag[0] = ok;
+        if (!ok) return;                           // (uniform: every lane factors the same block)
+        for (int i = c0 + 6 + lane; i <= np; i += 64) {
+            double *ri = S + (size_t)i * ld + c0;
+            double x[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) x[c] = ri[c];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                double v = x[c];
+#pragma unroll
+                for (int m = 0; m < c; ++m) v -= x[m] * Ld[c][m];
+                x[c] = v * inv[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) ri[c] = x[c];
+        }
+        if (lane < 6) {                            // factor rows of the diagonal block, inverse pivots
+            double *ro = S + (size_t)(c0 + lane) * ld + c0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                double v = Ld[0][c];
+#pragma unroll
+                for (int r = 1; r < 6; ++r) v = (lane == r) ? Ld[r][c] : v;
+                ro[c] = c > lane ? 0.0 : v;
+            }
+            double v = inv[0];
+#pragma unroll
+            for (int c = 1; c < 6; ++c) v = (lane == c) ? inv[c] : v;
+            invd[c0 + lane] = v;
+        }
+    };
+    // trailing update of (row i, block column jb) with block column kb:
+    //    S[i][6jb + c'] -= sum_c L[i][c0 + c] * L[6jb + c'][c0 + c]
+    auto trail = [&](const int kb, const int i, const int jb) {
+        const int c0 = 6 * kb;
+        const double *pi = S + (size_t)i * ld + c0;
+        double x[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) x[c] = pi[c];
+        double *u = S + (size_t)i * ld + 6 * jb;
+        const double *P = S + (size_t)(6 * jb) * ld + c0;
+#pragma unroll
+        for (int cp = 0; cp < 6; ++cp) {
+            const double *pr = P + (size_t)cp * ld;
+            u[cp] -= x[0] * pr[0] + x[1] * pr[1] + x[2] * pr[2] + x[3] * pr[3] + x[4] * pr[4] + x[5] * pr[5];
+        }
+    };
+    {
+        BA_PHASE_TID;
+        for (int i = tid; i < np; i += BA_THREADS) rhs[i] = bs[i];
+        if (tid == 0) iflag[0] = 1;
+        __syncthreads();
+        if (wv == 0) factor_panel(0, lane);
+        __syncthreads();
+    }
+    int ok = 1;
+#ifdef BA_CHOL_PROF
+    long long cp_t = wall_clock64();
+#define CP_TICK(i) do { if (prof && tid == 0) { long long t_ = wall_clock64(); prof[i] += t_ - cp_t; cp_t = t_; } } while (0)
+#else
+#define CP_TICK(i) do { } while (0)
+#endif
+    for (int kb = 0; kb < na; ++kb) {
+        BA_PHASE_TID;
+        ok = iflag[0];
+        if (!ok) break;                            // uniform
+        const int c0 = 6 * kb;
+        CP_TICK(12);
+        if (wv == 0) {
+            if (kb + 1 < na) {
+                for (int i = c0 + 6 + lane; i <= np; i += 64) trail(kb, i, kb + 1);      // rows inside the next diagonal block: its upper entries are never read
+                CP_TICK(13);
+                factor_panel(kb + 1, lane);
+                CP_TICK(14);
+            }
+        } else {
+            // block columns behind the next one, lower part only, one thread per (row, block column)
+            const int nbm = na - kb - 2, nrows = np + 1 - (c0 + 12);
+            for (int t = tid - 64; t < nrows * nbm; t += BA_THREADS - 64) {
+                const int i = c0 + 12 + t / nbm, jb = kb + 2 + t % nbm;
+                const int jb_last = (i < np) ? i / 6 : na - 1;
+                if (jb > jb_last) continue;
+                trail(kb, i, jb);
+            }
+            if (wv == 1 && lane < 6 && na >= 3) {
+                // inverse of the factor of diagonal block kb, column `lane` of it per lane: Li[c][c] = 1 / L[c][c],
+                // Li[r][c] = -(sum_{m = c}^{r - 1} L[r][m] Li[m][c]) / L[r][r]; stored full (zeros above the diagonal)
+                const double *Lk = S + (size_t)c0 * ld + c0;
+                double li[6];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    double sacc = 0;
+#pragma unroll
+                    for (int m = 0; m < r; ++m) sacc += Lk[(size_t)r * ld + m] * li[m];      // li[m] = 0 for m < lane
+                    const double piv = invd[c0 + r];
+                    li[r] = r < lane ? 0.0 : (r == lane ? piv : -sacc * piv);
+                }
+                double *Lw = linv_at(kb);
+#pragma unroll
+                for (int r = 0; r < 6; ++r) Lw[(size_t)r * ld + lane] = li[r];
+            }
+        }
+        __syncthreads();
+        CP_TICK(15);
+    }
+#undef CP_TICK
+    const int wv = ba_opaque(tid0) >> 6;
+    if (wv == 0) {
+        BA_PHASE_TID;
+        if (prof && tid == 0) { long long t_ = wall_clock64(); prof[7] += t_ - tprev; }
+        if (ok && np <= 64 && na >= 3) {
+            // rhs holds y; L^T x = y by blocks from the last: x_blk = Li^T y_blk (lane of unknown r: column r of Li against the
+            // block's six y, fetched with v_readlane), then every lane in front of the block subtracts the block's columns of L^T
+            double y = lane < np ? rhs[lane] : 0.0;
+            for (int kb = na - 1; kb >= 0; --kb) {
+                const int c0 = 6 * kb, r = lane - c0;
+                const bool inblk = r >= 0 && r < 6;
+                const double *Lr = linv_at(kb);
+                double a[6], lr[6], yb[6];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    a[c] = inblk ? Lr[(size_t)c * ld + r] : 0.0;                        // Li[c][r]
+                    lr[c] = lane < c0 ? S[(size_t)(c0 + c) * ld + lane] : 0.0;           // L[c0 + c][lane]
+                }
+#pragma unroll
+                for (int c = 0; c < 6; ++c) yb[c] = readlane_f64(y, c0 + c);
+                double xv = 0;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) xv += a[c] * yb[c];
+                y = inblk ? xv : y;
+                double xb[6];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) xb[c] = readlane_f64(y, c0 + c);
+#pragma unroll
+                for (int c = 0; c < 6; ++c) y -= lr[c] * xb[c];
+            }
+            if (lane < np) xp[lane] = y;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        } else if (ok) {
+            // rhs holds y; back-substitution L^T x = y with the stored inverse pivots.  x lives in registers
+            // (lane i: x_i, x_{i+64}, x_{i+128}), the pivot comes over v_readlane, row k of L is requested one
+            // step ahead: the serial chain per unknown is readlane -> multiply -> FMA, no LDS round trip.
+            double ivk[3], xr[3], srow[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int i = lane + 64 * c;
+                ivk[c] = i < np ? invd[i] : 0.0;
+                xr[c] = i < np ? rhs[i] : 0.0;
+                srow[c] = i < np ? S[(size_t)(np - 1) * ld + i] : 0.0;
+            }
+            for (int k = np - 1; k >= 0; --k) {
+                const int kc = k >> 6, kl = k & 63;
+                double crow[3], nxt[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    crow[c] = srow[c];
+                    const int i = lane + 64 * c;
+                    nxt[c] = (k > 0 && i < k) ? S[(size_t)(k - 1) * ld + i] : 0.0;
+                }
+                const double xsel = kc == 0 ? xr[0] : kc == 1 ? xr[1] : xr[2];
+                const double isel = kc == 0 ? ivk[0] : kc == 1 ? ivk[1] : ivk[2];
+                const double xk = readlane_f64(xsel, kl) * readlane_f64(isel, kl);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int i = lane + 64 * c;
+                    if (i < k) xr[c] -= crow[c] * xk;
+                    else if (i == k) xr[c] = xk;
+                    srow[c] = nxt[c];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { const int i = lane + 64 * c; if (i < np) xp[i] = xr[c]; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        }
+        if (lane == 0) iflag[0] = ok;
+    }
+    __syncthreads();
+    return iflag[0];
+}
+
 // Shared-map BA (BASELINE config 5): the same kernel cut at the points where ranks have to meet.  Every rank
 // holds all K poses and a shard of the landmarks with their edges; MODE 1 runs ONE piece of an LM trial per
 // launch and hands the host what must be summed over the ranks (RCCL all-reduce, host/shared_ba in
@@ -634,6 +871,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
     const int tid = tid0, lane = tid & 63, wv = tid >> 6;
     const int nkf = jd.nkf, nlm = jd.nlm, nobs = jd.nobs, na = jd.na, np = 6 * jd.na, nblk = jd.nblk;
     if (nobs <= 0 || na <= 0) { if (tid == 0) jd.iters_done = 0; return; }
+    if (MODE == 2 && jd.reserved == 2) return;             // every shard of the problem fits the resident layout: k_ba_ll (k_ba_ll.h) takes it
     long long *prof = (prof_all && job == 0) ? prof_all : nullptr;
     long long tprev = prof ? wall_clock64() : 0;
     // LDS carve (all dynamic): S[(np+1)*(np+1)] | bs[np] | xp[np] | Hpp[36*na] | bp[np] | red[W] | PT[12 na] | CT[32] | flag
@@ -1206,166 +1444,8 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                 __syncthreads();
                 BA_PROF(3);
             }
-            // ---- blocked (6x6 = one pose) right-looking Cholesky S = L L^T in LDS on the whole
-            // workgroup; the right-hand side rides along as row np, so L y = bs comes out of the
-            // same sweep; then L^T x = y on one wave.  Per block column: every thread factors the
-            // 6x6 diagonal block redundantly in registers (broadcast LDS reads), one thread per
-            // row solves the panel, one thread per (row, block) updates the trailing matrix.
-            int ok = 1;
-            {
-                BA_PHASE_TID;
-                double *rhs = S + (size_t)np * ld;        // extra row: bs on entry, y on exit
-                double *invd = xp;                         // 1 / L_kk (xp is free until the back-substitution)
-                for (int i = tid; i < np; i += BA_THREADS) rhs[i] = bs[i];
-                __syncthreads();
-                for (int kb = 0; kb < na; ++kb) {
-                    const int c0 = 6 * kb;
-                    // 1. + 2. diagonal block -> Ld (lower), inverse pivots
-                    double Ld[6][6], inv[6];
-#pragma unroll
-                    for (int r = 0; r < 6; ++r)
-#pragma unroll
-                        for (int c = 0; c <= r; ++c) Ld[r][c] = S[(size_t)(c0 + r) * ld + c0 + c];
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) {
-                        double d = Ld[c][c];
-#pragma unroll
-                        for (int m = 0; m < c; ++m) d -= Ld[c][m] * Ld[c][m];
-                        if (!(d > 0)) ok = 0;
-                        // rsqrt: hardware estimate + 2 Newton steps
-                        double y = __builtin_amdgcn_rsq(d);
-                        y = y * (1.5 - 0.5 * d * y * y);
-                        y = y * (1.5 - 0.5 * d * y * y);
-                        inv[c] = y;
-                        Ld[c][c] = d * y;
-#pragma unroll
-                        for (int r = c + 1; r < 6; ++r) {
-                            double v = Ld[r][c];
-#pragma unroll
-                            for (int m = 0; m < c; ++m) v -= Ld[r][m] * Ld[c][m];
-                            Ld[r][c] = v * y;
-                        }
-                    }
-                    if (!ok) break;                        // uniform: all threads factor the same block
-                    // 3. panel: one thread per row i below the diagonal block.  (The rows of the diagonal block itself
-                    // are written after the panel barrier: until then other threads may still be reading the block, and
-                    // nothing reads its factor before the final back-substitution — one barrier per block column less.)
-                    for (int i = c0 + 6 + tid; i <= np; i += BA_THREADS) {
-                        double *ri = S + (size_t)i * ld + c0;
-                        double x[6];
-#pragma unroll
-                        for (int c = 0; c < 6; ++c) x[c] = ri[c];
-#pragma unroll
-                        for (int c = 0; c < 6; ++c) {
-                            double v = x[c];
-#pragma unroll
-                            for (int m = 0; m < c; ++m) v -= x[m] * Ld[c][m];
-                            x[c] = v * inv[c];
-                        }
-#pragma unroll
-                        for (int c = 0; c < 6; ++c) ri[c] = x[c];
-                    }
-                    __syncthreads();
-                    if (tid < 6) {                         // factor rows of the diagonal block, inverse pivots
-                        double *ro = S + (size_t)(c0 + tid) * ld + c0;
-#pragma unroll
-                        for (int c = 0; c < 6; ++c) {
-                            double v = Ld[0][c];
-#pragma unroll
-                            for (int r = 1; r < 6; ++r) v = (tid == r) ? Ld[r][c] : v;
-                            ro[c] = c > tid ? 0.0 : v;
-                        }
-                        double v = inv[0];
-#pragma unroll
-                        for (int c = 1; c < 6; ++c) v = (tid == c) ? inv[c] : v;
-                        invd[c0 + tid] = v;
-                    }
-                    // 4. trailing update, one thread per (row i, block column jb):
-                    //    S[i][6jb + c'] -= sum_c L[i][c0 + c] * L[6jb + c'][c0 + c]   (lower triangle only)
-                    const int nbm = na - kb - 1, nrows = np + 1 - (c0 + 6);
-                    for (int t = tid; t < nrows * nbm; t += BA_THREADS) {
-                        const int i = c0 + 6 + t / nbm, jb = kb + 1 + t % nbm;
-                        const int jb_last = (i < np) ? i / 6 : na - 1;
-                        if (jb > jb_last) continue;
-                        const double *pi = S + (size_t)i * ld + c0;
-                        double x[6];
-#pragma unroll
-                        for (int c = 0; c < 6; ++c) x[c] = pi[c];
-                        double *u = S + (size_t)i * ld + 6 * jb;
-                        const double *P = S + (size_t)(6 * jb) * ld + c0;
-#pragma unroll
-                        for (int cp = 0; cp < 6; ++cp) {
-                            const double *pr = P + (size_t)cp * ld;
-                            u[cp] -= x[0] * pr[0] + x[1] * pr[1] + x[2] * pr[2] + x[3] * pr[3] + x[4] * pr[4] + x[5] * pr[5];
-                        }
-                    }
-                    __syncthreads();
-                }
-            }
-            if (wv == 0) {
-                BA_PHASE_TID;
-                double *rhs = S + (size_t)np * ld;
-                double *invd = xp;
-                if (prof && tid == 0) { long long t_ = wall_clock64(); prof[7] += t_ - tprev; }
-                if (ok && np <= 64) {
-                    // rhs holds y; back-substitution L^T x = y with the stored inverse pivots, one unknown per lane
-                    // (np <= 64: K <= 10 keyframes, the only shape the pipeline produces; the general version below
-                    // carries three 64-lane chunks through every step and cost 11.6 us of a 136-us trial).  x lives in
-                    // a register, the pivot comes over v_readlane, rows k - 1 and k - 2 of L are already requested
-                    // when step k runs: the serial chain per unknown is readlane -> multiply -> FMA.
-                    const double iv = lane < np ? invd[lane] : 0.0;
-                    double x = lane < np ? rhs[lane] : 0.0;
-                    double r0 = lane < np ? S[(size_t)(np - 1) * ld + lane] : 0.0;                  // row np - 1 of L
-                    double r1 = (np >= 2 && lane < np - 1) ? S[(size_t)(np - 2) * ld + lane] : 0.0;   // row np - 2
-                    for (int k = np - 1; k >= 0; --k) {
-                        const double r2 = (k >= 2 && lane < k - 1) ? S[(size_t)(k - 2) * ld + lane] : 0.0;
-                        const double xk = readlane_f64(x, k) * readlane_f64(iv, k);
-                        x = lane < k ? x - r0 * xk : (lane == k ? xk : x);
-                        r0 = r1; r1 = r2;
-                    }
-                    if (lane < np) xp[lane] = x;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                } else if (ok) {
-                    // rhs holds y; back-substitution L^T x = y with the stored inverse pivots.  x lives in registers
-                    // (lane i: x_i, x_{i+64}, x_{i+128}), the pivot comes over v_readlane, row k of L is requested one
-                    // step ahead: the serial chain per unknown is readlane -> multiply -> FMA, no LDS round trip.
-                    double ivk[3], xr[3], srow[3];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const int i = lane + 64 * c;
-                        ivk[c] = i < np ? invd[i] : 0.0;
-                        xr[c] = i < np ? rhs[i] : 0.0;
-                        srow[c] = i < np ? S[(size_t)(np - 1) * ld + i] : 0.0;
-                    }
-                    for (int k = np - 1; k >= 0; --k) {
-                        const int kc = k >> 6, kl = k & 63;
-                        double crow[3], nxt[3];
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            crow[c] = srow[c];
-                            const int i = lane + 64 * c;
-                            nxt[c] = (k > 0 && i < k) ? S[(size_t)(k - 1) * ld + i] : 0.0;
-                        }
-                        const double xsel = kc == 0 ? xr[0] : kc == 1 ? xr[1] : xr[2];
-                        const double isel = kc == 0 ? ivk[0] : kc == 1 ? ivk[1] : ivk[2];
-                        const double xk = readlane_f64(xsel, kl) * readlane_f64(isel, kl);
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            const int i = lane + 64 * c;
-                            if (i < k) xr[c] -= crow[c] * xk;
-                            else if (i == k) xr[c] = xk;
-                            srow[c] = nxt[c];
-                        }
-                    }
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) { const int i = lane + 64 * c; if (i < np) xp[i] = xr[c]; }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                }
-                if (lane == 0) iflag[0] = ok;
-            }
-            __syncthreads();
+            const int ok2 = ba_chol_solve(S, ld, np, na, bs, xp, iflag, tid0, prof, tprev);
             BA_PROF(4);
-            const int ok2 = iflag[0];
             double scale_part = 0, scale_pose_part = 0;
             // MODE 2, the whole shard in ONE tile: W, (Hll + lambda I)^-1 and bl of every landmark are still in LDS
             const bool ll_stored = MODE == 2 && ntile == 1 && jd.nmv == nlm;

@@ -332,7 +332,7 @@ k_ba_build(BaDev *jobs, const unsigned int *obs_packed, const float2 *obs_uv,
 // One workgroup per problem.  Shards without edges are masked out (BaDev::shmask) and their exchange slots zeroed.
 __global__ void __launch_bounds__(BB_THREADS)
 k_ba_split(const BaDev *parents, BaDev *shards, const unsigned int *obs_packed, int llw, int tile_cap, int max_nlm,
-           double *xch, size_t xch_stride, unsigned int *cnt)
+           double *xch, size_t xch_stride, unsigned int *cnt, int res_blocks, int res_landmarks, int res_edges)
 {
     extern __shared__ __attribute__((aligned(16))) int sp_lds[];
     const BaDev &pd = parents[blockIdx.x];
@@ -406,8 +406,29 @@ k_ba_split(const BaDev *parents, BaDev *shards, const unsigned int *obs_packed, 
             sh[w] = d;
         }
         tmpl[0] = (long long)mask;
+        for (int w = 0; w <= llw; ++w) cut[w] = estart[cut[w]];      // from here: first EDGE of shard w
+        for (int w = 0; w < llw; ++w) tmpl[1 + w] = 0;               // blocks per shard
     }
     __syncthreads();
+    // Does every shard fit the resident layout of k_ba_ll (blocks / landmarks / edges in LDS, ONE tile)?  Blocks are counted
+    // exactly: an edge opens a block when its (landmark, keyframe) differs from its predecessor's.
+    {
+        int *nb = reinterpret_cast<int *>(tmpl + 1);
+        for (int i = tid; i < nobs; i += BB_THREADS) {
+            const unsigned int ev = opk[i] & 0x00ffffffu, pv = i > 0 ? (opk[i - 1] & 0x00ffffffu) : 0xffffffffu;
+            if (ev == pv) continue;
+            int w = 0;
+            while (w + 1 < llw && i >= cut[w + 1]) ++w;
+            atomicAdd(&nb[w], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            bool fits = res_blocks > 0;
+            const int bcap = min(res_blocks, tile_cap), lcap = min(res_landmarks, tile_cap);
+            for (int w = 0; w < llw; ++w) fits = fits && nb[w] <= bcap && sh[w].nlm <= lcap && sh[w].nobs <= res_edges;
+            for (int w = 0; w < llw; ++w) sh[w].reserved = fits ? 2 : 1;
+        }
+    }
     // shards without edges never publish: their slots of the exchange area read as zero
     const unsigned mask = (unsigned)tmpl[0];
     double *xs = xch + (size_t)blockIdx.x * xch_stride;
@@ -431,5 +452,5 @@ __host__ __device__ inline size_t ba_split_aux_extra(int nkf, int llw)
 }
 static inline size_t ba_split_lds_bytes(int max_nlm, int llw)
 {
-    return sizeof(int) * (size_t)((max_nlm + 2 + 1) & ~1) + sizeof(long long) * ((size_t)max_nlm + 2 + BB_THREADS) + sizeof(int) * (size_t)(llw + 2) + 64;
+    return sizeof(int) * (size_t)((max_nlm + 2 + 1) & ~1) + sizeof(long long) * ((size_t)max_nlm + 2 + BB_THREADS) + sizeof(int) * (size_t)(llw + 2) + 64;      // (BB_THREADS >= 1 + llw ints for the per-shard block counts)
 }

@@ -30,6 +30,7 @@
 #include "k_geom.h"
 #include "k_ba.h"
 #include "k_ba_build.h"
+#include "k_ba_ll.h"
 #include "k_dmap.h"
 
 #define SVSLAM_DMAP_CHUNK 512     /* keyframe jobs per svslam_dmap_keyframe_batch call the staging arena is sized for */
@@ -83,7 +84,8 @@ struct svslam_ctx {
     std::unique_ptr<svs::ThreadPool> pool;   // host-side per-problem preparation
     long long *d_ba_prof = nullptr;
     // low-latency local BA (svslam_set_low_latency): a problem is dealt over ll.w workgroups (k_ba_split, k_local_ba_t<2>)
-    struct { int w = 0; BaDev *shards = nullptr; double *xch = nullptr; unsigned int *cnt = nullptr; size_t xch_stride = 0; BaWork bw; } ll;
+    struct { int w = 0; BaDev *shards = nullptr; double *xch = nullptr; unsigned int *cnt = nullptr; size_t xch_stride = 0; BaWork bw;
+             LlCaps caps = { 0, 0, 0 }; } ll;    // caps.B > 0: problems whose shards fit go to the resident kernel (k_ba_ll)
     double *d_lm_trace = nullptr;            // svslam_lm_trace test hook: [max_jobs][LM_TRACE_STRIDE]
     // host-side wall time (ns): 0 h2d enqueue, 1 d2h enqueue, 2 stream wait, 3 launches, 4 staging memcpy/prep
     long long host_ns[8] = { 0 };
@@ -205,12 +207,25 @@ template <int W> void launch_ba_ll_t(svslam_ctx *c, int nshards, BaDev *shards, 
                        recs, aux, c->ll.bw, delta, iters, chi, c->d_ba_prof, tile_cap,
                        SbaArgs{ 0, 0, 0.0, nullptr, c->d_lm_trace, 0, c->ll.xch, c->ll.cnt, parents, c->ll.xch_stride });
 }
+template <int W> void launch_ba_ll_resident(svslam_ctx *c, int nshards, BaDev *shards, const BaCams *cams, double *poses, double *pts, const BaRec *recs,
+                                            const int *aux, double delta, int iters, double *chi, BaDev *parents)
+{
+    hipLaunchKernelGGL((k_ba_ll<W>), dim3(nshards), dim3(BA_THREADS), ba_ll_lds_bytes(c->lim.max_kf, c->ll.caps), c->stream, shards, cams, poses, pts,
+                       recs, aux, delta, iters, chi, c->d_ba_prof, c->ll.caps,
+                       SbaArgs{ 0, 0, 0.0, nullptr, c->d_lm_trace, 0, c->ll.xch, c->ll.cnt, parents, c->ll.xch_stride });
+}
 bool ba_ll_usable(const svslam_ctx *c, int njobs) { return c->low_latency && c->ll.w > 0 && njobs <= SVSLAM_LL_MAX_PROBLEMS; }
+// tile capacity the shards of the low-latency solver are built with: what both of its kernels can hold
+int ba_ll_tile_cap(const svslam_ctx *c)
+{
+    const int t = ba_tile_cap_ll(c->lim.max_kf);
+    return c->ll.caps.B > 0 ? std::min(t, c->ll.caps.B) : t;
+}
 void launch_ba_solver(svslam_ctx *c, int njobs, bool ll, BaDev *jobs, const BaCams *cams, double *poses, double *pts, const unsigned int *packed,
                       const float2 *uv, const int *srt, BaRec *recs, int *aux, double *chi, int *flag, int max_nlm, int max_nobs,
                       double delta, int iters, bool split_timing)
 {
-    const int tile_cap = ll ? ba_tile_cap_ll(c->lim.max_kf) : ba_tile_cap(c->lim.max_kf);
+    const int tile_cap = ll ? ba_ll_tile_cap(c) : ba_tile_cap(c->lim.max_kf);
     const int ec = bb_edge_cache_fits(max_nlm, max_nobs) ? 1 : 0;
     if (!ll) {
         hipLaunchKernelGGL(k_ba_build, dim3(njobs), dim3(BB_THREADS), bb_lds_bytes(max_nlm, max_nobs), c->stream, jobs, packed, uv, srt, recs, aux,
@@ -223,13 +238,20 @@ void launch_ba_solver(svslam_ctx *c, int njobs, bool ll, BaDev *jobs, const BaCa
     const int W = c->ll.w;
     c->host_ns[6] += njobs;                    // svslam_debug_host_ns slot 6: problems the low-latency solver took
     hipLaunchKernelGGL(k_ba_split, dim3(njobs), dim3(BB_THREADS), ba_split_lds_bytes(max_nlm, W), c->stream, jobs, c->ll.shards, packed, W, tile_cap,
-                       max_nlm, c->ll.xch, c->ll.xch_stride, c->ll.cnt);
+                       max_nlm, c->ll.xch, c->ll.xch_stride, c->ll.cnt, c->ll.caps.B, c->ll.caps.L, c->ll.caps.E);
     hipLaunchKernelGGL(k_ba_build, dim3(njobs * W), dim3(BB_THREADS), bb_lds_bytes(max_nlm, max_nobs), c->stream, c->ll.shards, packed, uv, srt, recs, aux,
                        tile_cap, max_nlm, flag, 1 /* every keyframe active in every shard */, ec, 1 /* every landmark in the tile */);
     if (split_timing) { tm_end(c); tm_begin(c, FAM_DBG3, njobs); }
+    // problems whose shards all fit LDS: the resident kernel; the others: the streaming one (each kernel skips the other's)
+    if (c->ll.caps.B > 0) {
+        if (W == 4) launch_ba_ll_resident<4>(c, njobs * W, c->ll.shards, cams, poses, pts, recs, aux, delta, iters, chi, jobs);
+        else if (W == 8) launch_ba_ll_resident<8>(c, njobs * W, c->ll.shards, cams, poses, pts, recs, aux, delta, iters, chi, jobs);
+        else launch_ba_ll_resident<16>(c, njobs * W, c->ll.shards, cams, poses, pts, recs, aux, delta, iters, chi, jobs);
+    }
     if (W == 4) launch_ba_ll_t<4>(c, njobs * W, c->ll.shards, cams, poses, pts, recs, aux, delta, iters, chi, tile_cap, jobs);
     else if (W == 16) launch_ba_ll_t<16>(c, njobs * W, c->ll.shards, cams, poses, pts, recs, aux, delta, iters, chi, tile_cap, jobs);
-    else launch_ba_ll_t<8>(c, njobs * W, c->ll.shards, cams, poses, pts, recs, aux, delta, iters, chi, tile_cap, jobs);
+    else if (W == 8) launch_ba_ll_t<8>(c, njobs * W, c->ll.shards, cams, poses, pts, recs, aux, delta, iters, chi, tile_cap, jobs);
+    else return;
 }
 
 inline long long now_ns()
@@ -659,10 +681,10 @@ int svslam_set_low_latency(svslam_ctx *c, int on)
     // runtime instead of sleep-polling the event (SVSLAM_WAIT=poll|spin still overrides)
     if (!std::getenv("SVSLAM_WAIT")) c->wait_poll = !c->low_latency;
     // one local-BA problem over several workgroups (k_local_ba_t<2>): shard descriptors, exchange area, arrival counters and
-    // the per-shard solver scratch, once.  SVSLAM_LL_SHARDS = 4 | 8 (default) | 16; 0 keeps one workgroup per problem.
+    // the per-shard solver scratch, once.  SVSLAM_LL_SHARDS = 4 | 8 | 16 (default); 0 keeps one workgroup per problem.
     if (c->low_latency && !c->ll.shards && c->lim.max_kf > 0 && !c->ba_host_build && ba_tile_cap_ll(c->lim.max_kf) >= std::max(c->lim.max_kf, 64)) {
         const char *e = std::getenv("SVSLAM_LL_SHARDS");
-        int w = e ? atoi(e) : 8;
+        int w = e ? atoi(e) : 16;
         if (w != 0 && w != 4 && w != 8 && w != 16) return fail(c, "SVSLAM_LL_SHARDS=%d (4, 8, 16 or 0)", w);
         if (w > 0) {
             const size_t nsh = (size_t)SVSLAM_LL_MAX_PROBLEMS * w;
@@ -677,6 +699,13 @@ int svslam_set_low_latency(svslam_ctx *c, int on)
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_split), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)ba_split_lds_bytes(c->lim.max_lm, LL_MAX_W)));
             c->ll.w = w;
+            // the resident kernel (SVSLAM_LL_RESIDENT=0: every problem through the streaming kernel, A/B and its tests)
+            const char *er = std::getenv("SVSLAM_LL_RESIDENT");
+            c->ll.caps = (er && atoi(er) == 0) ? LlCaps{ 0, 0, 0 } : ba_ll_caps(c->lim.max_kf);
+            if (c->ll.caps.B > 0)
+                for (const void *f : { reinterpret_cast<const void *>(k_ba_ll<4>), reinterpret_cast<const void *>(k_ba_ll<8>),
+                                       reinterpret_cast<const void *>(k_ba_ll<16>) })
+                    HIPCHK(c, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ba_ll_lds_bytes(c->lim.max_kf, c->ll.caps)));
         }
     }
     return 0;
@@ -988,7 +1017,7 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
     static_assert(sizeof(BaJob) == sizeof(svslam_ba_job), "job layout");
     const size_t TO = (size_t)std::max(total_obs, 1);
     const bool use_ll = !c->ba_host_build && ba_ll_usable(c, njobs);
-    const int tile_cap = use_ll ? ba_tile_cap_ll(c->lim.max_kf) : ba_tile_cap(c->lim.max_kf);     // (reservations: the smaller tiles need more room)
+    const int tile_cap = use_ll ? ba_ll_tile_cap(c) : ba_tile_cap(c->lim.max_kf);     // (reservations: the smaller tiles need more room)
     // arena: cams | jobs | poses | points | [raw edges + order (device build)] | chi2 + flag (out) |
     //        records | aux  (records and aux are device-only when the device builds the structure)
     size_t ocams = c->ar.take(sizeof(BaCams));
@@ -1487,7 +1516,7 @@ int svslam_dmap_keyframe_batch(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, 
     }
     const int NF = m.NF, NL = m.NL, MO = c->lim.max_obs, MK = c->lim.max_kf, MC = p->num_features;
     const bool use_ll = ba_ll_usable(c, njobs);
-    const int tile_cap = use_ll ? ba_tile_cap_ll(MK) : ba_tile_cap(MK);
+    const int tile_cap = use_ll ? ba_ll_tile_cap(c) : ba_tile_cap(MK);
     const size_t aux_stride = ba_aux_layout(MK, NL, MO, MO, MK, 0, ba_tile_bound(NL, MO, MK, tile_cap)).total + ba_pitem_bound(MO, MK) +
                               (use_ll ? ba_split_aux_extra(MK, c->ll.w) : 0);
     const size_t n = njobs, P = n * NF, E = n * MO;
@@ -1627,7 +1656,7 @@ int svslam_debug_host_ns(svslam_ctx *c, long long *out8)
 }
 
 // test hook: the shard descriptors of the last low-latency local-BA call (k_ba_split / k_ba_build): 8 ints per shard —
-// landmarks, edges, blocks, tiles, landmarks in tiles, active poses, mask of shards with edges, iterations
+// landmarks, edges, blocks, tiles, solver (2: resident kernel k_ba_ll, 1: streaming k_local_ba_t<2>), active poses, mask of shards with edges, iterations
 int svslam_debug_ll_shards(svslam_ctx *c, int nproblems, int *out8, int *shards_per_problem)
 {
     if (shards_per_problem) *shards_per_problem = c->ll.w;
@@ -1637,7 +1666,7 @@ int svslam_debug_ll_shards(svslam_ctx *c, int nproblems, int *out8, int *shards_
     HIPCHK(c, hipMemcpy(h.data(), c->ll.shards, sizeof(BaDev) * h.size(), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < h.size(); ++i) {
         int *o = out8 + 8 * i;
-        o[0] = h[i].nlm; o[1] = h[i].nobs; o[2] = h[i].nblk; o[3] = h[i].ntile; o[4] = h[i].nmv; o[5] = h[i].na; o[6] = h[i].shmask; o[7] = h[i].iters_done;
+        o[0] = h[i].nlm; o[1] = h[i].nobs; o[2] = h[i].nblk; o[3] = h[i].ntile; o[4] = h[i].reserved; o[5] = h[i].na; o[6] = h[i].shmask; o[7] = h[i].iters_done;
     }
     return 0;
 }
@@ -1668,12 +1697,18 @@ int svslam_debug_clock_mhz(svslam_ctx *c, int blocks, double ms, double *mhz)
 int svslam_ba_profile(svslam_ctx *c, int enable, long long *out12)
 {
     if (enable && !c->d_ba_prof) {
-        HIPCHK(c, hipMalloc(&c->d_ba_prof, sizeof(long long) * BA_PROF_N));
-        HIPCHK(c, hipMemset(c->d_ba_prof, 0, sizeof(long long) * BA_PROF_N));
+        HIPCHK(c, hipMalloc(&c->d_ba_prof, sizeof(long long) * (BA_PROF_N + 4)));
+        HIPCHK(c, hipMemset(c->d_ba_prof, 0, sizeof(long long) * (BA_PROF_N + 4)));
     }
     if (out12 && c->d_ba_prof) {
-        HIPCHK(c, hipMemcpy(out12, c->d_ba_prof, sizeof(long long) * BA_PROF_N, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemset(c->d_ba_prof, 0, sizeof(long long) * BA_PROF_N));
+        long long all[BA_PROF_N + 4];
+        HIPCHK(c, hipMemcpy(all, c->d_ba_prof, sizeof(all), hipMemcpyDeviceToHost));
+        memcpy(out12, all, sizeof(long long) * BA_PROF_N);
+        // development (-DBA_CHOL_PROF builds): wave 0's clocks inside the factorisation — wait at the top of a block column,
+        // its share of the trailing update, factor + panel of the next column, wait at the column's barrier
+        if (std::getenv("SVSLAM_BA_PROF_EXTRA"))
+            fprintf(stderr, "[chol wave 0, us] top %.1f  trail %.1f  factor+panel %.1f  barrier %.1f\n", all[12] / 100.0, all[13] / 100.0, all[14] / 100.0, all[15] / 100.0);
+        HIPCHK(c, hipMemset(c->d_ba_prof, 0, sizeof(long long) * (BA_PROF_N + 4)));
     }
     if (!enable && c->d_ba_prof) { (void)hipFree(c->d_ba_prof); c->d_ba_prof = nullptr; }
     return 0;

@@ -22,24 +22,28 @@ def _sorted_job(job):
     return poses, pts, okf[o], olm[o], ori[o], ouv[o]
 
 
-def _make_ctx(svs, shards):
-    old = os.environ.get("SVSLAM_LL_SHARDS")
+def _make_ctx(svs, shards, resident):
+    """resident = 1: problems whose shards all fit LDS go to k_ba_ll, the others to k_local_ba_t<2>; 0: all to the latter"""
+    old = {k: os.environ.get(k) for k in ("SVSLAM_LL_SHARDS", "SVSLAM_LL_RESIDENT")}
     os.environ["SVSLAM_LL_SHARDS"] = str(shards)
+    os.environ["SVSLAM_LL_RESIDENT"] = str(resident)
     try:
         c = svs.Context(cm.W, cm.H, max_slots=1, max_jobs=16, max_kf=11, max_lm=4096, max_obs=16384)
         c.low_latency(True)
     finally:
-        if old is None:
-            os.environ.pop("SVSLAM_LL_SHARDS", None)
-        else:
-            os.environ["SVSLAM_LL_SHARDS"] = old
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     c.lm_trace(True)
+    c.resident = resident
     return c
 
 
-@pytest.fixture(scope="module", params=[8, 4, 16])
+@pytest.fixture(scope="module", params=[(16, 1), (16, 0), (8, 1), (4, 0)], ids=lambda p: "%dshards-%s" % (p[0], "resident" if p[1] else "streaming"))
 def ctx(svs, request):
-    c = _make_ctx(svs, request.param)
+    c = _make_ctx(svs, *request.param)
     yield c
     c.close()
 
@@ -68,6 +72,11 @@ def test_ll_on_captured_pipeline_problems(ctx, orc):
             assert np.array_equal(np.lexsort((job[2], job[3])), np.arange(len(job[2]))), "captured problems are landmark-major"
             (poses, pts, chi2, it), = ctx.local_ba([job], cam, cm.EXT_L, cam, ext_r)
             _took_ll(ctx, 1)
+            sh = ctx.ll_shards(1)[0]
+            if not ctx.resident:
+                assert np.all(sh[:, 4] == 1)
+            elif sh.shape[0] == 16:
+                assert np.all(sh[:, 4] == 2), "a K <= 10 window over 16 workgroups fits the resident layout: %s" % sh[:, :5].tolist()
             assert it == int(p["iters"][0])
             assert np.allclose(poses[:, 4:], p["poses"][:, 4:], atol=1e-6), (tag, i, np.abs(poses - p["poses"]).max())
             assert np.allclose(poses[:, :4], p["poses"][:, :4], atol=1e-7)

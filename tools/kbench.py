@@ -45,7 +45,7 @@ def ba(nj=1, nkf=10, nlm=700, reps=3, ll=0):
         prof = c.ba_profile(True, read=True)
         c.timing(True)
         if ll and r == 0:
-            print("  shards (landmarks, edges, blocks, tiles, landmarks in tiles):", c.ll_shards(1)[0][:, :5].tolist())
+            print("  shards (landmarks, edges, blocks, tiles, solver 2=resident):", c.ll_shards(1)[0][:, :5].tolist())
         names = ["edge+J", "lm+pose", "dinv/Y/Sinit", "schur", "chol", "backsub", "errors"]
         tot = sum(prof[:7])
         print("  rep %d: %.3f ms/launch; trials %d; phase us (100MHz ticks/100): " % (r, ms / max(n, 1), prof[11]) +
