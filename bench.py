@@ -67,6 +67,56 @@ def measured_traffic(fam, cnt, launches):
     return t["bytes"] * units / launches
 
 
+F64_VECTOR_PEAK_TFLOPS = 78.6       # MI355X f64 vector peak (half the f32 vector rate, MI355X_MICROARCH.md chip table)
+SIMDS = 256 * 4
+
+
+def compute_side(fam, cnt, fam_ms):
+    """The compute-side ruler of the two kernels that own most of the step (the HBM roofline says
+    nothing about a kernel bound by f64 latency or by integer issue).
+      local_ba: counted f64 flops of the timed problems / the family's HIP-event time, against the f64 vector peak.
+                Flop model: per LM trial E * 500 (residual, Jacobians, normal-equation sums of an edge)
+                + P * 324 (a block pair of the Schur complement: Y = W Dinv, Y W^T) + (6K)^3 / 3 (Cholesky), with
+                E edges, P block pairs, K keyframes and the trial count as the library logged them for the timed
+                problems (svslam_dmap_job::ba_npair / ba_ntrial).
+      lk:       VALU wave-instructions issued / time, against the issue peak of its instruction class
+                (v_dot2 / v_perm / v_mad_i24 class: 1.75 ns per wave-instruction per SIMD at full occupancy,
+                profiles/r3_ubench_valu_issue_rates.txt); instructions per point from the committed PMC pass.
+    valu_busy comes from the committed PMC passes (profiles/pmc_valu.json: tools/pmc_ba.sh, tools/pmc_lk.sh), like
+    `traffic` it is a constant of the build, not something this run measured."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_valu.json")))
+    except (OSError, ValueError):
+        pmc = {}
+    t = fam_ms / 1e3
+    if t <= 0:
+        return None
+    if fam == "local_ba":
+        calls = max(cnt["ba_calls"], 1)
+        trials = cnt.get("ba_trials", 0) or cnt["ba_iters"]
+        k = cnt["ba_kf"] / calls
+        flops = (trials / calls) * (cnt["ba_edges"] * 500.0 + cnt.get("ba_pairs", 0) * 324.0 + calls * (6 * k) ** 3 / 3.0)
+        p = pmc.get("local_ba", {})
+        return {"kernel": "local_ba", "flops": round(flops), "flops_per_problem": round(flops / calls),
+                "lm_trials_per_problem": round(trials / calls, 2), "block_pairs_per_problem": round(cnt.get("ba_pairs", 0) / calls, 1),
+                "achieved_tflops": round(flops / t / 1e12, 3), "peak_tflops": F64_VECTOR_PEAK_TFLOPS,
+                "frac": round(flops / t / 1e12 / F64_VECTOR_PEAK_TFLOPS, 5),
+                "valu_busy": p.get("valu_busy"), "valu_insts_per_problem": p.get("valu_insts_per_unit"),
+                "valu_source": p.get("source", "no committed PMC pass")}
+    if fam == "lk":
+        p = pmc.get("lk", {})
+        ipp = p.get("valu_insts_per_unit")
+        pts = cnt["track_pts"] + cnt["right_pts"]
+        if not ipp or not pts:
+            return None
+        peak = SIMDS / 1.75e-9 / 1e9           # G wave-instructions / s
+        ach = ipp * pts / t / 1e9
+        return {"kernel": "lk", "valu_wave_insts": round(ipp * pts), "valu_insts_per_point": ipp,
+                "achieved_ginst_s": round(ach, 1), "peak_ginst_s": round(peak, 1), "frac": round(ach / peak, 4),
+                "valu_busy": p.get("valu_busy"), "valu_source": p.get("source", "no committed PMC pass")}
+    return None
+
+
 def effective_cpus():
     """CPUs this process may actually burn: min(affinity, cgroup v2 cpu.max quota)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
@@ -142,6 +192,10 @@ def main():
                     help="keep every stream's map (window, features, landmarks, observations) on the HOST as in rounds 1-2; "
                          "default: the map lives in HBM and the keyframe path is one chain of kernels (svslam_dmap_*) — "
                          "bit-identical results, a fraction of the host CPU")
+    ap.add_argument("--full-res-streams", type=int, default=2048,
+                    help="streams of the value_full_res leg: after the reported run the script runs itself once more with the "
+                         "frames stored at the camera's 1241x376 (BASELINE's metric names that size) and the 1/2 decimation "
+                         "fused into the pyramid, same steps / warm-up (0 = skip; one GPU only)")
     ap.add_argument("--full-res", action="store_true",
                     help="keep the frames in HBM at the camera's 1241x376 and fuse the reference's 1/2 "
                          "decimation (Dataset::NextFrame) into the pyramid's level 0 (SURVEY 8 row f3); 4x the "
@@ -491,12 +545,14 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "peak_measured": HBM_PEAK_MEASURED_GBS, "frac_of_peak_measured": round(achieved / HBM_PEAK_MEASURED_GBS, 6),
                          "traffic": measured_traffic(dom, cnt, launches),
+                         "traffic_source": "committed PMC pass (profiles/pmc_traffic.json, tools/pmc_traffic.sh), not measured by this run",
                          "avg_launch_us": round(avg_s * 1e6, 2), "launches": launches,
                          "algorithmic_bytes_per_launch": round(abytes / max(launches, 1), 1)},
             # every kernel family priced the same way (launches of different groups overlap, so each
             # family's duration is its own HIP-event time, not a share of the wall clock), and the
             # whole step: all algorithmic bytes of the timed region over its wall time
             "roofline_by_family": by_fam,
+            "roofline_compute": {f: compute_side(f, cnt, fam_t[f][0]) for f in ("local_ba", "lk") if fam_t[f][1]},
             "roofline_solo": solo,
             "value_spread": {"windows": [round(v, 1) for v in spread], "steps_each": K,
                              "min": round(min(spread), 1) if spread else None, "max": round(max(spread), 1) if spread else None,
@@ -529,9 +585,32 @@ def main():
                                 effective_cpus())
             out["cpu_baseline"] = base["one_thread"]
             out["cpu_baseline_all_cores"] = base["all_cores"]
-        print(json.dumps(out), flush=True)
+    run_full_res = rank == 0 and world == 1 and args.full_res_streams > 0 and not args.full_res
+    if run_full_res:
+        ctx.dev_free(d_left); ctx.dev_free(d_right)     # (before the contexts go: the leg below needs the memory)
     for p in pipes:
         p.close()
+    if rank == 0:
+        # ---- value_full_res: BASELINE.json's metric names 1241x376 frames; the reported run keeps the frames in HBM already
+        #      decimated (the reference's working resolution).  This leg stores them at full size and fuses the decimation
+        #      (src/dataset.cpp:126-129) into the pyramid's level 0: the same hot path plus the 4x larger frame read.
+        if run_full_res:
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), "--full-res", "--streams", str(args.full_res_streams), "--steps", str(K),
+                   "--warmup", str(Wm), "--no-cpu-baseline", "--spread-windows", "0", "--host-input-steps", "0", "--solo-steps", "0",
+                   "--full-res-streams", "0"]
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+                d = json.loads(r.stdout.strip().splitlines()[-1])
+                out["value_full_res"] = {"value": d["value"], "unit": "frames/s", "streams": d["config"]["streams_per_gpu"], "steps": d["steps"],
+                                         "ms_per_step": d["ms_per_step"], "frame": d["config"]["frame"],
+                                         "checks": d["config"]["checks"],
+                                         "how": "the same script run once more after the reported measurement: frames kept in HBM at "
+                                                "1241x376, 1/2 decimation fused into the pyramid kernel (SURVEY 8 row f3); fewer streams "
+                                                "because a frame is 4x the bytes"}
+            except Exception as e:   # noqa: BLE001
+                out["value_full_res"] = {"error": repr(e)[:300]}
+        print(json.dumps(out), flush=True)
     rk.close()
 
 

@@ -188,7 +188,7 @@ typedef struct svslam_ba_job {
     int lm_ofs, nlm;
     int obs_ofs, nobs;
     int iters_done;     /* out: LM iterations executed                       */
-    int reserved;
+    int reserved;       /* out: accounting — (LM trials << 24) | block pairs of the Schur complement */
 } svslam_ba_job;
 
 int svslam_local_ba_batch(svslam_ctx *ctx, int njobs, svslam_ba_job *jobs,
@@ -344,6 +344,7 @@ typedef struct svslam_dmap_job {
     int    ba_nkf, ba_nlm, ba_nobs, ba_iters;
     int    flags;          /* 1 corners dropped (max_pts), 2 landmark slots exhausted, 4 BA skipped (max_obs)    */
     int    dead;
+    int    ba_npair, ba_ntrial; /* accounting: (pose, landmark) block pairs of the Schur complement, LM trials (accepted + rejected) */
     int    ev_ofs, ev_n;   /* the landmarks this job freed: records [ev_ofs, ev_ofs + ev_n) of svslam_dmap_evicted()    */
     double win_pose[12][7];/* poses of the BA problem's keyframes after the solve ...                            */
     int    win_slot[12];   /* ... and their slots                                                                */

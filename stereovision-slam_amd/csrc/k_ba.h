@@ -75,6 +75,8 @@ struct BaDev {               // device-side job descriptor (built on the host)
     int lm_base;             // low-latency shards (k_ba_split): the packed edges name landmarks of the PARENT problem;
                              // this shard owns [lm_base, lm_base + nlm) of them
     int shmask;              // low-latency shards: bit v set = shard v of the problem has edges (takes part in the exchanges)
+    int ntrial;              // out: LM trials executed (accepted + rejected); with ncontrib (block pairs of the Schur
+                             // complement) the accounting of the compute-side roofline (bench.py)
 };
 
 struct BaWork {              // per-job HBM scratch, strided by the context limits
@@ -329,7 +331,7 @@ struct BaHostStruct {        // scratch reused across jobs
         cp(L.pcs, pcs, (size_t)ntile * ((size_t)na * (na + 1) / 2) + 1); cp(L.pitem, pitem, ncontrib);
         d.kf_ofs = j.kf_ofs; d.nkf = j.nkf; d.lm_ofs = j.lm_ofs; d.nlm = j.nlm; d.obs_ofs = j.obs_ofs; d.nobs = j.nobs;
         d.nblk = nblk; d.na = na; d.ncontrib = ncontrib; d.ntile = ntile; d.iters_done = 0; d.rec_ofs = 0;
-        d.lay_nblk = nblk; d.lay_na = na; d.lay_ntile = ntile; d.nmv = nmv; d.reserved = 0; d.lm_base = 0; d.shmask = 0;
+        d.lay_nblk = nblk; d.lay_na = na; d.lay_ntile = ntile; d.nmv = nmv; d.reserved = 0; d.lm_base = 0; d.shmask = 0; d.ntrial = 0;
     }
 };
 
@@ -1106,7 +1108,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
     };
 
     double lambda = MODE == 1 ? sba.lambda : 0, ni = 2;
-    int it_done = 0;
+    int it_done = 0, trials_done = 0;
     const int npairs = na * (na + 1) / 2;
     double currentChi = 0;
     if (MODE == 1 && sba.phase == 4) {                     // reject the trial
@@ -1616,7 +1618,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                 lambda *= ni; ni *= 2;                     // rejected: `cur` was never touched
                 if (!isfinite(lambda)) break;
             }
-            ++qmax;
+            ++qmax; ++trials_done;
             if (prof && tid == 0) prof[BA_PROF_N - 1] += 1;
         } while (rho < 0 && qmax < 10);
         if (ll_failed) break;
@@ -1655,7 +1657,13 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
         d3[0] = cur[3 * (size_t)j]; d3[1] = cur[3 * (size_t)j + 1]; d3[2] = cur[3 * (size_t)j + 2];
     }
     if (pcur != poses && (MODE != 2 || ll_leader)) for (int i = tid; i < 7 * nkf; i += BA_THREADS) poses[i] = pcur[i];
-    if (tid == 0) { jd.iters_done = it_done; if (MODE == 2 && ll_leader) sba.parents[ll_prob].iters_done = it_done; }
+    if (tid == 0) {
+        jd.iters_done = it_done; jd.ntrial = trials_done;
+        if (MODE == 2) {        // the problem's totals for its caller: iterations / trials once, block pairs summed over the shards
+            if (ll_leader) { sba.parents[ll_prob].iters_done = it_done; sba.parents[ll_prob].ntrial = trials_done; }
+            atomicAdd(&sba.parents[ll_prob].ncontrib, jd.ncontrib);
+        }
+    }
 }
 
 static inline size_t ba_lds_fixed_bytes(int max_kf)

@@ -82,7 +82,7 @@ k_ba_build(BaDev *jobs, const unsigned int *obs_packed, const float2 *obs_uv,
     BaRec *recL = recs_all + jd.rec_ofs, *recP = recL + nobs;
     int *aux = aux_all + jd.aux_ofs;
     if (nobs <= 0 || nlm <= 0 || nkf <= 0) {
-        if (tid == 0) { jd.nblk = 0; jd.na = 0; jd.ncontrib = 0; jd.ntile = 0; jd.nmv = 0; }
+        if (tid == 0) { jd.nblk = 0; jd.na = 0; jd.ncontrib = 0; jd.ntile = 0; jd.nmv = 0; jd.ntrial = 0; }
         return;
     }
     const BaAuxLayout AL = ba_aux_layout(nkf, nlm, nobs, jd.lay_nblk, jd.lay_na, 0, jd.lay_ntile);
@@ -348,7 +348,7 @@ k_ba_split(const BaDev *parents, BaDev *shards, const unsigned int *obs_packed, 
     if (empty) {
         for (int w = tid; w < llw; w += BB_THREADS) {
             BaDev d = pd;
-            d.nlm = 0; d.nobs = 0; d.nblk = d.na = d.ncontrib = d.ntile = d.nmv = 0; d.shmask = 0; d.lm_base = 0; d.iters_done = 0;
+            d.nlm = 0; d.nobs = 0; d.nblk = d.na = d.ncontrib = d.ntile = d.nmv = 0; d.shmask = 0; d.lm_base = 0; d.iters_done = 0; d.ntrial = 0;
             sh[w] = d;
         }
         return;
@@ -398,7 +398,7 @@ k_ba_split(const BaDev *parents, BaDev *shards, const unsigned int *obs_packed, 
             const int a = cut[w], b = cut[w + 1], e0 = estart[a], e1 = estart[b];
             BaDev d = pd;
             d.lm_ofs = pd.lm_ofs + a; d.nlm = b - a; d.obs_ofs = pd.obs_ofs + e0; d.nobs = e1 - e0; d.lm_base = a; d.shmask = (int)mask;
-            d.nblk = d.na = d.ncontrib = d.ntile = d.nmv = 0; d.iters_done = 0; d.reserved = 1;
+            d.nblk = d.na = d.ncontrib = d.ntile = d.nmv = 0; d.iters_done = 0; d.reserved = 1; d.ntrial = 0;
             d.rec_ofs = pd.rec_ofs + 2 * e0;
             d.lay_nblk = d.nobs; d.lay_na = nkf; d.lay_ntile = ba_tile_bound(d.nlm, d.nobs, nkf, tile_cap);
             d.aux_ofs = (int)aux;

@@ -288,7 +288,7 @@ k_ba_ll(BaDev *shards, const BaCams *camsp, double *poses_all, double *pts_all, 
     };
 
     double lambda = 0, ni = 2;
-    int it_done = 0;
+    int it_done = 0, trials_done = 0;
     double currentChi = 0;
     bool ll_failed = false;
     const __amdgpu_buffer_rsrc_t rs_all = ll_rsrc(ll_xs, (size_t)LLW * LL_SLAB(np));
@@ -505,7 +505,7 @@ k_ba_ll(BaDev *shards, const BaCams *camsp, double *poses_all, double *pts_all, 
             scale += 1e-3;
             rho /= scale;
             if (sba.trace && tid == 0 && ll_leader) lm_trace_put(sba.trace, ll_prob, it, lambda, currentChi, tempChi, rho, rho > 0 && isfinite(tempChi));
-            ++qmax;
+            ++qmax; ++trials_done;
             if (rho > 0 && isfinite(tempChi)) {
                 double t = 2 * rho - 1;
                 double alpha = 1. - t * t * t;
@@ -547,7 +547,11 @@ k_ba_ll(BaDev *shards, const BaCams *camsp, double *poses_all, double *pts_all, 
         d3[0] = LLX(sx)[3 * j]; d3[1] = LLX(sx)[3 * j + 1]; d3[2] = LLX(sx)[3 * j + 2];
     }
     if (ll_leader) for (int i = tid; i < 7 * nkf; i += BA_THREADS) poses[i] = LLP(sx)[i];
-    if (tid == 0) { jd.iters_done = it_done; if (ll_leader) sba.parents[ll_prob].iters_done = it_done; }
+    if (tid == 0) {
+        jd.iters_done = it_done; jd.ntrial = trials_done;
+        if (ll_leader) { sba.parents[ll_prob].iters_done = it_done; sba.parents[ll_prob].ntrial = trials_done; }
+        atomicAdd(&sba.parents[ll_prob].ncontrib, jd.ncontrib);     // block pairs of the problem = sum over its shards
+    }
 }
 #undef LLX
 #undef LLP

@@ -63,6 +63,7 @@ struct DmJob {                // device copy of svslam_dmap_job + placement (hos
     int stamp, pad0;
     // outputs (device-written)
     int ok, n_features, n_corners, n_right_ok, n_tri_in, n_tri_ok, ba_nkf, ba_nlm, ba_nobs, ba_iters, flags, dead;
+    int ba_npair, ba_ntrial;  // block pairs of the Schur complement, LM trials: the flop accounting of bench.py
     int ev_ofs, ev_n;         // the landmarks this call freed: records [ev_ofs, ev_ofs + ev_n) of the batch's evicted list
     double win_pose[12][7];   // poses of the BA problem's keyframes after the solve, by local index
     int win_slot[12];
@@ -113,6 +114,7 @@ k_dmap_begin(DmJob *jobs, DMap m, RtStore rs, DmEvicted *ev, int *ev_cursor, int
     if (tid == 0) {
         jb.ok = jb.is_init ? 0 : 1; jb.dead = 0; jb.flags = 0; jb.n_corners = jb.n_right_ok = jb.n_tri_in = jb.n_tri_ok = 0;
         jb.ba_nkf = jb.ba_nlm = jb.ba_nobs = jb.ba_iters = 0; jb.n_features = jb.npts; jb.pad0 = 0; jb.ev_ofs = jb.ev_n = 0;
+        jb.ba_npair = jb.ba_ntrial = 0;
     }
     if (jb.is_init) return;
     const size_t L = dm_l(m, s);
@@ -338,7 +340,7 @@ k_dmap_ba_gather(DmJob *jobs, DMap m, DmParams prm, BaDev *badev, double *poses,
     if (tid == 0) {
         bd.kf_ofs = j * max_kf; bd.lm_ofs = j * NL; bd.obs_ofs = j * prm.max_obs; bd.rec_ofs = 2 * j * prm.max_obs;
         bd.nkf = bd.nlm = bd.nobs = 0; bd.nblk = bd.na = bd.ncontrib = bd.ntile = 0; bd.iters_done = 0; bd.nmv = 0; bd.reserved = 1;
-        bd.aux_ofs = (int)(aux_stride * j); bd.lay_nblk = bd.lay_na = bd.lay_ntile = 0; bd.lm_base = 0; bd.shmask = 0;
+        bd.aux_ofs = (int)(aux_stride * j); bd.lay_nblk = bd.lay_na = bd.lay_ntile = 0; bd.lm_base = 0; bd.shmask = 0; bd.ntrial = 0;
     }
     if (jb.dead) return;
     // active keyframes in id order (Map::active_keyframes_ is id-ordered): <= KW of them
@@ -509,7 +511,7 @@ k_dmap_ba_scatter(DmJob *jobs, DMap m, DmParams prm, const BaDev *badev, const d
         m.lm_pos[(L + l) * 3] = pts[((size_t)j * m.NL + i) * 3]; m.lm_pos[(L + l) * 3 + 1] = pts[((size_t)j * m.NL + i) * 3 + 1];
         m.lm_pos[(L + l) * 3 + 2] = pts[((size_t)j * m.NL + i) * 3 + 2];
     }
-    if (tid == 0) jb.ba_iters = bd.iters_done;
+    if (tid == 0) { jb.ba_iters = bd.iters_done; jb.ba_npair = bd.ncontrib; jb.ba_ntrial = bd.ntrial; }
 }
 
 // ---------------------------------------------------------------- the keyframe's features -> the list the next frame tracks from

@@ -251,9 +251,9 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
     __shared__ __attribute__((aligned(16))) double s_red[4 * WAVES * 32];
     __shared__ double s_one[2][4 * WAVES];
     __shared__ int s_int[WAVES];
-    PoseJob &jb = jobs[blockIdx.x];
+    PoseJob &jb = jobs[blockIdx.x];                    // (may be pinned host memory, svslam_hip.hip:dpz — every field is read once)
     const int tid = threadIdx.x;
-    const int n = jb.npts;
+    const int n = jb.npts, jb_pt_ofs = jb.pt_ofs;
 #ifdef PO_PROF     // development: clock ticks (100 MHz) per phase as two extra trace records
     long long po_t = wall_clock64(), po_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 #define PO_TICK(i) do { long long t_ = wall_clock64(); po_acc[i] += t_ - po_t; po_t = t_; } while (0)
@@ -282,11 +282,11 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
     for (int s = 0; s < SLOTS; ++s) {
         const int e = s * NT + tid;
         bool v = e < n;
-        if (v && edge_valid && !edge_valid[jb.pt_ofs + e]) v = false;
+        if (v && edge_valid && !edge_valid[jb_pt_ofs + e]) v = false;
         vmask |= (v ? 1u : 0u) << s;
         if (s < RS) {
             if (e < n) {
-                const int pt = jb.pt_ofs + e;
+                const int pt = jb_pt_ofs + e;
                 P[s][0] = xyz[3 * pt]; P[s][1] = xyz[3 * pt + 1]; P[s][2] = xyz[3 * pt + 2];
                 const float2 m = uv[pt];
                 mu[s] = (double)m.x; mv[s] = (double)m.y;
@@ -297,7 +297,7 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
     auto edge = [&](int s, double *Pq, double &u_, double &v_) {
         if (s < RS) { Pq[0] = P[s < RS ? s : 0][0]; Pq[1] = P[s < RS ? s : 0][1]; Pq[2] = P[s < RS ? s : 0][2]; u_ = mu[s < RS ? s : 0]; v_ = mv[s < RS ? s : 0]; }
         else {
-            const int pt = jb.pt_ofs + s * NT + tid;
+            const int pt = jb_pt_ofs + s * NT + tid;
             Pq[0] = xyz[3 * pt]; Pq[1] = xyz[3 * pt + 1]; Pq[2] = xyz[3 * pt + 2];
             const float2 m = uv[pt];
             u_ = (double)m.x; v_ = (double)m.y;
@@ -468,7 +468,7 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
         int e = s * NT + tid;
-        if (e < n) outlier[jb.pt_ofs + e] = ((vmask & omask) >> s) & 1;
+        if (e < n) outlier[jb_pt_ofs + e] = ((vmask & omask) >> s) & 1;
     }
     if (tid == 0) {
 #pragma unroll
@@ -530,7 +530,7 @@ struct RtStore { float2 *xy[2]; int *mp[2]; double *xyz[2]; int max_pts; };
 __global__ void __launch_bounds__(256)
 k_rt_gather(const RtJob *jobs, RtStore rs, const double *cam, float2 *prev_xy, float2 *next_xy, uint8_t *has_mp, double *xyz)
 {
-    const RtJob &jb = jobs[blockIdx.y];
+    const RtJob jb = jobs[blockIdx.y];                 // a copy: the array may be pinned host memory
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= jb.npts) return;
     const size_t src = (size_t)jb.stream * rs.max_pts + i;
@@ -560,21 +560,21 @@ __global__ void __launch_bounds__(64)
 k_rt_finish(RtJob *jobs, RtStore rs, const float2 *next_xy, const uint8_t *status, const uint8_t *outlier,
             const double *xyz, float2 *out_xy, int *out_mp)
 {
-    RtJob &jb = jobs[blockIdx.x];
+    RtJob &jb = jobs[blockIdx.x];                      // (may be pinned host memory: fields read once)
     const int lane = threadIdx.x;
-    const int dstb = jb.src_buf ^ 1;
+    const int srcb = jb.src_buf, dstb = srcb ^ 1, npts = jb.npts, pt_ofs = jb.pt_ofs;
     const size_t sbase = (size_t)jb.stream * rs.max_pts;
     int base = 0, n_edges = 0, n_out = 0;
-    for (int c0 = 0; c0 < jb.npts; c0 += 64) {
+    for (int c0 = 0; c0 < npts; c0 += 64) {
         const int i = c0 + lane;
-        const bool in = i < jb.npts;
-        const int pt = jb.pt_ofs + (in ? i : 0);
+        const bool in = i < npts;
+        const int pt = pt_ofs + (in ? i : 0);
         const bool ok = in && status[pt] != 0;
         const unsigned long long bal = __ballot(ok);
         int mp = -1;
         bool edge = false, outl = false;
         if (ok) {
-            mp = rs.mp[jb.src_buf][sbase + i];
+            mp = rs.mp[srcb][sbase + i];
             edge = mp >= 0;
             outl = edge && outlier[pt] != 0;
             if (outl) mp = -1;
@@ -584,8 +584,8 @@ k_rt_finish(RtJob *jobs, RtStore rs, const float2 *next_xy, const uint8_t *statu
             rs.mp[dstb][sbase + r] = mp;
             double *Xd = rs.xyz[dstb] + 3 * (sbase + r);
             Xd[0] = xyz[3 * (size_t)pt]; Xd[1] = xyz[3 * (size_t)pt + 1]; Xd[2] = xyz[3 * (size_t)pt + 2];
-            out_xy[jb.pt_ofs + r] = q;
-            out_mp[jb.pt_ofs + r] = mp;
+            out_xy[pt_ofs + r] = q;
+            out_mp[pt_ofs + r] = mp;
         }
         base += __popcll(bal);
         n_edges += __popcll(__ballot(edge));

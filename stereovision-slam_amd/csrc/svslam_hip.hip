@@ -92,6 +92,8 @@ struct svslam_ctx {
     bool wait_poll = true;
     bool wait_block = false;    // SVSLAM_WAIT=block: the completion event sleeps in the driver (hipEventBlockingSync)
     bool low_latency = false;   // svslam_set_low_latency: 4-wave pose-only blocks
+    bool zero_copy = false;     // low latency: the small job / result structs of the tracking path are read and written by the
+                                // kernels straight in the pinned staging memory (no copy kernel, no boundary before / after it)
     bool timing_split = false;  // SVSLAM_TIMING_SPLIT: per-kernel events of the multi-kernel families (families 6..9)
     bool ba_host_build = false; // SVSLAM_BA_HOST_BUILD: problem structure on the host (the checker of k_ba_build), A/B
     int src_w = 0, src_h = 0;     // > 0: level 0 is the 2:1 decimation of src_w x src_h inputs
@@ -339,6 +341,10 @@ int d2h_sync(svslam_ctx *c, size_t from, size_t to)
 
 template <typename T> T *hp(svslam_ctx *c, size_t off) { return reinterpret_cast<T *>(c->ar.h + off); }
 template <typename T> T *dp(svslam_ctx *c, size_t off) { return reinterpret_cast<T *>(c->ar.d + off); }
+// a staged struct array as the kernels see it: the device mirror, or (zero_copy) the pinned host memory itself — hipHostMalloc
+// memory is mapped into the device's address space at the same address, coherent, and what a kernel wrote there is visible to
+// the host once the event behind the kernel has completed
+template <typename T> T *dpz(svslam_ctx *c, size_t off) { return c->zero_copy ? hp<T>(c, off) : dp<T>(c, off); }
 
 // The staging arena (and job 0 of the BA scratch) belongs to a submitted, uncollected local-BA batch or to an
 // open shared-map shard: every other batched call on the context is refused until collect / close.
@@ -434,8 +440,8 @@ int pyramid_common(svslam_ctx *c, int n, const int *slots, const void *const *im
             hj[i].slot = slots[i];
         }
     }
-    if (h2d(c, ojobs, c->ar.off)) return -1;
-    if (launch_pyramid(c, dp<PyrJob>(c, ojobs), n, decimate, src_w, src_h)) return -1;
+    if (!c->zero_copy && h2d(c, ojobs, c->ar.off)) return -1;
+    if (launch_pyramid(c, dpz<PyrJob>(c, ojobs), n, decimate, src_w, src_h)) return -1;
     if (sync) return d2h_sync(c, 0, 0);
     return 0;
 }
@@ -680,6 +686,7 @@ int svslam_set_low_latency(svslam_ctx *c, int on)
     // a caller that waits for one camera's frame wants the result, not its core back: block in the
     // runtime instead of sleep-polling the event (SVSLAM_WAIT=poll|spin still overrides)
     if (!std::getenv("SVSLAM_WAIT")) c->wait_poll = !c->low_latency;
+    { const char *z = std::getenv("SVSLAM_ZERO_COPY"); c->zero_copy = c->low_latency && !(z && atoi(z) == 0); }
     // one local-BA problem over several workgroups (k_local_ba_t<2>): shard descriptors, exchange area, arrival counters and
     // the per-shard solver scratch, once.  SVSLAM_LL_SHARDS = 4 | 8 | 16 (default); 0 keeps one workgroup per problem.
     if (c->low_latency && !c->ll.shards && c->lim.max_kf > 0 && !c->ba_host_build && ba_tile_cap_ll(c->lim.max_kf) >= std::max(c->lim.max_kf, 64)) {
@@ -1118,7 +1125,7 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
             d.nblk = d.na = d.ncontrib = d.ntile = 0; d.iters_done = 0; d.nmv = 0;
             d.rec_ofs = 2 * j.obs_ofs;
             d.lay_nblk = j.nobs; d.lay_na = j.nkf; d.lay_ntile = ba_tile_bound(j.nlm, j.nobs, j.nkf, tile_cap);
-            d.aux_ofs = (int)at; d.lm_base = 0; d.shmask = 0;
+            d.aux_ofs = (int)at; d.lm_base = 0; d.shmask = 0; d.ntrial = 0;
             at += ba_aux_layout(j.nkf, j.nlm, j.nobs, d.lay_nblk, d.lay_na, 0, d.lay_ntile).total + ba_pitem_bound(j.nobs, j.nkf);
             if (use_ll) at += ba_split_aux_extra(j.nkf, c->ll.w);
             if (!d.reserved) all_sorted = false;
@@ -1172,6 +1179,7 @@ int svslam_local_ba_collect(svslam_ctx *c, int njobs, svslam_ba_job *jobs, int t
     for (int i = 0; i < njobs; ++i) {
         if (dj[i].iters_done < 0) return fail(c, "local_ba: job %d: a workgroup of the low-latency solver never arrived (GPU oversubscribed?)", i);
         jobs[i].iters_done = dj[i].iters_done;
+        jobs[i].reserved = (int)(((unsigned)std::min(dj[i].ntrial, 255) << 24) | ((unsigned)dj[i].ncontrib & 0x00ffffffu));   // accounting (svslam.h)
     }
     if (total_kf > 0) memcpy(poses, hp<void>(c, c->ba_pending.oposes), sizeof(double) * 7 * total_kf);
     if (total_lm > 0) memcpy(pts, hp<void>(c, c->ba_pending.opts), sizeof(double) * 3 * total_lm);
@@ -1238,7 +1246,7 @@ int svslam_sba_open(svslam_ctx *c, const double cam_l[4], const double ext_l[7],
     d.kf_ofs = 0; d.nkf = nkf; d.lm_ofs = 0; d.nlm = nlm; d.obs_ofs = 0; d.nobs = nobs;
     d.nblk = d.na = d.ncontrib = d.ntile = 0; d.iters_done = 0; d.rec_ofs = 0; d.nmv = 0; d.reserved = sorted ? 1 : 0;
     d.lay_nblk = nobs; d.lay_na = nkf; d.lay_ntile = ba_tile_bound(nlm, nobs, nkf, tile_cap);
-    d.aux_ofs = 0; d.lm_base = 0; d.shmask = 0;
+    d.aux_ofs = 0; d.lm_base = 0; d.shmask = 0; d.ntrial = 0;
     (void)c->ar.take(sizeof(int) * (ba_aux_layout(nkf, nlm, nobs, d.lay_nblk, d.lay_na, 0, d.lay_ntile).total + ba_pitem_bound(nobs, nkf)));
     if (c->ar.off > c->ar.cap) return fail(c, "sba_open: staging arena too small");
     memcpy(hp<void>(c, ouv_o), obs_uv, sizeof(float) * 2 * TO);
@@ -1886,28 +1894,29 @@ int svslam_rtrack_batch(svslam_ctx *c, int njobs, svslam_rtrack_job *jobs, const
         rj[i].n_tracked = rj[i].n_edges = rj[i].n_outlier = 0; rj[i].pad = 0;
     }
     memcpy(hp<void>(c, ocam), cam, 32);
-    if (h2d(c, base, in_end)) return -1;
+    if (!c->zero_copy && h2d(c, base, in_end)) return -1;
     if (maxn > 0) {
-        hipLaunchKernelGGL(k_rt_gather, dim3(cdiv(maxn, 256), njobs), dim3(256), 0, c->stream, dp<RtJob>(c, ort), c->rt,
-                           dp<double>(c, ocam), dp<float2>(c, oprev), dp<float2>(c, onext), dp<uint8_t>(c, omp), dp<double>(c, oxyz));
+        hipLaunchKernelGGL(k_rt_gather, dim3(cdiv(maxn, 256), njobs), dim3(256), 0, c->stream, dpz<RtJob>(c, ort), c->rt,
+                           dpz<double>(c, ocam), dp<float2>(c, oprev), dp<float2>(c, onext), dp<uint8_t>(c, omp), dp<double>(c, oxyz));
         tm_begin(c, FAM_LK, total_pts);
-        launch_lk(c, njobs, maxn, dp<LkJob>(c, olk), dp<float2>(c, oprev), dp<float2>(c, onext), dp<uint8_t>(c, ostat),
+        launch_lk(c, njobs, maxn, dpz<LkJob>(c, olk), dp<float2>(c, oprev), dp<float2>(c, onext), dp<uint8_t>(c, ostat),
                   dp<float>(c, oerr), p);
         tm_end(c);
         hipLaunchKernelGGL(k_track_filter, dim3(njobs), dim3(256), 0, c->stream,
-                           reinterpret_cast<const LkJobView *>(dp<LkJob>(c, olk)), dp<float2>(c, onext),
+                           reinterpret_cast<const LkJobView *>(dpz<LkJob>(c, olk)), dp<float2>(c, onext),
                            dp<uint8_t>(c, ostat), dp<uint8_t>(c, omp), dp<uint8_t>(c, oval), dp<int>(c, ontr),
                            c->geom.w[0], c->geom.h[0]);
     }
     tm_begin(c, FAM_POSE, njobs);
-    launch_pose_only(c, njobs, dp<PoseJob>(c, opj), dp<double>(c, ocam), dp<double>(c, oxyz), dp<float2>(c, onext),
+    launch_pose_only(c, njobs, dpz<PoseJob>(c, opj), dpz<double>(c, ocam), dp<double>(c, oxyz), dp<float2>(c, onext),
                      dp<uint8_t>(c, oval), dp<uint8_t>(c, oout), chi2_th, 4, 10);
     tm_end(c);
-    hipLaunchKernelGGL(k_rt_finish, dim3(njobs), dim3(64), 0, c->stream, dp<RtJob>(c, ort), c->rt, dp<float2>(c, onext),
-                       dp<uint8_t>(c, ostat), dp<uint8_t>(c, oout), dp<double>(c, oxyz), dp<float2>(c, oxy), dp<int>(c, ompo));
+    hipLaunchKernelGGL(k_rt_finish, dim3(njobs), dim3(64), 0, c->stream, dpz<RtJob>(c, ort), c->rt, dp<float2>(c, onext),
+                       dp<uint8_t>(c, ostat), dp<uint8_t>(c, oout), dp<double>(c, oxyz), dpz<float2>(c, oxy), dpz<int>(c, ompo));
     HIPCHK(c, hipGetLastError());
-    // pose jobs, rt jobs (+ the compacted survivors unless the caller keeps its map on the device and passes no buffers)
-    if (d2h_sync(c, opj, (out_xy || out_mp) ? out_end : in_end)) return -1;
+    // pose jobs, rt jobs (+ the compacted survivors unless the caller keeps its map on the device and passes no buffers);
+    // zero_copy: the kernels wrote them where the host reads them, only the completion is awaited
+    if (c->zero_copy ? d2h_sync(c, 0, 0) : d2h_sync(c, opj, (out_xy || out_mp) ? out_end : in_end)) return -1;
     for (int i = 0; i < njobs; ++i) {
         svslam_rtrack_job &j = jobs[i];
         memcpy(j.pose, pj[i].pose, 56);

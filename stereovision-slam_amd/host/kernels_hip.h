@@ -35,6 +35,7 @@ public:
             ba_ctx_ = nullptr;
             throw std::runtime_error("backend context: " + msg);
         }
+        if (low_latency_) svslam_set_low_latency(ba_ctx_, 1);
     }
     HipKernels(const HipKernels &) = delete;
     HipKernels &operator=(const HipKernels &) = delete;
@@ -48,7 +49,12 @@ public:
     }
     svslam_ctx *backend_ctx() { return ba_ctx_ ? ba_ctx_ : ctx_; }
     int set_source_size(int src_w, int src_h) { return svslam_set_source_size(ctx_, src_w, src_h); }
-    int set_low_latency(int on) { return svslam_set_low_latency(ctx_, on); }
+    int set_low_latency(int on)
+    {
+        low_latency_ = on;
+        if (ba_ctx_ && svslam_set_low_latency(ba_ctx_, on) != 0) return -1;
+        return svslam_set_low_latency(ctx_, on);
+    }
 
     int pyramid(int n, const int *slots, const void *const *imgs, const int *strides, int is_device)
     { return svslam_pyramid_batch(ctx_, n, slots, imgs, strides, is_device); }
@@ -107,6 +113,7 @@ private:
     svslam_ctx *ctx_ = nullptr;
     svslam_ctx *ba_ctx_ = nullptr;
     bool ba_failed_ = false;
+    int low_latency_ = 0;
 };
 
 } // namespace svs

@@ -43,6 +43,7 @@ typedef struct svs_pipe_counters {
     long long ba_calls, ba_edges, ba_kf, ba_lm, ba_iters, pyr_left, pyr_right;
     long long ns_step, ns_kernel_calls;
     long long corners_dropped, ba_skipped;   /* per-stream capacity events (max_pts / max_lm / max_obs) */
+    long long ba_pairs, ba_trials;           /* block pairs of the Schur complements, LM trials: the flop accounting of bench.py */
     long long lm_total, lm_resident;         /* landmarks ever created / MapPoint objects the host still holds (the rest
                                                 were evicted to the 16-byte archive, Map::ReleaseRetired)              */
 } svs_pipe_counters;

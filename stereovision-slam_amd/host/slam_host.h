@@ -352,6 +352,7 @@ struct Counters {                      // workload accounting for the roofline (
     long long gftt_calls = 0, gftt_rects = 0, corners = 0;
     long long right_pts = 0, tri_pts = 0;
     long long ba_calls = 0, ba_edges = 0, ba_kf = 0, ba_lm = 0, ba_iters = 0;
+    long long ba_pairs = 0, ba_trials = 0;        // block pairs of the Schur complements, LM trials (the flop accounting of bench.py)
     long long pyr_left = 0, pyr_right = 0;
     long long ns_step = 0, ns_kernel_calls = 0;   // wall time inside step() / inside the C-ABI calls
     long long corners_dropped = 0, ba_skipped = 0; // per-stream capacity events (Config::max_*)
@@ -747,6 +748,7 @@ private:
             if (j.flags & 4) cnt_.ba_skipped++;
             if (prm.ba_iters > 0 && !(j.flags & 4)) {
                 cnt_.ba_calls++; cnt_.ba_edges += j.ba_nobs; cnt_.ba_kf += j.ba_nkf; cnt_.ba_lm += j.ba_nlm; cnt_.ba_iters += j.ba_iters;
+                cnt_.ba_pairs += j.ba_npair; cnt_.ba_trials += j.ba_ntrial;
                 // :224-246 on the mirror: the window's poses
                 for (int a = 0; a < j.ba_nkf; ++a)
                     for (Frame *kf : st.map.active_keyframes_)
@@ -1258,6 +1260,7 @@ private:
             const svslam_ba_job &j = jobs_ba_[i];
             cnt_.ba_calls++; cnt_.ba_edges += j.nobs; cnt_.ba_kf += j.nkf; cnt_.ba_lm += j.nlm;
             cnt_.ba_iters += j.iters_done;
+            cnt_.ba_pairs += (long long)((unsigned)j.reserved & 0x00ffffffu); cnt_.ba_trials += (long long)((unsigned)j.reserved >> 24);
         }
         pool_.parallel_for(n, [&](int i) {
             Stream &st = *streams_[MS[i]];

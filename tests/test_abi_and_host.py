@@ -55,6 +55,14 @@ def test_product_never_touches_the_oracle():
     if os.path.exists(so):
         needed = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
         assert "libsvslam_hip.so" in needed and "oracle" not in needed
+    # ... and nothing in the environment can point the product's loaders at another library (an
+    # SVS_PIPELINE_LIB override could have loaded the oracle twin, which has the same C API)
+    for f in ("__init__.py", "pipeline.py"):
+        txt = open(os.path.join(pkg, f)).read()
+        for m in re.finditer(r"CDLL\(([^)]*)\)", txt):
+            assert "environ" not in m.group(1) and "getenv" not in m.group(1)
+        for m in re.finditer(r"environ(?:\.get)?\(?\[?[\"']([A-Z_]+)", txt):
+            assert "LIB" not in m.group(1), (f, m.group(1))
 
 
 def _run_twin(svs, seeds, nframes, cfg=None):
