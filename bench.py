@@ -497,6 +497,7 @@ def main():
         ate.append(pl.ate_rmse(res["pose"][:, s_], gt))
     total_frames = S * K * world
     value = total_frames / elapsed
+    ranks_seen = int(round(rk.sum_over_ranks(1.0)))      # an all-reduce of ones over the job's communicator (1 without a process group)
 
     if rank == 0:
         dom = max(fam_t, key=lambda f: fam_t[f][0])
@@ -514,7 +515,11 @@ def main():
         out = {
             "metric": "stereo frames/sec (track + local BA), KITTI-00-shaped synthetic stereo 1241x376 "
                       "(620x188 after the reference's 1/2 decimation)",
-            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "ranks_seen": ranks_seen,
+            "rank_exchange": "RCCL (torch.distributed nccl): barrier + max-reduction of the elapsed time, no data-path collective"
+                             if rk.dist is not None and os.environ.get("SVS_DIST_BACKEND", "nccl") == "nccl" else
+                             ("gloo (dry run)" if rk.dist is not None else "none (a single process outside torch.distributed.run)"),
+            "steps": K, "warmup": Wm,
             "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/i32 fixed-point (pyramid, LK), f32 (GFTT), f64 (LM, BA)",
             "data": "synthetic",

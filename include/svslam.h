@@ -330,7 +330,10 @@ int svslam_rtrack_upload(svslam_ctx *ctx, int n, const int *streams, const int *
  * the slot of the keyframe to retire (-1: none; the se3-log distance rule of RemoveOldKeyframe stays on the host),
  * and reads counts and the window's poses back.  mp values in the resident lists are landmark SLOTS here.       */
 typedef struct svslam_dmap_job {
-    int    stream, slot_cur, slot_right, is_init;
+    int    stream, slot_cur, slot_right, is_init;  /* is_init: 0 keyframe of a tracked frame, 1 StereoInit, 2 no keyframe at all —
+                                                      one local BA over the stream's window as it is (Backend::UpdateMap called from
+                                                      outside the frontend, include/StereoVisionSLAM/backend.h:30): only stream, npts and
+                                                      the BA outputs are used; such jobs do not share a call with keyframe jobs */
     int    kf_slot, remove_slot, kf_id, npts;   /* npts: features the frame has (tracked survivors); 0 at init   */
     long long frame_id;
     double pose[7];        /* in: T_cw (identity at init); out: after the local BA                              */

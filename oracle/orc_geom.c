@@ -413,7 +413,7 @@ static void po_optimize(int n, const double cam[4], double T[7], const double *x
         if (it == 0) {
             double md = 0;
             for (int a = 0; a < 6; ++a) if (fabs(H[a * 7]) > md) md = fabs(H[a * 7]);
-            lambda = 1e-5 * md; ni = 2;
+            lambda = (orc_whatif[1] ? 1e-3 : 1e-5) * md; ni = 2;
         }
         double rho = 0; int qmax = 0;
         double x[6] = { 0, 0, 0, 0, 0, 0 };
@@ -431,7 +431,7 @@ static void po_optimize(int n, const double cam[4], double T[7], const double *x
             rho = currentChi - tempChi;
             double scale = 0;
             for (int a = 0; a < 6; ++a) scale += x[a] * (lambda * x[a] + b[a]);
-            scale += 1e-3;
+            if (!orc_whatif[2]) scale += 1e-3;
             rho /= scale;
             if (po_trace && po_trace_n < po_trace_cap) {
                 double *t = po_trace + (size_t)ORC_TRACE_REC * po_trace_n++;
@@ -690,7 +690,7 @@ int orc_local_ba_trace(const double cam_l[4], const double ext_l[7],
             ba_error(&cams, obs_is_right[e] ? 1 : 0, poses + 7 * obs_kf[e], pts + 3 * obs_lm[e], \
                      obs_uv + 2 * e, err + 2 * e); \
             double r_[3]; \
-            huber(err[2 * e] * err[2 * e] + err[2 * e + 1] * err[2 * e + 1], huber_delta, r_); \
+            huber(err[2 * e] * err[2 * e] + err[2 * e + 1] * err[2 * e + 1], (orc_whatif[7] ? sqrt(huber_delta) : huber_delta), r_); \
             chi_ += r_[0]; \
         } \
         (chi_out) = chi_; } while (0)
@@ -714,7 +714,7 @@ int orc_local_ba_trace(const double cam_l[4], const double ext_l[7],
             else ba_jac_analytic(&cams, cam, poses + 7 * k, pts + 3 * j, Jp, Jl);
             const double *er = err + 2 * e;
             double r[3];
-            huber(er[0] * er[0] + er[1] * er[1], huber_delta, r);
+            huber(er[0] * er[0] + er[1] * er[1], (orc_whatif[7] ? sqrt(huber_delta) : huber_delta), r);
             double w = r[1];
             int pk = 6 * kf_idx[k];
             for (int a = 0; a < 6; ++a) {
@@ -735,7 +735,7 @@ int orc_local_ba_trace(const double cam_l[4], const double ext_l[7],
             for (int a = 0; a < np; ++a) if (fabs(Hpp[(size_t)a * np + a]) > md) md = fabs(Hpp[(size_t)a * np + a]);
             for (int j = 0; j < nlm; ++j) if (lm_act[j])
                 for (int a = 0; a < 3; ++a) if (fabs(Hll[9 * j + a * 4]) > md) md = fabs(Hll[9 * j + a * 4]);
-            lambda = 1e-5 * md; ni = 2;
+            lambda = (orc_whatif[1] ? 1e-3 : 1e-5) * md; ni = 2;
         }
         double rho = 0; int qmax = 0;
         do {
@@ -814,7 +814,7 @@ int orc_local_ba_trace(const double cam_l[4], const double ext_l[7],
                 for (int j = 0; j < nlm; ++j) if (lm_act[j])
                     for (int a = 0; a < 3; ++a) scale += xl[3 * j + a] * (lambda * xl[3 * j + a] + bl[3 * j + a]);
             }
-            scale += 1e-3;
+            if (!orc_whatif[2]) scale += 1e-3;
             rho /= scale;
             if (trace && ntrace < trace_cap) {
                 double *t = trace + (size_t)ORC_TRACE_REC * ntrace++;

@@ -39,8 +39,8 @@ static inline int reflect101(int p, int len)
 
 void orc_min_eig_map(const uint8_t *img, int stride, int w, int h, float *eig)
 {
-    const float s1 = (float)(1.0 / 3060.0);
-    const float s2 = (float)(2.0 * (1.0 / 3060.0));
+    const float s1 = orc_whatif[3] ? (float)(1.0 / 12.0) : (float)(1.0 / 3060.0);
+    const float s2 = orc_whatif[3] ? (float)(2.0 * (1.0 / 12.0)) : (float)(2.0 * (1.0 / 3060.0));
     size_t P = (size_t)w * h;
     float *cxx = (float *)malloc(sizeof(float) * P);
     float *cxy = (float *)malloc(sizeof(float) * P);
@@ -68,11 +68,14 @@ void orc_min_eig_map(const uint8_t *img, int stride, int w, int h, float *eig)
         for (int x = 0; x < w; ++x) {
             int xs[3] = { reflect101(x - 1, w), x, reflect101(x + 1, w) };
             double sxx = 0, sxy = 0, syy = 0; /* exact in f64 */
+            float fxx = 0.f, fxy = 0.f, fyy = 0.f;
             for (int j = 0; j < 3; ++j)
                 for (int i = 0; i < 3; ++i) {
                     size_t q = (size_t)ys[j] * w + xs[i];
                     sxx += cxx[q]; sxy += cxy[q]; syy += cyy[q];
+                    fxx += cxx[q]; fxy += cxy[q]; fyy += cyy[q];
                 }
+            if (orc_whatif[5]) { sxx = fxx; sxy = fxy; syy = fyy; }
             float a = (float)sxx * 0.5f, b = (float)sxy, c = (float)syy * 0.5f;
             float t = a - c;
             eig[(size_t)y * w + x] = (a + c) - sqrtf(t * t + b * b);
@@ -91,6 +94,10 @@ void orc_gftt_mask(uint8_t *mask, int w, int h, const float *rect_xy, int nrect)
         float fx = rect_xy[2 * r], fy = rect_xy[2 * r + 1];
         int x1 = (int)lrintf(fx - 10.f), y1 = (int)lrintf(fy - 10.f);
         int x2 = (int)lrintf(fx + 10.f), y2 = (int)lrintf(fy + 10.f);
+        if (orc_whatif[4]) {
+            x1 = (int)floorf(fx - 10.f + 0.5f); y1 = (int)floorf(fy - 10.f + 0.5f);
+            x2 = (int)floorf(fx + 10.f + 0.5f); y2 = (int)floorf(fy + 10.f + 0.5f);
+        }
         if (x1 < 0) x1 = 0;
         if (y1 < 0) y1 = 0;
         if (x2 > w - 1) x2 = w - 1;
@@ -108,6 +115,7 @@ static int cand_cmp(const void *pa, const void *pb)
     const cand_t *a = (const cand_t *)pa, *b = (const cand_t *)pb;
     if (a->v > b->v) return -1;
     if (a->v < b->v) return 1;
+    if (orc_whatif[6]) return a->idx < b->idx ? -1 : (a->idx > b->idx ? 1 : 0);
     return a->idx > b->idx ? -1 : (a->idx < b->idx ? 1 : 0);
 }
 

@@ -165,6 +165,9 @@ void orc_scharr(const uint8_t *src, int w, int h, int stride, int16_t *out)
 #define W_BITS 14
 #define DESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
 
+int orc_whatif[ORC_WHATIF_N] = { 0 };       /* svs_oracle.h: what-if knobs, all 0 = the oracle as declared */
+void orc_set_whatif(int which, int value) { if (which >= 0 && which < ORC_WHATIF_N) orc_whatif[which] = value; }
+
 static inline int cv_round_f(float v) { return (int)lrintf(v); } /* half-to-even */
 static inline int cv_floor_f(float v) { return (int)floorf(v); }
 
@@ -205,6 +208,7 @@ static void lk_level(const orc_plane *I, const orc_plane *J, const dplane *dI,
         int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
 
         long long sA11 = 0, sA12 = 0, sA22 = 0;
+        float fA11 = 0.f, fA12 = 0.f, fA22 = 0.f;       /* what-if 0: f32 accumulators in pixel order */
         for (int y = 0; y < win; ++y) {
             const uint8_t *src = I->data + (ptrdiff_t)(y + ipy) * I->stride + ipx;
             const int16_t *ds = dI->data + ((ptrdiff_t)(y + ipy) * dI->stride + ipx) * 2;
@@ -222,11 +226,13 @@ static void lk_level(const orc_plane *I, const orc_plane *J, const dplane *dI,
                 sA11 += (long long)ixval * ixval;
                 sA12 += (long long)ixval * iyval;
                 sA22 += (long long)iyval * iyval;
+                fA11 += (float)(ixval * ixval); fA12 += (float)(ixval * iyval); fA22 += (float)(iyval * iyval);
             }
         }
         /* declared order: exact integer sums, one conversion to float */
         float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE,
               A22 = (float)sA22 * FLT_SCALE;
+        if (orc_whatif[0]) { A11 = fA11 * FLT_SCALE; A12 = fA12 * FLT_SCALE; A22 = fA22 * FLT_SCALE; }
         float D = A11 * A22 - A12 * A12;
         float dd = A11 - A22;
         float minEig = (A22 + A11 - sqrtf(dd * dd + 4.f * A12 * A12)) /
@@ -250,6 +256,7 @@ static void lk_level(const orc_plane *I, const orc_plane *J, const dplane *dI,
             iw10 = cv_round_f((1.f - a) * b * (1 << W_BITS));
             iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
             long long sb1 = 0, sb2 = 0;
+            float fb1 = 0.f, fb2 = 0.f;
             for (int y = 0; y < win; ++y) {
                 const uint8_t *Jp = J->data + (ptrdiff_t)(y + iny) * J->stride + inx;
                 int sJ = J->stride;
@@ -258,9 +265,11 @@ static void lk_level(const orc_plane *I, const orc_plane *J, const dplane *dI,
                                        Jp[x + sJ + 1] * iw11, W_BITS - 5) - Ibuf[y * win + x];
                     sb1 += (long long)diff * dIbuf[(y * win + x) * 2];
                     sb2 += (long long)diff * dIbuf[(y * win + x) * 2 + 1];
+                    fb1 += (float)(diff * dIbuf[(y * win + x) * 2]); fb2 += (float)(diff * dIbuf[(y * win + x) * 2 + 1]);
                 }
             }
             float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
+            if (orc_whatif[0]) { b1 = fb1 * FLT_SCALE; b2 = fb2 * FLT_SCALE; }
             float dx = (A12 * b2 - A22 * b1) * D;
             float dy = (A12 * b1 - A11 * b2) * D;
             nx += dx; ny += dy;

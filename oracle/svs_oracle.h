@@ -30,6 +30,22 @@ extern "C" {
 
 #define ORC_MAX_LEVELS 4
 
+/* ---- what-if knobs (sensitivity study of the recalled upstream conventions, tests/oracle_sensitivity.py) ----
+ * The oracle restates OpenCV / g2o from published descriptions (PARITY UNPINNED above).  Each knob flips ONE recalled
+ * convention to its plausible alternative so that the effect of a misrecollection on corners, poses and trajectory
+ * error can be measured.  All knobs are 0 by default — the oracle as declared; nothing but that study sets them.
+ *   0  LK normal-equation sums: 1 = f32 accumulators in pixel order (OpenCV's scalar path) instead of exact integers
+ *   1  g2o LM tau (lambda_0 = tau max diag H): 1 = 1e-3 instead of 1e-5
+ *   2  g2o rho denominator: 1 = without the + 1e-3
+ *   3  Sobel scale of goodFeaturesToTrack: 1 = 1/12 (no 1/255 for 8-bit input) instead of 1/3060
+ *   4  cv::rectangle corner rounding (Point2f -> Point): 1 = half-up instead of half-to-even
+ *   5  box filter of cornerMinEigenVal: 1 = f32 accumulators instead of f64
+ *   6  goodFeaturesToTrack tie-break of equal responses: 1 = address ascending instead of descending
+ *   7  Huber kernel of the local BA: 1 = delta^2 = chi2_th (kernel bends at chi2 > 5.991) instead of delta = chi2_th  */
+#define ORC_WHATIF_N 8
+extern int orc_whatif[ORC_WHATIF_N];
+void orc_set_whatif(int which, int value);
+
 /* ---- pyramids (cv::buildOpticalFlowPyramid, pyrDown, calcSharrDeriv) ---- */
 typedef struct orc_plane {
     int w, h;

@@ -514,6 +514,23 @@ k_dmap_ba_scatter(DmJob *jobs, DMap m, DmParams prm, const BaDev *badev, const d
     if (tid == 0) { jb.ba_iters = bd.iters_done; jb.ba_npair = bd.ncontrib; jb.ba_ntrial = bd.ntrial; }
 }
 
+// ---------------------------------------------------------------- after a local BA that ran outside a keyframe step
+// (Backend::UpdateMap called from outside the frontend, include/StereoVisionSLAM/backend.h:30): the resident list of the
+// frame being tracked keeps its features, only the positions of the landmarks they name are the optimised ones
+__global__ void __launch_bounds__(DM_THREADS)
+k_dmap_refresh_xyz(DmJob *jobs, DMap m, RtStore rs)
+{
+    const DmJob &jb = jobs[blockIdx.x];
+    const int tid = threadIdx.x, s = jb.stream;
+    const size_t L = dm_l(m, s), R = (size_t)s * rs.max_pts;
+    for (int p = tid; p < jb.npts; p += DM_THREADS) {
+        const int mp = rs.mp[jb.src_buf][R + p];
+        if (mp < 0) continue;
+        double *X = rs.xyz[jb.src_buf] + 3 * (R + p);
+        X[0] = m.lm_pos[(L + mp) * 3]; X[1] = m.lm_pos[(L + mp) * 3 + 1]; X[2] = m.lm_pos[(L + mp) * 3 + 2];
+    }
+}
+
 // ---------------------------------------------------------------- the keyframe's features -> the list the next frame tracks from
 __global__ void __launch_bounds__(DM_THREADS)
 k_dmap_refresh(DmJob *jobs, DMap m, RtStore rs)

@@ -1507,17 +1507,30 @@ int svslam_dmap_keyframe_batch(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, 
     if (p->num_features < 1 || p->num_features > c->lim.max_corners) return fail(c, "dmap: num_features %d out of [1,%d]", p->num_features, c->lim.max_corners);
     if (p->num_active_keyframes + 1 > m.KW) return fail(c, "dmap: window of %d keyframes needs max_kf >= %d", p->num_active_keyframes, p->num_active_keyframes + 1);
     std::vector<int> slots; std::vector<const void *> imgs; std::vector<int> strd;
+    // is_init == 2: no keyframe — ONE local BA over the stream's window as it is (Backend::UpdateMap from outside the
+    // frontend, include/StereoVisionSLAM/backend.h:30).  A call holds keyframe jobs or such jobs, not both.
+    int n_opt = 0;
+    for (int i = 0; i < njobs; ++i) n_opt += jobs[i].is_init == 2 ? 1 : 0;
+    if (n_opt != 0 && n_opt != njobs) return fail(c, "dmap: optimise-only jobs (is_init 2) cannot share a call with keyframe jobs");
+    const bool opt_only = n_opt == njobs;
     for (int i = 0; i < njobs; ++i) {
         svslam_dmap_job &j = jobs[i];
         if (j.stream < 0 || j.stream >= c->lim.max_streams) return fail(c, "dmap: job %d stream %d out of range", i, j.stream);
+        if (opt_only) {
+            if (j.npts != c->rt_count[(size_t)j.stream]) return fail(c, "dmap: job %d says %d features, stream %d holds %d", i, j.npts, j.stream, c->rt_count[(size_t)j.stream]);
+            continue;
+        }
         if (check_slot(c, j.slot_cur) || check_slot(c, j.slot_right)) return -1;
         if (j.kf_slot < 0 || j.kf_slot >= m.KW || j.remove_slot >= m.KW) return fail(c, "dmap: job %d keyframe slot out of range", i);
         if (j.is_init ? j.npts != 0 : j.npts != c->rt_count[(size_t)j.stream])
             return fail(c, "dmap: job %d says %d features, stream %d holds %d", i, j.npts, j.stream, c->rt_count[(size_t)j.stream]);
         if (j.is_init) { slots.push_back(j.slot_cur); imgs.push_back(left_imgs[i]); strd.push_back(strides[i]); }
     }
-    for (int i = 0; i < njobs; ++i) { slots.push_back(jobs[i].slot_right); imgs.push_back(right_imgs[i]); strd.push_back(strides[i]); }
-    {
+    for (int i = 0; i < njobs && !opt_only; ++i) { slots.push_back(jobs[i].slot_right); imgs.push_back(right_imgs[i]); strd.push_back(strides[i]); }
+    if (opt_only) {
+        if (arena_busy(c)) return -1;
+        c->ar.reset();
+    } else {
         const bool dec = c->src_w > 0;
         if (pyramid_common(c, (int)slots.size(), slots.data(), imgs.data(), strd.data(), src_is_device, dec, dec ? c->src_w : c->geom.w[0],
                            dec ? c->src_h : c->geom.h[0], false)) return -1;
@@ -1556,6 +1569,11 @@ int svslam_dmap_keyframe_batch(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, 
         hj[i].src_buf = c->rt_which[(size_t)hj[i].stream];
         hj[i].dst_buf = c->rt_which[(size_t)hj[i].stream];      // the survivors have been copied into the keyframe by then
         hj[i].stamp = c->dm_stamp;
+        if (opt_only) {          // what k_dmap_begin would have initialised
+            hj[i].ok = 1; hj[i].dead = 0; hj[i].flags = 0; hj[i].n_features = hj[i].npts; hj[i].n_corners = hj[i].n_right_ok = hj[i].n_tri_in = hj[i].n_tri_ok = 0;
+            hj[i].ba_nkf = hj[i].ba_nlm = hj[i].ba_nobs = hj[i].ba_iters = hj[i].ba_npair = hj[i].ba_ntrial = 0; hj[i].ev_ofs = hj[i].ev_n = 0;
+            hj[i].kf_slot = -1; hj[i].remove_slot = -1; hj[i].pad0 = 0;
+        }
         gj[i].slot = hj[i].slot_cur; gj[i].nrect = hj[i].npts;
         gj[i].rect_ofs = (int)(((size_t)hj[i].stream * m.KW + hj[i].kf_slot) * NF);
     }
@@ -1572,6 +1590,7 @@ int svslam_dmap_keyframe_batch(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, 
     if (h2d(c, base, in_end)) return -1;
     HIPCHK(c, hipMemsetAsync(dp<void>(c, oflag), 0, sizeof(int) * 4, c->stream));
     DmJob *dj = dp<DmJob>(c, ojobs);
+    if (!opt_only) {
     hipLaunchKernelGGL(k_dmap_begin, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, c->rt, dp<DmEvicted>(c, oev), dp<int>(c, oflag) + 1, ev_cap);
     if (launch_gftt(c, njobs, dp<GfttJob>(c, ogj), m.f_xy, MC, 0.01, 20.0, dp<float2>(c, ocor), dp<int>(c, oncor))) return -1;   // src/frontend.cpp:24
     hipLaunchKernelGGL(k_dmap_stereo_prep, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, prm, dp<float2>(c, ocor), dp<int>(c, oncor), MC,
@@ -1589,6 +1608,7 @@ int svslam_dmap_keyframe_batch(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, 
                        dp<double>(c, oxyz), dp<uint8_t>(c, ook));
     tm_end(c);
     hipLaunchKernelGGL(k_dmap_commit, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, dp<double>(c, oxyz), dp<uint8_t>(c, ook), dp<int>(c, otidx), dp<int>(c, oslot));
+    }
     // Backend::UpdateMap (src/backend.cpp:14-18) only runs with a backend: a paused / absent one (ba_iters <= 0) means no
     // Optimize, so no outlier classification and no observation removed either — like the host-map path
     if (p->ba_iters > 0) {
@@ -1602,7 +1622,8 @@ int svslam_dmap_keyframe_batch(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, 
                            dp<double>(c, ochi), dp<int>(c, oref), dp<int>(c, olms), MK);
         tm_end(c);
     }
-    hipLaunchKernelGGL(k_dmap_refresh, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, c->rt);
+    if (opt_only) hipLaunchKernelGGL(k_dmap_refresh_xyz, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, c->rt);
+    else hipLaunchKernelGGL(k_dmap_refresh, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, c->rt);
     HIPCHK(c, hipGetLastError());
     if (d2h_sync(c, ojobs, ojobs + sizeof(DmJob) * n)) return -1;
     if (d2h_sync(c, oflag, oflag + sizeof(int) * 4)) return -1;
@@ -1613,7 +1634,7 @@ int svslam_dmap_keyframe_batch(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, 
         c->evicted.assign(hp<DmEvicted>(c, oev), hp<DmEvicted>(c, oev) + nev);
     }
     memcpy(jobs, hj, sizeof(DmJob) * n);
-    for (int i = 0; i < njobs; ++i) c->rt_count[(size_t)jobs[i].stream] = jobs[i].n_features;
+    for (int i = 0; i < njobs && !opt_only; ++i) c->rt_count[(size_t)jobs[i].stream] = jobs[i].n_features;
     for (int i = 0; i < njobs; ++i)
         if (jobs[i].ba_iters < 0) return fail(c, "dmap: job %d: a workgroup of the low-latency BA solver never arrived (GPU oversubscribed?)", i);
     return 0;

@@ -64,7 +64,10 @@ def init(backend="nccl"):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    # A lone process needs no process group.  Under torch.distributed.run (what the driver launches N > 1 with, and what
+    # tools/scale.sh launches at any N) the group is formed even for one rank, so that the RCCL path — communicator,
+    # barrier, all-reduce on the device — runs on every box, not only where several GPUs are visible.
+    if world <= 1 and "TORCHELASTIC_RUN_ID" not in os.environ:
         return Rank(0, local_rank, 1)
     import torch
     import torch.distributed as dist

@@ -9,6 +9,7 @@ namespace svs {
 
 class HipKernels {
 public:
+    static constexpr bool kHasDeviceMap = true;       // svslam_dmap_*: the map of every stream can live in device memory
     explicit HipKernels(const svslam_limits &lim)
     {
         int rc = svslam_create(&lim, &ctx_);

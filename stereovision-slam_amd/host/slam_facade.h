@@ -249,9 +249,16 @@ struct FrontendOptions {            // the hyper-parameters Frontend::Frontend()
     int num_active_keyframes = 10;
     double chi2_th = 5.991;
     int device = 0;
+    // 1 (default): the stream's map — window, keyframe features, landmarks, observation counts — lives in device memory
+    // and a keyframe is ONE chain of kernels (svslam_dmap_keyframe_batch), the configuration every throughput figure of
+    // this library uses; 0: the host keeps it (rounds 1-2).  Same results bit for bit (tests/test_facade_kitti.py).
+    // Not a key of the reference's config files: `device_map: 0` in the YAML (or this field) selects the host map.
+    // A kernel provider without a device map (the CPU twin of the tests) ignores it.
+    int device_map = 1;
     static FrontendOptions FromConfig(const ConfigFile &c)
     {
         FrontendOptions o;
+        o.device_map = (int)c.Num("device_map", o.device_map);
         o.num_features = (int)c.Num("num_features", o.num_features);
         o.num_features_init = (int)c.Num("num_features_init", o.num_features_init);
         o.num_features_tracking = (int)c.Num("num_features_tracking", o.num_features_tracking);
@@ -264,6 +271,10 @@ struct FrontendOptions {            // the hyper-parameters Frontend::Frontend()
         return o;
     }
 };
+
+// does the kernel provider offer a device-resident map (HipKernels::kHasDeviceMap)?  The CPU twin's provider does not.
+template <class K> constexpr auto provider_has_device_map(int) -> decltype(K::kHasDeviceMap) { return K::kHasDeviceMap; }
+template <class K> constexpr bool provider_has_device_map(long) { return false; }
 
 template <class K>
 class FrontendT {
@@ -328,14 +339,17 @@ private:
         cfg.num_active_keyframes = opt_.num_active_keyframes; cfg.chi2_th = opt_.chi2_th;
         cfg.backend_on = 1;                        // gated by SetBackendEnabled: see SetBackend
         cfg.width = dw; cfg.height = dh; cfg.src_width = w; cfg.src_height = h;
-        cfg.resident_track = 0;                    // one stream: the host keeps the feature lists (Backend::UpdateMap from outside)
+        const bool dmap = opt_.device_map != 0 && provider_has_device_map<K>(0) && cfg.num_active_keyframes + 1 <= 12;
+        cfg.resident_track = dmap ? 1 : 0;         // host map: the host keeps the feature lists; device map: nothing per feature on the host
+        cfg.device_map = dmap ? 1 : 0;
         cfg.cam_l = *camera_left_; cfg.cam_r = *camera_right_;
         cfg.max_pts = 512; cfg.max_kf = cfg.num_active_keyframes + 1; cfg.max_lm = 4096; cfg.max_obs = 16384;
         svslam_limits lim;
         std::memset(&lim, 0, sizeof(lim));
         lim.device = opt_.device; lim.width = dw; lim.height = dh; lim.max_slots = 3; lim.max_jobs = 2;
         lim.max_pts = cfg.max_pts; lim.max_corners = cfg.num_features;
-        lim.max_kf = cfg.max_kf; lim.max_lm = cfg.max_lm; lim.max_obs = cfg.max_obs; lim.max_streams = 0;
+        lim.max_kf = cfg.max_kf; lim.max_lm = cfg.max_lm; lim.max_obs = cfg.max_obs;
+        lim.max_streams = dmap ? 1 : 0; lim.device_map = dmap ? 1 : 0;
         kernels_.reset(new K(lim));
         if (kernels_->set_source_size(w, h) != 0) throw SLAMException(std::string("source size: ") + kernels_->last_error());
         pipe_.reset(new Pipeline<K>(cfg, *kernels_, 1, 1));
@@ -370,8 +384,7 @@ private:
         map_->landmarks_fn = [this]() {
             std::vector<LandmarkView> o;
             if (!pipe_) return o;
-            auto &m = pipe_->stream(0).map;
-            for (const svs::LandmarkRecord &p : m.AllLandmarks())
+            for (const svs::LandmarkRecord &p : pipe_->AllLandmarks(0))
                 o.push_back(LandmarkView{ (unsigned long)p.id, { p.pos[0], p.pos[1], p.pos[2] }, p.observed_times, p.active });
             return o;
         };

@@ -528,19 +528,7 @@ public:
         Stream &st = *streams_[s];
         std::ofstream pcd(dir + "/landmarks.pcd");
         if (!pcd) return false;
-        std::vector<LandmarkRecord> all = st.map.AllLandmarks();
-        if (device_map()) {
-            // the map lives in the provider's memory: the archive of what it freed (above) + the landmarks it still holds,
-            // id-ascending
-            const int NL = cfg_.max_lm;
-            std::vector<int> id((size_t)NL), obs((size_t)NL);
-            std::vector<double> pos(3 * (size_t)NL);
-            std::vector<uint8_t> stt((size_t)NL);
-            check(k_.dmap_read(s, nullptr, nullptr, nullptr, nullptr, id.data(), pos.data(), obs.data(), stt.data()), "dmap_read");
-            for (int l = 0; l < NL; ++l)
-                if (id[(size_t)l] >= 0) all.push_back(LandmarkRecord{ id[(size_t)l], { pos[3 * (size_t)l], pos[3 * (size_t)l + 1], pos[3 * (size_t)l + 2] }, obs[(size_t)l], stt[(size_t)l] == 1 });
-            std::sort(all.begin(), all.end(), [](const LandmarkRecord &a, const LandmarkRecord &b) { return a.id < b.id; });
-        }
+        std::vector<LandmarkRecord> all = AllLandmarks(s);
         const size_t n = all.size();
         pcd << "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\n"
             << "COUNT 1 1 1\nWIDTH " << n << "\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS " << n << "\nDATA ascii\n";
@@ -564,6 +552,26 @@ public:
         }
         return true;
     }
+
+    // Map::landmarks_ of stream s (src/map.h:15): every landmark ever created, id-ascending — wherever the map lives
+    std::vector<LandmarkRecord> AllLandmarks(int s)
+    {
+        Stream &st = *streams_[s];
+        std::vector<LandmarkRecord> all = st.map.AllLandmarks();
+        if (device_map()) {
+            // the map lives in the provider's memory: the archive of what it freed (above) + the landmarks it still holds
+            const int NL = cfg_.max_lm;
+            std::vector<int> id((size_t)NL), obs((size_t)NL);
+            std::vector<double> pos(3 * (size_t)NL);
+            std::vector<uint8_t> stt((size_t)NL);
+            check(k_.dmap_read(s, nullptr, nullptr, nullptr, nullptr, id.data(), pos.data(), obs.data(), stt.data()), "dmap_read");
+            for (int l = 0; l < NL; ++l)
+                if (id[(size_t)l] >= 0) all.push_back(LandmarkRecord{ id[(size_t)l], { pos[3 * (size_t)l], pos[3 * (size_t)l + 1], pos[3 * (size_t)l + 2] }, obs[(size_t)l], stt[(size_t)l] == 1 });
+            std::sort(all.begin(), all.end(), [](const LandmarkRecord &a, const LandmarkRecord &b) { return a.id < b.id; });
+        }
+        return all;
+    }
+    bool MapOnDevice() const { return device_map(); }
 
 private:
     void check(int rc, const char *what)
@@ -1311,6 +1319,7 @@ public:
     // BA over every stream's active window, now.  Needs the host-side feature lists (resident_track = 0).
     void OptimizeNow()
     {
+        if (device_map()) { OptimizeNowOnDevice(); return; }
         if (resident()) throw std::runtime_error("OptimizeNow: the feature lists live on the device (resident_track)");
         BackendCollect();
         std::vector<int> MS;
@@ -1318,6 +1327,45 @@ public:
         if (MS.empty()) return;
         BackendSubmit(MS);
         BackendCollect();
+    }
+    // ... with the map in the provider's memory: one optimise-only job per stream (svslam_dmap_job::is_init == 2), the
+    // window's poses come back like after a keyframe
+    void OptimizeNowOnDevice()
+    {
+        if (!backend_enabled_) return;
+        std::vector<int> MS;
+        for (int s = 0; s < nstreams(); ++s) if (!streams_[s]->map.active_keyframes_.empty()) MS.push_back(s);
+        const int n = (int)MS.size();
+        if (n == 0) return;
+        jobs_dm_.assign((size_t)n, svslam_dmap_job());
+        dm_left_.assign((size_t)n, nullptr); dm_right_.assign((size_t)n, nullptr); strides_.assign((size_t)n, cfg_.width);
+        for (int i = 0; i < n; ++i) {
+            svslam_dmap_job &j = jobs_dm_[i];
+            std::memset(&j, 0, sizeof(j));
+            j.stream = MS[i]; j.is_init = 2; j.npts = streams_[MS[i]]->dev_feat; j.kf_slot = -1; j.remove_slot = -1;
+        }
+        svslam_dmap_params prm;
+        prm.num_features = cfg_.num_features; prm.num_features_init = cfg_.num_features_init;
+        prm.num_active_keyframes = cfg_.num_active_keyframes; prm.ba_iters = 10;
+        prm.max_triangulation_depth = cfg_.max_triangulation_depth; prm.chi2_th = cfg_.chi2_th;
+        for (int c0 = 0; c0 < n; c0 += dm_chunk_) {
+            const int m = std::min(dm_chunk_, n - c0);
+            KTimer kt_(cnt_);
+            check(k_.dmap_keyframe(m, jobs_dm_.data() + c0, dm_left_.data() + c0, dm_right_.data() + c0, strides_.data() + c0, 1,
+                                   cam_l_, cfg_.cam_l.pose.v, cam_r_, cfg_.cam_r.pose.v, &prm), "dmap_keyframe (optimise only)");
+        }
+        for (int i = 0; i < n; ++i) {
+            Stream &st = *streams_[MS[i]];
+            const svslam_dmap_job &j = jobs_dm_[i];
+            if (j.flags & 4) { cnt_.ba_skipped++; continue; }
+            cnt_.ba_calls++; cnt_.ba_edges += j.ba_nobs; cnt_.ba_kf += j.ba_nkf; cnt_.ba_lm += j.ba_nlm; cnt_.ba_iters += j.ba_iters;
+            cnt_.ba_pairs += j.ba_npair; cnt_.ba_trials += j.ba_ntrial;
+            for (int a = 0; a < j.ba_nkf; ++a)
+                for (Frame *kf : st.map.active_keyframes_)
+                    if (kf->dslot == j.win_slot[a]) { kf->pose = SE3(j.win_pose[a]); break; }
+            for (Frame *kf : st.map.active_keyframes_)
+                if (kf->keyframe_id != 0 && kf->prev_keyframe) kf->relative_pose_pkf = kf->pose * kf->prev_keyframe->pose.inverse();
+        }
     }
     // the hooks the reference fires at the end of InsertKeyframe / StereoInit (src/frontend.cpp:618-640,
     // 236-246): backend_->UpdateMap() is the pipeline's own BA; loop closure and viewer are callbacks

@@ -32,12 +32,14 @@ int main(int argc, char **argv)
     vo.frontend()->SetLoopClosure([&](const Frame::Ptr &f) { ++n_kf_hook; CHECK_VOID(f->is_keyframe_); });
     vo.frontend()->SetViewer([&](const Frame::Ptr &) { ++n_view_hook; });
     CHECK(vo.GetFrontendStatus() == FrontendStatus::INITING);
+    bool said_map = false;
     int n = 0, nkf = 0;
     const int pause_from = 8, pause_to = 12;
     while (true) {
         if (n == pause_from && vo.backend()) { vo.backend()->PauseRequest(); CHECK(vo.backend()->IsPaused()); }
         if (n == pause_to && vo.backend()) { vo.backend()->Resume(); CHECK(!vo.backend()->IsPaused()); }
         if (!vo.step()) break;
+        if (!said_map) { std::printf("map: %s\n", vo.frontend()->pipeline()->MapOnDevice() ? "device" : "host"); said_map = true; }
         Frame::Ptr f = vo.frontend()->GetLastFrame();
         CHECK(f && f->id_ == (unsigned long)n);
         nkf += f->is_keyframe_ ? 1 : 0;
