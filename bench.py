@@ -234,7 +234,7 @@ def main():
         # ~27 us of host CPU per frame; keep its memory footprint in proportion
         # (only with the map on the host: the device-resident map costs the host < 1 core per 12 288 streams)
         lw = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-        if args.host_map or args.backend_mode != 1:
+        if args.host_map:
             S = min(S, 1024 * max(1, effective_cpus() // max(1, lw)))
     if S > cap:
         S = max(512, cap // 512 * 512) if cap >= 512 else max(1, cap)
@@ -245,7 +245,7 @@ def main():
     cores = max(1, effective_cpus() // max(1, local_world))
     pinned = set() if args.no_pin else sdist.pin_to_device_numa(local_rank, min_cpus=cores)
     # (about 1024 streams per group: 8 groups up to 8192 streams, 12 beyond; tools/sweep.sh)
-    dev_map = not (args.host_map or args.backend_mode != 1)
+    dev_map = not args.host_map       # (round 4: also with the backend beside the frontend, --backend-mode 2)
     # with the map on the device a group's thread only enqueues and waits: the group count follows the GPU (kernels
     # of different groups overlap), not the cores, and one bookkeeping thread per group is plenty
     # (measured, tools/sweep_devmap.sh: 4 / 6 / 8 / 12 / 16 groups at 12 288 streams = 483 / 487 / 500 / 495 / 480 k frames/s,
@@ -259,11 +259,12 @@ def main():
     cfg = pl.default_config(W, H, host_threads=max(1, args.host_threads), backend_on=args.backend_mode,
                             src_width=SW if args.full_res else 0, src_height=SH if args.full_res else 0,
                             low_latency=1 if args.low_latency else 0,
-                            device_map=0 if (args.host_map or args.backend_mode != 1) else 1, backend_lag=max(1, args.backend_lag))
+                            device_map=0 if args.host_map else 1, backend_lag=max(1, args.backend_lag))
     pipes = [pl.Pipeline(cfg, nstreams=Sg, device=local_rank) for _ in range(G)]
     ctxs = [svs.Context.borrow(p.kernel_ctx(), W, H) for p in pipes]   # alloc / timing through the pipelines' contexts
     ctx = ctxs[0]
-    if args.backend_mode == 2:       # the backend's own contexts (second HIP stream per pipeline)
+    sep_backend = args.backend_mode == 2 and not dev_map      # host map: the backend has its own context (second HIP stream) per pipeline
+    if sep_backend:
         ctxs = ctxs + [svs.Context.borrow(p.backend_ctx(), W, H) for p in pipes]
 
     img = SW * SH
@@ -459,7 +460,7 @@ def main():
         render_block(frame_pos)
         cs0 = pipes[0].counters()
         ctxs[0].timing(True)
-        if args.backend_mode == 2:
+        if sep_backend:
             ctxs[G].timing(True)
         run_all(0, Ks, False, groups=[0])
         if torch.cuda.is_available():
@@ -467,7 +468,7 @@ def main():
         cs1 = pipes[0].counters()
         cnt_s = {k: cs1[k] - cs0[k] for k in cs1}
         for f in svs.FAMILIES:
-            parts = [ctxs[0].timing_get(f)] + ([ctxs[G].timing_get(f)] if args.backend_mode == 2 else [])
+            parts = [ctxs[0].timing_get(f)] + ([ctxs[G].timing_get(f)] if sep_backend else [])
             fms, fl = sum(p[0] for p in parts), sum(p[1] for p in parts)
             fb_ = algorithmic_bytes(f, cnt_s, fl)
             if fl and fms > 0:
@@ -527,8 +528,8 @@ def main():
                                    "(GFTT + pyramidal LK + triangulation + pose-only LM) with HIP local BA per "
                                    "keyframe (%s), config-00.yaml hyper-parameters (150 features, 10 active "
                                    "keyframes)" % ("completes before the next frame" if args.backend_mode == 1 else
-                                                   "runs beside the next frame like the reference's backend thread, "
-                                                   "lands one frame late, all of it inside the timed region"),
+                                                   "runs beside the next frames like the reference's backend thread, "
+                                                   "lands %d frame(s) late, all of it inside the timed region" % max(1, args.backend_lag)),
                        **({"timed_blocks": "%d blocks of <= %d steps, each between barrier + synchronize; the next block's frames are "
                                            "rendered into the HBM ring in between, outside the timing" % (len(blocks), FB)} if len(blocks) > 1 else {}),
                        "map": "host (Frontend/Map/Backend bookkeeping on the CPU)" if cfg.device_map == 0 else

@@ -356,7 +356,17 @@ typedef struct svslam_dmap_job {
 typedef struct svslam_dmap_params {
     int    num_features, num_features_init, num_active_keyframes, ba_iters;
     double max_triangulation_depth, chi2_th;
+    int    ba_defer;       /* 1: the local BA of this call runs BESIDE what follows, on a second stream of the context (the
+                              reference's backend thread, src/backend.cpp:250-287): the call returns once the keyframe is in
+                              the map and its problem gathered; svslam_dmap_ba_collect applies the result — window poses,
+                              landmark positions, outlier observations — later.  One deferred batch at a time. */
+    int    reserved;
 } svslam_dmap_params;
+/* Applies the local BA a svslam_dmap_keyframe_batch call with ba_defer = 1 left running: waits for it, writes poses /
+ * positions back into the device map, removes the outlier observations (src/backend.cpp:167-246) and refreshes the positions
+ * in every job's resident feature list.  jobs_out (njobs as in that call, same order) receives the jobs with their BA
+ * outputs (ba_*, win_pose / win_slot, pose).  Returns 0 and touches nothing when no batch is in flight (*njobs_inflight = 0). */
+int svslam_dmap_ba_collect(svslam_ctx *ctx, int njobs, svslam_dmap_job *jobs_out, int *njobs_inflight);
 
 int svslam_dmap_keyframe_batch(svslam_ctx *ctx, int njobs, svslam_dmap_job *jobs,
                                const void *const *left_imgs, const void *const *right_imgs, const int *strides,

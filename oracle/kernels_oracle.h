@@ -156,6 +156,7 @@ public:
                       const double *, const double *, const double *, const svslam_dmap_params *)
     { err_ = "the CPU twin keeps its map on the host (device_map = 0)"; return -1; }
     int dmap_evicted(const svslam_dmap_evicted_rec **, int *) { err_ = "no device map in the CPU twin"; return -1; }
+    int dmap_ba_collect(int, svslam_dmap_job *, int *) { err_ = "no device map in the CPU twin"; return -1; }
     int dmap_read(int, long long *, int *, double *, int *, int *, double *, int *, uint8_t *) { err_ = "no device map in the CPU twin"; return -1; }
     int rtrack_upload(int n, const int *streams, const int *ofs, const int *counts, const float *xy, const int *mp,
                       const double *xyz)

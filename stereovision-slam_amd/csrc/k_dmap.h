@@ -517,16 +517,16 @@ k_dmap_ba_scatter(DmJob *jobs, DMap m, DmParams prm, const BaDev *badev, const d
 // ---------------------------------------------------------------- after a local BA that ran outside a keyframe step
 // (Backend::UpdateMap called from outside the frontend, include/StereoVisionSLAM/backend.h:30): the resident list of the
 // frame being tracked keeps its features, only the positions of the landmarks they name are the optimised ones
+// list3: per job { stream, buffer of the resident list, features in it } as they are NOW (a deferred BA lands frames later)
 __global__ void __launch_bounds__(DM_THREADS)
-k_dmap_refresh_xyz(DmJob *jobs, DMap m, RtStore rs)
+k_dmap_refresh_xyz(const int *list3, DMap m, RtStore rs)
 {
-    const DmJob &jb = jobs[blockIdx.x];
-    const int tid = threadIdx.x, s = jb.stream;
+    const int tid = threadIdx.x, s = list3[3 * blockIdx.x], buf = list3[3 * blockIdx.x + 1], npts = list3[3 * blockIdx.x + 2];
     const size_t L = dm_l(m, s), R = (size_t)s * rs.max_pts;
-    for (int p = tid; p < jb.npts; p += DM_THREADS) {
-        const int mp = rs.mp[jb.src_buf][R + p];
+    for (int p = tid; p < npts; p += DM_THREADS) {
+        const int mp = rs.mp[buf][R + p];
         if (mp < 0) continue;
-        double *X = rs.xyz[jb.src_buf] + 3 * (R + p);
+        double *X = rs.xyz[buf] + 3 * (R + p);
         X[0] = m.lm_pos[(L + mp) * 3]; X[1] = m.lm_pos[(L + mp) * 3 + 1]; X[2] = m.lm_pos[(L + mp) * 3 + 2];
     }
 }

@@ -104,6 +104,11 @@ struct svslam_ctx {
     DMap dm = {};                 // device-resident maps (limits.device_map)
     void *dm_all = nullptr;
     int dm_stamp = 0;
+    // a deferred local BA of the device map (svslam_dmap_params::ba_defer): its problem, solver scratch and a copy of the jobs
+    // live in a buffer of their own (the staging arena is recycled by every call), the solve runs on a second stream
+    struct { unsigned char *buf = nullptr; size_t cap = 0; bool inflight = false; int njobs = 0; hipStream_t stream = nullptr;
+             hipEvent_t gathered = nullptr, solved = nullptr, t0 = nullptr, t1 = nullptr;
+             size_t ojobs = 0, obd = 0, oposes = 0, opts = 0, ochi = 0, oref = 0, olms = 0, oflag = 0; DmParams prm; int MK = 0; } dmba;
     hipEvent_t done = nullptr;   // recorded after the last enqueue of a call; the stream may be shared
     // a submitted, not yet collected local-BA batch owns the staging arena
     struct { bool active = false; int njobs = 0, total_kf = 0, total_lm = 0, total_obs = 0;
@@ -606,6 +611,10 @@ void svslam_destroy(svslam_ctx *c)
     for (int b = 0; b < 2; ++b) { (void)hipFree(c->rt.xy[b]); (void)hipFree(c->rt.mp[b]); (void)hipFree(c->rt.xyz[b]); }
     (void)hipFree(c->d_pyr);
     if (c->dm_all) (void)hipFree(c->dm_all);
+    if (c->dmba.stream) (void)hipStreamSynchronize(c->dmba.stream);
+    if (c->dmba.buf) (void)hipFree(c->dmba.buf);
+    for (hipEvent_t e : { c->dmba.gathered, c->dmba.solved, c->dmba.t0, c->dmba.t1 }) if (e) (void)hipEventDestroy(e);
+    if (c->dmba.stream) (void)hipStreamDestroy(c->dmba.stream);
     (void)hipFree(c->ar.d);
     if (c->ar.h) (void)hipHostFree(c->ar.h);
     (void)hipFree(c->d_img);
@@ -1552,10 +1561,33 @@ int svslam_dmap_keyframe_batch(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, 
     size_t ostat = c->ar.take(P), oerr = c->ar.take(sizeof(float) * P);
     size_t otj = c->ar.take(sizeof(TriJob) * n), oul = c->ar.take(sizeof(float2) * P), our_ = c->ar.take(sizeof(float2) * P);
     size_t otidx = c->ar.take(sizeof(int) * P), oxyz = c->ar.take(sizeof(double) * 3 * P), ook = c->ar.take(P), oslot = c->ar.take(sizeof(int) * P);
-    size_t obd = c->ar.take(sizeof(BaDev) * n), oposes = c->ar.take(sizeof(double) * 7 * MK * n), opts = c->ar.take(sizeof(double) * 3 * NL * n);
-    size_t opk = c->ar.take(sizeof(unsigned int) * E), ouv = c->ar.take(sizeof(float2) * E), oref = c->ar.take(sizeof(int) * E);
-    size_t olms = c->ar.take(sizeof(int) * NL * n), ochi = c->ar.take(sizeof(double) * E), oflag = c->ar.take(sizeof(int) * 4);
-    size_t orecs = c->ar.take(sizeof(BaRec) * 2 * E), oaux = c->ar.take(sizeof(int) * aux_stride * n);
+    // the local-BA problem and the solver's scratch: in the arena, or — deferred — in the buffer that outlives this call
+    const bool defer = p->ba_defer != 0 && p->ba_iters > 0 && !opt_only;
+    if (c->dmba.inflight) return fail(c, "dmap: a deferred local BA is in flight: call svslam_dmap_ba_collect first");
+    Arena bar;                                    // offsets only (take()): base pointer chosen below
+    bar.cap = ~(size_t)0;
+    Arena &A = defer ? bar : c->ar;
+    size_t obd = A.take(sizeof(BaDev) * n), oposes = A.take(sizeof(double) * 7 * MK * n), opts = A.take(sizeof(double) * 3 * NL * n);
+    size_t opk = A.take(sizeof(unsigned int) * E), ouv = A.take(sizeof(float2) * E), oref = A.take(sizeof(int) * E);
+    size_t olms = A.take(sizeof(int) * NL * n), ochi = A.take(sizeof(double) * E), oflag = A.take(sizeof(int) * 4);
+    size_t orecs = A.take(sizeof(BaRec) * 2 * E), oaux = A.take(sizeof(int) * aux_stride * n);
+    size_t obcams = 0, objobs = 0;
+    if (defer) {
+        obcams = A.take(sizeof(BaCams)); objobs = A.take(sizeof(DmJob) * n);
+        if (!c->dmba.stream) {
+            HIPCHK(c, hipStreamCreateWithFlags(&c->dmba.stream, hipStreamNonBlocking));
+            for (hipEvent_t *e : { &c->dmba.gathered, &c->dmba.solved }) HIPCHK(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
+            for (hipEvent_t *e : { &c->dmba.t0, &c->dmba.t1 }) HIPCHK(c, hipEventCreate(e));
+        }
+        if (A.off > c->dmba.cap) {
+            if (c->dmba.buf) { HIPCHK(c, hipStreamSynchronize(c->dmba.stream)); (void)hipFree(c->dmba.buf); c->dmba.buf = nullptr; c->dmba.cap = 0; }
+            const size_t want = A.off + A.off / 4;
+            HIPCHK(c, hipMalloc(&c->dmba.buf, want));
+            c->dmba.cap = want;
+        }
+    }
+    unsigned char *bab = defer ? c->dmba.buf : c->ar.d;          // base of the BA buffers
+    auto bp_ = [&](size_t off) { return bab + off; };
     // (test hook SVSLAM_DMAP_EVICT_CAP: a smaller list for the whole call, to exercise the "waits for the next keyframe" path)
     static const int ev_cap_env = []{ const char *e = std::getenv("SVSLAM_DMAP_EVICT_CAP"); return e ? atoi(e) : 0; }();
     const int ev_cap = ev_cap_env > 0 ? std::min(ev_cap_env, njobs * SVSLAM_DMAP_EVICT_PER_JOB) : njobs * SVSLAM_DMAP_EVICT_PER_JOB;
@@ -1588,10 +1620,16 @@ int svslam_dmap_keyframe_batch(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, 
     TriCams tc;
     memcpy(tc.cam_l, cam_l, 32); memcpy(tc.ext_l, ext_l, 56); memcpy(tc.cam_r, cam_r, 32); memcpy(tc.ext_r, ext_r, 56);
     if (h2d(c, base, in_end)) return -1;
-    HIPCHK(c, hipMemsetAsync(dp<void>(c, oflag), 0, sizeof(int) * 4, c->stream));
+    // flag words: [0] BA structure build overflow, [1] evicted-list cursor.  Deferred: the build's word lives with the problem,
+    // the cursor of this call's evicted list stays in the arena
+    size_t oevc = oflag;
+    if (defer) { oevc = c->ar.take(sizeof(int) * 4); if (c->ar.off > c->ar.cap) return fail(c, "dmap: staging arena too small"); }
+    HIPCHK(c, hipMemsetAsync(bp_(oflag), 0, sizeof(int) * 4, c->stream));
+    if (defer) HIPCHK(c, hipMemsetAsync(dp<void>(c, oevc), 0, sizeof(int) * 4, c->stream));
+    int *d_evcur = defer ? dp<int>(c, oevc) + 1 : reinterpret_cast<int *>(bp_(oflag)) + 1;
     DmJob *dj = dp<DmJob>(c, ojobs);
     if (!opt_only) {
-    hipLaunchKernelGGL(k_dmap_begin, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, c->rt, dp<DmEvicted>(c, oev), dp<int>(c, oflag) + 1, ev_cap);
+    hipLaunchKernelGGL(k_dmap_begin, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, c->rt, dp<DmEvicted>(c, oev), d_evcur, ev_cap);
     if (launch_gftt(c, njobs, dp<GfttJob>(c, ogj), m.f_xy, MC, 0.01, 20.0, dp<float2>(c, ocor), dp<int>(c, oncor))) return -1;   // src/frontend.cpp:24
     hipLaunchKernelGGL(k_dmap_stereo_prep, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, prm, dp<float2>(c, ocor), dp<int>(c, oncor), MC,
                        dp<LkJob>(c, olk), dp<float2>(c, oprev), dp<float2>(c, onext));
@@ -1612,23 +1650,54 @@ int svslam_dmap_keyframe_batch(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, 
     // Backend::UpdateMap (src/backend.cpp:14-18) only runs with a backend: a paused / absent one (ba_iters <= 0) means no
     // Optimize, so no outlier classification and no observation removed either — like the host-map path
     if (p->ba_iters > 0) {
-        tm_begin(c, FAM_BA, njobs);
-        hipLaunchKernelGGL(k_dmap_ba_gather, dim3(njobs), dim3(DMG_THREADS), dmg_lds_bytes(NL), c->stream, dj, m, prm, dp<BaDev>(c, obd), dp<double>(c, oposes),
-                           dp<double>(c, opts), dp<unsigned int>(c, opk), dp<float2>(c, ouv), dp<int>(c, oref), dp<int>(c, olms), MK, tile_cap, aux_stride);
-        launch_ba_solver(c, njobs, use_ll, dp<BaDev>(c, obd), dp<BaCams>(c, ocams), dp<double>(c, oposes), dp<double>(c, opts), dp<unsigned int>(c, opk),
-                         dp<float2>(c, ouv), dp<int>(c, oref) /* order: identity, not read */, dp<BaRec>(c, orecs), dp<int>(c, oaux), dp<double>(c, ochi),
-                         dp<int>(c, oflag), NL, MO, p->chi2_th, p->ba_iters, false);
-        hipLaunchKernelGGL(k_dmap_ba_scatter, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, prm, dp<BaDev>(c, obd), dp<double>(c, oposes), dp<double>(c, opts),
-                           dp<double>(c, ochi), dp<int>(c, oref), dp<int>(c, olms), MK);
-        tm_end(c);
+        BaDev *b_bd = reinterpret_cast<BaDev *>(bp_(obd));
+        double *b_poses = reinterpret_cast<double *>(bp_(oposes)), *b_pts = reinterpret_cast<double *>(bp_(opts)), *b_chi = reinterpret_cast<double *>(bp_(ochi));
+        int *b_ref = reinterpret_cast<int *>(bp_(oref)), *b_lms = reinterpret_cast<int *>(bp_(olms));
+        const BaCams *b_cams = defer ? reinterpret_cast<const BaCams *>(bp_(obcams)) : dp<BaCams>(c, ocams);
+        hipStream_t main_stream = c->stream;
+        if (!defer) tm_begin(c, FAM_BA, njobs);
+        hipLaunchKernelGGL(k_dmap_ba_gather, dim3(njobs), dim3(DMG_THREADS), dmg_lds_bytes(NL), c->stream, dj, m, prm, b_bd, b_poses, b_pts,
+                           reinterpret_cast<unsigned int *>(bp_(opk)), reinterpret_cast<float2 *>(bp_(ouv)), b_ref, b_lms, MK, tile_cap, aux_stride);
+        if (defer) {
+            // the solve leaves this call's stream: a copy of the jobs (the scatter needs streams, window slots) and of the
+            // cameras goes with the problem; the second stream picks up behind the gather
+            HIPCHK(c, hipMemcpyAsync(bp_(objobs), dj, sizeof(DmJob) * n, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(bp_(obcams), dp<void>(c, ocams), sizeof(BaCams), hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipEventRecord(c->dmba.gathered, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->dmba.stream, c->dmba.gathered, 0));
+            c->stream = c->dmba.stream;                       // (launch_ba_solver enqueues on the context's stream)
+            (void)hipEventRecord(c->dmba.t0, c->stream);
+        }
+        launch_ba_solver(c, njobs, use_ll, b_bd, b_cams, b_poses, b_pts, reinterpret_cast<unsigned int *>(bp_(opk)),
+                         reinterpret_cast<float2 *>(bp_(ouv)), b_ref /* order: identity, not read */, reinterpret_cast<BaRec *>(bp_(orecs)),
+                         reinterpret_cast<int *>(bp_(oaux)), b_chi, reinterpret_cast<int *>(bp_(oflag)), NL, MO, p->chi2_th, p->ba_iters, false);
+        if (defer) {
+            (void)hipEventRecord(c->dmba.t1, c->stream);
+            const hipError_t rec_rc = hipEventRecord(c->dmba.solved, c->stream);
+            c->stream = main_stream;
+            HIPCHK(c, rec_rc);
+            c->dmba.inflight = true; c->dmba.njobs = njobs; c->dmba.ojobs = objobs; c->dmba.obd = obd; c->dmba.oposes = oposes; c->dmba.opts = opts;
+            c->dmba.ochi = ochi; c->dmba.oref = oref; c->dmba.olms = olms; c->dmba.oflag = oflag; c->dmba.prm = prm; c->dmba.MK = MK;
+        } else {
+            hipLaunchKernelGGL(k_dmap_ba_scatter, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, prm, b_bd, b_poses, b_pts, b_chi, b_ref, b_lms, MK);
+            tm_end(c);
+        }
     }
-    if (opt_only) hipLaunchKernelGGL(k_dmap_refresh_xyz, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, c->rt);
-    else hipLaunchKernelGGL(k_dmap_refresh, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, c->rt);
+    if (opt_only) {
+        size_t ol3 = c->ar.take(sizeof(int) * 3 * n);
+        if (c->ar.off > c->ar.cap) return fail(c, "dmap: staging arena too small");
+        int *l3 = hp<int>(c, ol3);
+        for (int i = 0; i < njobs; ++i) { l3[3 * i] = hj[i].stream; l3[3 * i + 1] = hj[i].src_buf; l3[3 * i + 2] = hj[i].npts; }
+        if (h2d(c, ol3, ol3 + sizeof(int) * 3 * n)) return -1;
+        hipLaunchKernelGGL(k_dmap_refresh_xyz, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dp<int>(c, ol3), m, c->rt);
+    } else hipLaunchKernelGGL(k_dmap_refresh, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, c->rt);
     HIPCHK(c, hipGetLastError());
     if (d2h_sync(c, ojobs, ojobs + sizeof(DmJob) * n)) return -1;
-    if (d2h_sync(c, oflag, oflag + sizeof(int) * 4)) return -1;
-    if (const int fl = hp<int>(c, oflag)[0]) return fail(c, "dmap: the BA structure build overflowed a capacity (code %d)", fl);
-    if (const int nev = hp<int>(c, oflag)[1]) {                // the landmarks this call freed (svslam_dmap_evicted)
+    // (deferred: the build's overflow word is read by svslam_dmap_ba_collect; word 0 of the arena copy stays 0)
+    if (d2h_sync(c, defer ? oevc : oflag, (defer ? oevc : oflag) + sizeof(int) * 4)) return -1;
+    const int *fw = hp<int>(c, defer ? oevc : oflag);
+    if (const int fl = fw[0]) return fail(c, "dmap: the BA structure build overflowed a capacity (code %d)", fl);
+    if (const int nev = fw[1]) {                // the landmarks this call freed (svslam_dmap_evicted)
         if (nev < 0 || nev > ev_cap) return fail(c, "dmap: evicted-list cursor %d out of [0,%d]", nev, ev_cap);
         if (d2h_sync(c, oev, oev + sizeof(DmEvicted) * (size_t)nev)) return -1;
         c->evicted.assign(hp<DmEvicted>(c, oev), hp<DmEvicted>(c, oev) + nev);
@@ -1637,6 +1706,53 @@ int svslam_dmap_keyframe_batch(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, 
     for (int i = 0; i < njobs && !opt_only; ++i) c->rt_count[(size_t)jobs[i].stream] = jobs[i].n_features;
     for (int i = 0; i < njobs; ++i)
         if (jobs[i].ba_iters < 0) return fail(c, "dmap: job %d: a workgroup of the low-latency BA solver never arrived (GPU oversubscribed?)", i);
+    return 0;
+}
+
+int svslam_dmap_ba_collect(svslam_ctx *c, int njobs, svslam_dmap_job *jobs_out, int *njobs_inflight)
+{
+    if (njobs_inflight) *njobs_inflight = c->dmba.inflight ? c->dmba.njobs : 0;
+    if (!c->dmba.inflight) return 0;
+    if (njobs != c->dmba.njobs || !jobs_out) return fail(c, "dmap_ba_collect: %d jobs are in flight, the caller passed %d", c->dmba.njobs, njobs);
+    if (arena_busy(c)) return -1;
+    c->dmba.inflight = false;
+    const DMap &m = c->dm;
+    unsigned char *b = c->dmba.buf;
+    const size_t n = (size_t)njobs;
+    c->ar.reset();
+    size_t ojobs = c->ar.take(sizeof(DmJob) * n), oflag = c->ar.take(sizeof(int) * 4), ol3 = c->ar.take(sizeof(int) * 3 * n);
+    if (c->ar.off > c->ar.cap) return fail(c, "dmap_ba_collect: staging arena too small");
+    // the solve is done when its event is: this stream goes on behind it
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->dmba.solved, 0));
+    DmJob *dj = reinterpret_cast<DmJob *>(b + c->dmba.ojobs);
+    tm_begin(c, FAM_BA, 0);
+    hipLaunchKernelGGL(k_dmap_ba_scatter, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, c->dmba.prm, reinterpret_cast<const BaDev *>(b + c->dmba.obd),
+                       reinterpret_cast<const double *>(b + c->dmba.oposes), reinterpret_cast<const double *>(b + c->dmba.opts),
+                       reinterpret_cast<const double *>(b + c->dmba.ochi), reinterpret_cast<const int *>(b + c->dmba.oref),
+                       reinterpret_cast<const int *>(b + c->dmba.olms), c->dmba.MK);
+    tm_end(c);
+    // the jobs come back first: the streams whose resident lists are refreshed are named by them
+    HIPCHK(c, hipMemcpyAsync(hp<void>(c, ojobs), dj, sizeof(DmJob) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hp<void>(c, oflag), b + c->dmba.oflag, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
+    if (d2h_sync(c, 0, 0)) return -1;
+    {   // the solver's time, measured on its own stream
+        float ms = 0.f;
+        if (c->timing && hipEventElapsedTime(&ms, c->dmba.t0, c->dmba.t1) == hipSuccess) { c->tm.ms[FAM_BA] += ms; c->tm.launches[FAM_BA] += 1; c->tm.units[FAM_BA] += njobs; }
+    }
+    if (const int fl = hp<int>(c, oflag)[0]) return fail(c, "dmap: the BA structure build overflowed a capacity (code %d)", fl);
+    const DmJob *hj = hp<DmJob>(c, ojobs);
+    int *l3 = hp<int>(c, ol3);
+    for (int i = 0; i < njobs; ++i) {
+        const int s_ = hj[i].stream;
+        l3[3 * i] = s_; l3[3 * i + 1] = c->rt_which[(size_t)s_]; l3[3 * i + 2] = c->rt_count[(size_t)s_];
+    }
+    if (h2d(c, ol3, ol3 + sizeof(int) * 3 * n)) return -1;
+    hipLaunchKernelGGL(k_dmap_refresh_xyz, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dp<int>(c, ol3), m, c->rt);
+    HIPCHK(c, hipGetLastError());
+    if (d2h_sync(c, 0, 0)) return -1;
+    memcpy(jobs_out, hj, sizeof(DmJob) * n);
+    for (int i = 0; i < njobs; ++i)
+        if (jobs_out[i].ba_iters < 0) return fail(c, "dmap: job %d: a workgroup of the low-latency BA solver never arrived (GPU oversubscribed?)", i);
     return 0;
 }
 

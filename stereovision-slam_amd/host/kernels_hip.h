@@ -74,6 +74,7 @@ public:
                       const svslam_dmap_params *p)
     { return svslam_dmap_keyframe_batch(ctx_, n, jobs, left, right, strides, is_device, cam_l, ext_l, cam_r, ext_r, p); }
     int dmap_evicted(const svslam_dmap_evicted_rec **recs, int *n) { return svslam_dmap_evicted(ctx_, recs, n); }
+    int dmap_ba_collect(int n, svslam_dmap_job *jobs, int *inflight) { return svslam_dmap_ba_collect(ctx_, n, jobs, inflight); }
     int dmap_read(int stream, long long *kf_frame, int *kf_id, double *kf_pose, int *kf_n, int *lm_id, double *lm_pos,
                   int *lm_obs, uint8_t *lm_state)
     { return svslam_dmap_read(ctx_, stream, kf_frame, kf_id, kf_pose, kf_n, lm_id, lm_pos, lm_obs, lm_state); }

@@ -35,7 +35,7 @@ svs::Config to_config(const svs_pipe_config &c)
     g.resident_track = c.resident_track;
     g.max_pts = c.max_pts > 0 ? c.max_pts : 512;
     g.max_kf = c.num_active_keyframes + 1; g.max_lm = c.max_lm; g.max_obs = c.max_obs;
-    g.device_map = (c.device_map && c.resident_track && c.backend_on == 1) ? 1 : 0;
+    g.device_map = (c.device_map && c.resident_track) ? 1 : 0;
     g.backend_lag = c.backend_lag > 0 ? c.backend_lag : 1;
     return g;
 }
@@ -62,12 +62,15 @@ void *svs_pipe_create(const svs_pipe_config *cfg, int nstreams, int device)
         lim.max_slots = 3 * nstreams; lim.max_jobs = 2 * nstreams; // one call may build left+right pyramids
         lim.max_pts = cfg->max_pts > 0 ? cfg->max_pts : 512; lim.max_corners = cfg->num_features;
         lim.max_kf = cfg->num_active_keyframes + 1; lim.max_lm = cfg->max_lm; lim.max_obs = cfg->max_obs;
-        lim.max_streams = (cfg->resident_track && cfg->backend_on <= 1) ? nstreams : 0;
-        lim.device_map = (cfg->device_map && cfg->resident_track && cfg->backend_on == 1) ? 1 : 0;
+        // the map on the device (any backend mode: with backend_on 2 the local BA of a keyframe runs on a second stream of the
+        // same context, svslam_dmap_params::ba_defer); otherwise backend_on 2 gives the BA its own context
+        const bool dmap = cfg->device_map && cfg->resident_track;
+        lim.max_streams = (cfg->resident_track && (cfg->backend_on <= 1 || dmap)) ? nstreams : 0;
+        lim.device_map = dmap ? 1 : 0;
         svslam_limits lim_front = lim;
-        if (cfg->backend_on >= 2) { lim_front.max_kf = 0; lim_front.max_lm = 0; lim_front.max_obs = 0; }   // BA lives in its own context
+        if (cfg->backend_on >= 2 && !dmap) { lim_front.max_kf = 0; lim_front.max_lm = 0; lim_front.max_obs = 0; }   // BA lives in its own context
         h->kernels.reset(SVS_PIPE_MAKE_KERNELS(lim_front));
-        if (cfg->backend_on >= 2) {
+        if (cfg->backend_on >= 2 && !dmap) {
             svslam_limits lim_ba = lim;
             lim_ba.max_jobs = nstreams;
             h->kernels->enable_backend_context(lim_ba);

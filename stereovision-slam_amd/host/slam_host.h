@@ -455,6 +455,9 @@ public:
         DS.insert(DS.end(), KS.begin(), KS.end());
         std::vector<int> MS;                      // streams that triangulate + BA
         if (device_map()) {
+            // backend_on 2: the local BA of the last keyframe step runs beside the tracking (a second stream of the provider's
+            // context); its result lands backend_lag frames later, or before the next keyframe step touches the map
+            if (dm_inflight_ && (++ba_age_ >= std::max(1, cfg_.backend_lag) || !DS.empty())) DmCollect();
             if (!DS.empty()) KeyframeOnDevice(IS, KS, left, right, strides, is_device, MS);
         } else if (!DS.empty()) {
             BuildPyramids(IS, DS, left, right, strides, is_device);
@@ -650,8 +653,8 @@ private:
         cnt_.track_pts += ofs; cnt_.pyr_left += n;
     }
 
-    bool resident() const { return cfg_.resident_track && cfg_.backend_on <= 1; }
-    bool device_map() const { return cfg_.device_map && resident() && cfg_.backend_on == 1; }
+    bool resident() const { return cfg_.resident_track && (cfg_.backend_on <= 1 || cfg_.device_map); }
+    bool device_map() const { return cfg_.device_map && cfg_.resident_track; }
 
     // ---- the keyframe path with the map in device memory: InsertKeyframe (:576-643) / StereoInit (:216-249) and
     // Backend::Optimize as ONE call of the kernel provider.  The host keeps the window's frames (ids, poses, slots):
@@ -708,12 +711,18 @@ private:
         });
         svslam_dmap_params prm;
         prm.num_features = cfg_.num_features; prm.num_features_init = cfg_.num_features_init;
-        prm.num_active_keyframes = cfg_.num_active_keyframes; prm.ba_iters = backend_enabled_ ? 10 : 0;   // src/backend.cpp:163
+        prm.num_active_keyframes = cfg_.num_active_keyframes; prm.ba_iters = (backend_enabled_ && cfg_.backend_on >= 1) ? 10 : 0;   // src/backend.cpp:163
         prm.max_triangulation_depth = cfg_.max_triangulation_depth; prm.chi2_th = cfg_.chi2_th;
+        prm.ba_defer = 0; prm.reserved = 0;
         st_[6] += now_ns() - t_h;
-        // a provider call holds at most dm_chunk_ jobs (its staging memory is sized for that)
+        // a provider call holds at most dm_chunk_ jobs (its staging memory is sized for that); with the backend beside the
+        // frontend (backend_on 2) the LAST call's local BA is left running (one deferred batch at a time; the calls before
+        // it, if any — only a start-up with more than dm_chunk_ streams has them — complete theirs at once)
+        int defer_from = n;
         for (int c0 = 0; c0 < n; c0 += dm_chunk_) {
             const int m = std::min(dm_chunk_, n - c0);
+            prm.ba_defer = (cfg_.backend_on >= 2 && prm.ba_iters > 0 && c0 + m >= n) ? 1 : 0;
+            if (prm.ba_defer) defer_from = c0;
             KTimer kt_(cnt_);
             check(k_.dmap_keyframe(m, jobs_dm_.data() + c0, dm_left_.data() + c0, dm_right_.data() + c0, strides_.data() + c0, is_device,
                                    cam_l_, cfg_.cam_l.pose.v, cam_r_, cfg_.cam_r.pose.v, &prm), "dmap_keyframe");
@@ -754,16 +763,38 @@ private:
             MS.push_back(DS[i]);
             cnt_.tri_pts += j.n_tri_in;
             if (j.flags & 4) cnt_.ba_skipped++;
-            if (prm.ba_iters > 0 && !(j.flags & 4)) {
-                cnt_.ba_calls++; cnt_.ba_edges += j.ba_nobs; cnt_.ba_kf += j.ba_nkf; cnt_.ba_lm += j.ba_nlm; cnt_.ba_iters += j.ba_iters;
-                cnt_.ba_pairs += j.ba_npair; cnt_.ba_trials += j.ba_ntrial;
-                // :224-246 on the mirror: the window's poses
-                for (int a = 0; a < j.ba_nkf; ++a)
-                    for (Frame *kf : st.map.active_keyframes_)
-                        if (kf->dslot == j.win_slot[a]) { kf->pose = SE3(j.win_pose[a]); break; }
-                for (Frame *kf : st.map.active_keyframes_)
-                    if (kf->keyframe_id != 0 && kf->prev_keyframe) kf->relative_pose_pkf = kf->pose * kf->prev_keyframe->pose.inverse();
-            }
+            if (prm.ba_iters > 0 && i < defer_from) ApplyDeviceBa(st, j);
+        }
+        if (defer_from < n) {                  // the deferred batch: its jobs and streams wait for DmCollect
+            dm_pending_.assign(jobs_dm_.begin() + defer_from, jobs_dm_.end());
+            dm_pending_streams_.assign(DS.begin() + defer_from, DS.end());
+            dm_inflight_ = true; ba_age_ = 0;
+        }
+        st_[7] += now_ns() - t_h;
+    }
+    // Backend::Optimize's write-back on the host mirror (:224-246): counters, the window's poses
+    void ApplyDeviceBa(Stream &st, const svslam_dmap_job &j)
+    {
+        if (j.flags & 4) return;
+        cnt_.ba_calls++; cnt_.ba_edges += j.ba_nobs; cnt_.ba_kf += j.ba_nkf; cnt_.ba_lm += j.ba_nlm; cnt_.ba_iters += j.ba_iters;
+        cnt_.ba_pairs += j.ba_npair; cnt_.ba_trials += j.ba_ntrial;
+        for (int a = 0; a < j.ba_nkf; ++a)
+            for (Frame *kf : st.map.active_keyframes_)
+                if (kf->dslot == j.win_slot[a]) { kf->pose = SE3(j.win_pose[a]); break; }
+        for (Frame *kf : st.map.active_keyframes_)
+            if (kf->keyframe_id != 0 && kf->prev_keyframe) kf->relative_pose_pkf = kf->pose * kf->prev_keyframe->pose.inverse();
+    }
+    // the deferred local BA of the device map lands (svslam_dmap_ba_collect)
+    void DmCollect()
+    {
+        if (!dm_inflight_) return;
+        dm_inflight_ = false;
+        int nin = 0;
+        { KTimer kt_(cnt_); check(k_.dmap_ba_collect((int)dm_pending_.size(), dm_pending_.data(), &nin), "dmap_ba_collect"); }
+        long long t_h = now_ns();
+        for (size_t i = 0; i < dm_pending_.size(); ++i) {
+            if (dm_pending_[i].is_init && !dm_pending_[i].ok) continue;
+            ApplyDeviceBa(*streams_[dm_pending_streams_[i]], dm_pending_[i]);
         }
         st_[7] += now_ns() - t_h;
     }
@@ -1310,7 +1341,7 @@ private:
 
 public:
     // completes a backend optimisation that is still in flight (backend_on 2)
-    void Flush() { BackendCollect(); }
+    void Flush() { BackendCollect(); DmCollect(); }
     // Backend::PauseRequest / Resume (src/backend.cpp:296-343): keyframes inserted while the backend is
     // paused are not optimised
     void SetBackendEnabled(bool on) { backend_enabled_ = on; }
@@ -1376,6 +1407,9 @@ private:
     std::vector<int> ba_ms_;
     bool ba_inflight_ = false;
     int ba_age_ = 0;
+    bool dm_inflight_ = false;                       // device map, backend_on 2: a deferred local BA is running
+    std::vector<svslam_dmap_job> dm_pending_;
+    std::vector<int> dm_pending_streams_;
     int ba_ko_ = 0, ba_lo_ = 0, ba_oo_ = 0;
     long long st_[12] = { 0 };   // 0 begin 1 track-prep 2 track-finish 3 detect 4 right 5 tri 6 ba-gather 7 ba-scatter 8 end
     Config cfg_;
