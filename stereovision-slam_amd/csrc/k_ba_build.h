@@ -330,7 +330,8 @@ k_ba_build(BaDev *jobs, const unsigned int *obs_packed, const float2 *obs_uv,
 // so a shard is a sub-range of the parent's landmark, position and edge arrays and k_ba_build / k_local_ba_t<2> work on it
 // in place: results land where the parent's caller expects them.  Every shard gets all keyframes (k_ba_build all_active).
 // One workgroup per problem.  Shards without edges are masked out (BaDev::shmask) and their exchange slots zeroed.
-__global__ void __launch_bounds__(BB_THREADS)
+#define SP_THREADS 1024     // (the pass over the edges is a chain of dependent global loads per thread: more threads, fewer rounds)
+__global__ void __launch_bounds__(SP_THREADS)
 k_ba_split(const BaDev *parents, BaDev *shards, const unsigned int *obs_packed, int llw, int tile_cap, int max_nlm,
            double *xch, size_t xch_stride, unsigned int *cnt, int res_blocks, int res_landmarks, int res_edges)
 {
@@ -341,12 +342,12 @@ k_ba_split(const BaDev *parents, BaDev *shards, const unsigned int *obs_packed, 
     BaDev *sh = shards + (size_t)blockIdx.x * llw;
     int *estart = sp_lds;                     // [nlm + 1] first edge of landmark l
     long long *cost = reinterpret_cast<long long *>(sp_lds + ((max_nlm + 2 + 1) & ~1));   // [nlm + 1] exclusive prefix of the cost
-    long long *tmpl = cost + max_nlm + 2;     // [BB_THREADS]
-    int *cut = reinterpret_cast<int *>(tmpl + BB_THREADS);    // [llw + 1] first landmark of shard w
+    long long *tmpl = cost + max_nlm + 2;     // [SP_THREADS]
+    int *cut = reinterpret_cast<int *>(tmpl + SP_THREADS);    // [llw + 1] first landmark of shard w
     if (tid < LL_CNT_WORDS) cnt[(size_t)LL_CNT_WORDS * blockIdx.x + tid] = 0u;    // arrival counter + abort word of this call
     const bool empty = nobs <= 0 || nlm <= 0 || nkf <= 0 || pd.reserved == 0;        // (unsorted edges: the host does not come here)
     if (empty) {
-        for (int w = tid; w < llw; w += BB_THREADS) {
+        for (int w = tid; w < llw; w += SP_THREADS) {
             BaDev d = pd;
             d.nlm = 0; d.nobs = 0; d.nblk = d.na = d.ncontrib = d.ntile = d.nmv = 0; d.shmask = 0; d.lm_base = 0; d.iters_done = 0; d.ntrial = 0;
             sh[w] = d;
@@ -354,7 +355,7 @@ k_ba_split(const BaDev *parents, BaDev *shards, const unsigned int *obs_packed, 
         return;
     }
     const unsigned int *opk = obs_packed + pd.obs_ofs;
-    for (int i = tid; i < nobs; i += BB_THREADS) {
+    for (int i = tid; i < nobs; i += SP_THREADS) {
         const int l = (int)(opk[i] & 0xffffu);
         const int lp = i > 0 ? (int)(opk[i - 1] & 0xffffu) : -1;
         if (l != lp) for (int q = lp + 1; q <= l; ++q) estart[q] = i;
@@ -362,19 +363,19 @@ k_ba_split(const BaDev *parents, BaDev *shards, const unsigned int *obs_packed, 
     }
     __syncthreads();
     // exclusive prefix of the landmark costs
-    const int per = (nlm + BB_THREADS - 1) / BB_THREADS;
+    const int per = (nlm + SP_THREADS - 1) / SP_THREADS;
     const int l0 = min(tid * per, nlm), l1 = min(l0 + per, nlm);
     long long sum = 0;
     for (int l = l0; l < l1; ++l) { const long long e = estart[l + 1] - estart[l]; sum += e * (4 + e); }
     tmpl[tid] = sum;
     __syncthreads();
-    for (int d = 1; d < BB_THREADS; d <<= 1) {
+    for (int d = 1; d < SP_THREADS; d <<= 1) {
         const long long add = tid >= d ? tmpl[tid - d] : 0;
         __syncthreads();
         tmpl[tid] += add;
         __syncthreads();
     }
-    const long long total = tmpl[BB_THREADS - 1];
+    const long long total = tmpl[SP_THREADS - 1];
     {
         long long run = tmpl[tid] - sum;
         for (int l = l0; l < l1; ++l) { const long long e = estart[l + 1] - estart[l]; cost[l] = run; run += e * (4 + e); }
@@ -384,7 +385,7 @@ k_ba_split(const BaDev *parents, BaDev *shards, const unsigned int *obs_packed, 
     __syncthreads();
     // shard of landmark l = floor(cost_before(l) * llw / total); cut[w] = first landmark of shard w (monotone)
     auto shard_of = [&](int l) -> int { const int w = (int)((cost[l] * llw) / (total > 0 ? total : 1)); return w < llw ? w : llw - 1; };
-    for (int l = tid; l < nlm; l += BB_THREADS) {
+    for (int l = tid; l < nlm; l += SP_THREADS) {
         const int w = shard_of(l), wp = l > 0 ? shard_of(l - 1) : -1;
         for (int q = wp + 1; q <= w; ++q) cut[q] = l;
     }
@@ -414,7 +415,7 @@ k_ba_split(const BaDev *parents, BaDev *shards, const unsigned int *obs_packed, 
     // exactly: an edge opens a block when its (landmark, keyframe) differs from its predecessor's.
     {
         int *nb = reinterpret_cast<int *>(tmpl + 1);
-        for (int i = tid; i < nobs; i += BB_THREADS) {
+        for (int i = tid; i < nobs; i += SP_THREADS) {
             const unsigned int ev = opk[i] & 0x00ffffffu, pv = i > 0 ? (opk[i - 1] & 0x00ffffffu) : 0xffffffffu;
             if (ev == pv) continue;
             int w = 0;
@@ -435,13 +436,13 @@ k_ba_split(const BaDev *parents, BaDev *shards, const unsigned int *obs_packed, 
     for (int w = 0; w < llw; ++w) {
         if ((mask >> w) & 1u) continue;
         double *slab = xs + (size_t)w * LL_SLAB(np), *x0 = xs + (size_t)llw * LL_SLAB(np) + (size_t)w * LL_X0(np);
-        for (size_t i = tid; i < LL_SLAB(np); i += BB_THREADS) slab[i] = 0.0;
-        for (size_t i = tid; i < LL_X0(np); i += BB_THREADS) x0[i] = 0.0;
+        for (size_t i = tid; i < LL_SLAB(np); i += SP_THREADS) slab[i] = 0.0;
+        for (size_t i = tid; i < LL_X0(np); i += SP_THREADS) x0[i] = 0.0;
     }
     // the granules of the rho exchange are tagged with epochs that count from 1 in every launch: all of them start at 0
     {
         double *xb = xs + (size_t)llw * (LL_SLAB(np) + LL_X0(np));
-        for (int i = tid; i < llw * LL_XB; i += BB_THREADS) xb[i] = 0.0;
+        for (int i = tid; i < llw * LL_XB; i += SP_THREADS) xb[i] = 0.0;
     }
 }
 // extra aux ints a parent's reservation needs so that its llw shards fit (per-shard constants of ba_aux_layout, two tiles of
@@ -452,5 +453,5 @@ __host__ __device__ inline size_t ba_split_aux_extra(int nkf, int llw)
 }
 static inline size_t ba_split_lds_bytes(int max_nlm, int llw)
 {
-    return sizeof(int) * (size_t)((max_nlm + 2 + 1) & ~1) + sizeof(long long) * ((size_t)max_nlm + 2 + BB_THREADS) + sizeof(int) * (size_t)(llw + 2) + 64;      // (BB_THREADS >= 1 + llw ints for the per-shard block counts)
+    return sizeof(int) * (size_t)((max_nlm + 2 + 1) & ~1) + sizeof(long long) * ((size_t)max_nlm + 2 + SP_THREADS) + sizeof(int) * (size_t)(llw + 2) + 64;      // (SP_THREADS >= 1 + llw ints for the per-shard block counts)
 }

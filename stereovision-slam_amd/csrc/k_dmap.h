@@ -319,7 +319,7 @@ k_dmap_commit(DmJob *jobs, DMap m, const double *tri_xyz, const uint8_t *tri_ok,
 // ---------------------------------------------------------------- Backend::Optimize: the problem, in k_ba_build's input layout
 // Per job the BA arrays have fixed strides (max_kf poses, NL points, max_obs edges).  LDS: sort keys [NL] u64,
 // local index by slot [NL] i32, edge counts / starts [NL + 1] i32.
-#define DMG_THREADS 512
+#define DMG_THREADS 1024
 static inline size_t dmg_lds_bytes(int NL) { return (size_t)NL * 8 + (size_t)NL * 4 + ((size_t)NL + 2) * 4 + DMG_THREADS * 4 + 256; }
 
 __global__ void __launch_bounds__(DMG_THREADS)
@@ -357,35 +357,56 @@ k_dmap_ba_gather(DmJob *jobs, DMap m, DmParams prm, BaDev *badev, double *poses,
     }
     // vertices: active landmarks with an observation, in id order (Map::active_landmarks_ is id-ordered; a landmark
     // becomes a vertex with its first observation, src/backend.cpp:118-130)
-    for (int l = tid; l < NL; l += DMG_THREADS) {
-        const bool v = m.lm_st[L + l] == 1 && m.lm_obs[L + l] > 0;
-        keys[l] = v ? (((unsigned long long)(unsigned)m.lm_id[L + l] << 32) | (unsigned)l) : ~0ull;
-        local_of[l] = -1;
+    // The vertices' keys are compacted first (thread t owns slots [t per, (t + 1) per): stable), so that the bitonic sort
+    // runs over the next power of two above their number — ~1 700 of 4 096 slots hold a vertex in a full window — instead of
+    // over all NL slots: 99 -> ~30 us for a lone camera's keyframe (round 4).  The compacted copy borrows the local_of /
+    // estart area, which is initialised afterwards.
+    unsigned long long *ck = reinterpret_cast<unsigned long long *>(local_of);      // [NL] (local_of + estart: 8 NL + 8 bytes)
+    int nvalid = 0, n2 = 2;
+    {
+        const int per = (NL + DMG_THREADS - 1) / DMG_THREADS;
+        const int l0 = min(tid * per, NL), l1 = min(l0 + per, NL);
+        int cnt = 0;
+        for (int l = l0; l < l1; ++l) {
+            const bool v = m.lm_st[L + l] == 1 && m.lm_obs[L + l] > 0;
+            keys[l] = v ? (((unsigned long long)(unsigned)m.lm_id[L + l] << 32) | (unsigned)l) : ~0ull;
+            cnt += v ? 1 : 0;
+        }
+        tmp[tid] = cnt;
+        __syncthreads();
+        for (int d = 1; d < DMG_THREADS; d <<= 1) {
+            const int add = tid >= d ? tmp[tid - d] : 0;
+            __syncthreads();
+            tmp[tid] += add;
+            __syncthreads();
+        }
+        nvalid = tmp[DMG_THREADS - 1];
+        int pos = tmp[tid] - cnt;
+        for (int l = l0; l < l1; ++l) if (keys[l] != ~0ull) ck[pos++] = keys[l];
+        while (n2 < nvalid) n2 <<= 1;
+        __syncthreads();
+        for (int i = nvalid + tid; i < n2; i += DMG_THREADS) ck[i] = ~0ull;
+        __syncthreads();
     }
-    __syncthreads();
-    for (int k2 = 2; k2 <= NL; k2 <<= 1)               // bitonic sort (NL is a power of two)
+    for (int k2 = 2; k2 <= n2; k2 <<= 1)               // bitonic sort of the compacted keys
         for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-            for (int i = tid; i < NL; i += DMG_THREADS) {
+            for (int i = tid; i < n2; i += DMG_THREADS) {
                 const int ixj = i ^ j2;
                 if (ixj > i) {
-                    const unsigned long long a = keys[i], b = keys[ixj];
+                    const unsigned long long a = ck[i], b = ck[ixj];
                     const bool up = (i & k2) == 0;
-                    if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+                    if ((a > b) == up) { ck[i] = b; ck[ixj] = a; }
                 }
             }
             __syncthreads();
         }
-    int nlm_part = 0;
-    for (int i = tid; i < NL; i += DMG_THREADS) {
-        const unsigned long long k = keys[i];
-        if (k != ~0ull) { local_of[(int)(k & 0xffffffffu)] = i; nlm_part = i + 1 > nlm_part ? i + 1 : nlm_part; }
-    }
+    for (int i = tid; i < NL; i += DMG_THREADS) keys[i] = i < n2 ? ck[i] : ~0ull;     // sorted vertices first, the rest empty
     __syncthreads();
-    tmp[tid] = nlm_part;
+    for (int l = tid; l < NL; l += DMG_THREADS) local_of[l] = -1;
     __syncthreads();
-    if (tid == 0) { int n = 0; for (int i = 0; i < DMG_THREADS; ++i) n = tmp[i] > n ? tmp[i] : n; small[17] = n; }
+    for (int i = tid; i < nvalid; i += DMG_THREADS) local_of[(int)(keys[i] & 0xffffffffu)] = i;      // (the vertices are keys [0, nvalid))
     __syncthreads();
-    const int nkf = small[16], nlm = small[17];
+    const int nkf = small[16], nlm = nvalid;
     // edges per vertex
     for (int i = tid; i <= nlm + 1; i += DMG_THREADS) estart[i] = 0;
     __syncthreads();

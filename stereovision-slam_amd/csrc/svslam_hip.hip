@@ -244,7 +244,7 @@ void launch_ba_solver(svslam_ctx *c, int njobs, bool ll, BaDev *jobs, const BaCa
     }
     const int W = c->ll.w;
     c->host_ns[6] += njobs;                    // svslam_debug_host_ns slot 6: problems the low-latency solver took
-    hipLaunchKernelGGL(k_ba_split, dim3(njobs), dim3(BB_THREADS), ba_split_lds_bytes(max_nlm, W), c->stream, jobs, c->ll.shards, packed, W, tile_cap,
+    hipLaunchKernelGGL(k_ba_split, dim3(njobs), dim3(SP_THREADS), ba_split_lds_bytes(max_nlm, W), c->stream, jobs, c->ll.shards, packed, W, tile_cap,
                        max_nlm, c->ll.xch, c->ll.xch_stride, c->ll.cnt, c->ll.caps.B, c->ll.caps.L, c->ll.caps.E);
     hipLaunchKernelGGL(k_ba_build, dim3(njobs * W), dim3(BB_THREADS), bb_lds_bytes(max_nlm, max_nobs), c->stream, c->ll.shards, packed, uv, srt, recs, aux,
                        tile_cap, max_nlm, flag, 1 /* every keyframe active in every shard */, ec, 1 /* every landmark in the tile */);
@@ -1692,14 +1692,22 @@ int svslam_dmap_keyframe_batch(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, 
         hipLaunchKernelGGL(k_dmap_refresh_xyz, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dp<int>(c, ol3), m, c->rt);
     } else hipLaunchKernelGGL(k_dmap_refresh, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, c->rt);
     HIPCHK(c, hipGetLastError());
-    if (d2h_sync(c, ojobs, ojobs + sizeof(DmJob) * n)) return -1;
+    // ONE wait for everything the host reads (round 4: three copies each behind its own wait cost a lone camera ~50 us per
+    // keyframe): the jobs, the flag words and the head of the evicted list ride one completion; only a list longer than the
+    // head is fetched with a second copy
     // (deferred: the build's overflow word is read by svslam_dmap_ba_collect; word 0 of the arena copy stays 0)
-    if (d2h_sync(c, defer ? oevc : oflag, (defer ? oevc : oflag) + sizeof(int) * 4)) return -1;
-    const int *fw = hp<int>(c, defer ? oevc : oflag);
+    const size_t ofw = defer ? oevc : oflag;
+    const int ev_head = std::min(ev_cap, 256);
+    HIPCHK(c, hipMemcpyAsync(hp<void>(c, ojobs), dp<void>(c, ojobs), sizeof(DmJob) * n, hipMemcpyDeviceToHost, c->stream));
+    if (defer) HIPCHK(c, hipMemcpyAsync(hp<void>(c, ofw), dp<void>(c, ofw), sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
+    else HIPCHK(c, hipMemcpyAsync(hp<void>(c, ofw), bp_(ofw), sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
+    if (!opt_only && ev_head > 0) HIPCHK(c, hipMemcpyAsync(hp<void>(c, oev), dp<void>(c, oev), sizeof(DmEvicted) * (size_t)ev_head, hipMemcpyDeviceToHost, c->stream));
+    if (d2h_sync(c, 0, 0)) return -1;
+    const int *fw = hp<int>(c, ofw);
     if (const int fl = fw[0]) return fail(c, "dmap: the BA structure build overflowed a capacity (code %d)", fl);
     if (const int nev = fw[1]) {                // the landmarks this call freed (svslam_dmap_evicted)
         if (nev < 0 || nev > ev_cap) return fail(c, "dmap: evicted-list cursor %d out of [0,%d]", nev, ev_cap);
-        if (d2h_sync(c, oev, oev + sizeof(DmEvicted) * (size_t)nev)) return -1;
+        if (nev > ev_head && d2h_sync(c, oev + sizeof(DmEvicted) * (size_t)ev_head, oev + sizeof(DmEvicted) * (size_t)nev)) return -1;
         c->evicted.assign(hp<DmEvicted>(c, oev), hp<DmEvicted>(c, oev) + nev);
     }
     memcpy(jobs, hj, sizeof(DmJob) * n);
