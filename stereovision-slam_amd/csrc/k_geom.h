@@ -7,6 +7,7 @@
 // order, so agreement is to rounding (tolerances in tests/).
 #pragma once
 #include "dev_common.h"
+#include "k_rt.h"
 // f64 LM kernels: tolerance-level parity, FMA contraction allowed (see dev_common.h)
 #pragma clang fp contract(fast)
 
@@ -242,10 +243,16 @@ __device__ __forceinline__ int po_block_sum_i32(int x, int *buf, int tid)
 #else
 #define PO_VGPR_ATTR
 #endif
-template <int WAVES>
+// FUSED (resident tracking): the kernel also does what stands before and after the optimisation in a tracked frame — the
+// survivor filter of TrackLastFrame (status && inside the image, src/frontend.cpp:361-371; an edge iff it also carries a map
+// point, :443-444; k_track_filter as a kernel of its own) on the way in, and the hand-over of the survivors to the stream's
+// other buffer (k_rt.h: rt_finish_wave) on the way out.  Same operations on the same values: results identical to the chain
+// of three launches, two dependent launches (~10 us each for a lone camera) fewer.
+struct PoFuse { uint8_t *status; const uint8_t *has_mp; int w, h; RtJob *rt; RtStore rs; float2 *out_xy; int *out_mp; };
+template <int WAVES, bool FUSED>
 __global__ void __launch_bounds__(64 * WAVES) PO_VGPR_ATTR
 k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *uv,
-            const uint8_t *edge_valid, uint8_t *outlier, double chi2_th, int rounds, int iters, double *trace)
+            const uint8_t *edge_valid, uint8_t *outlier, double chi2_th, int rounds, int iters, double *trace, PoFuse fz)
 {
     constexpr int NT = 64 * WAVES, SLOTS = PO_MAX_EDGES / NT;
     __shared__ __attribute__((aligned(16))) double s_red[4 * WAVES * 32];
@@ -282,7 +289,16 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
     for (int s = 0; s < SLOTS; ++s) {
         const int e = s * NT + tid;
         bool v = e < n;
-        if (v && edge_valid && !edge_valid[jb_pt_ofs + e]) v = false;
+        if (FUSED) {
+            if (v) {
+                const int pt = jb_pt_ofs + e;
+                const float2 q = uv[pt];
+                bool ok = fz.status[pt] != 0;
+                if (q.y < 0.f || q.y >= (float)fz.h || q.x < 0.f || q.x >= (float)fz.w) ok = false;
+                fz.status[pt] = ok ? 1 : 0;
+                v = ok && fz.has_mp[pt] != 0;
+            }
+        } else if (v && edge_valid && !edge_valid[jb_pt_ofs + e]) v = false;
         vmask |= (v ? 1u : 0u) << s;
         if (s < RS) {
             if (e < n) {
@@ -484,6 +500,10 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
     }
 #undef PO_TICK
 #undef PO_TICKV
+    if (FUSED) {
+        __syncthreads();            // the outlier flags of all threads, the filtered status bytes
+        if (tid < 64) rt_finish_wave(fz.rt[blockIdx.x], fz.rs, uv, fz.status, outlier, xyz, fz.out_xy, fz.out_mp, tid);
+    }
 }
 
 // ------------------------------------------------------------------ fused-track filter
@@ -515,83 +535,20 @@ k_track_filter(const LkJobView *jobs, const float2 *next_xy, uint8_t *status, co
 
 #pragma clang fp contract(off)
 // ---------------------------------------------------------------- device-resident tracking
-// The features of every stream's last frame (position, map-point id, map-point position)
-// stay in HBM in two alternating buffers per stream; a frame that is not a keyframe never
-// costs the host a per-feature operation (Frontend::TrackLastFrame :322-392 gather and
-// :361-381 / EstimateCurrentPose :546-553 scatter become the two kernels below).
-struct RtJob {
-    int stream, pt_ofs, npts, src_buf;
-    double T_cam_w[7];      // cam_left.pose * predicted T_cw (src/camera.cpp:74-80)
-    int n_tracked, n_edges, n_outlier, pad;
-};
-struct RtStore { float2 *xy[2]; int *mp[2]; double *xyz[2]; int max_pts; };
-
-// thread per feature of the previous frame: LK inputs + pose-only inputs
+// (RtJob / RtStore, the gather and the finish bodies: k_rt.h)
 __global__ void __launch_bounds__(256)
 k_rt_gather(const RtJob *jobs, RtStore rs, const double *cam, float2 *prev_xy, float2 *next_xy, uint8_t *has_mp, double *xyz)
 {
     const RtJob jb = jobs[blockIdx.y];                 // a copy: the array may be pinned host memory
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= jb.npts) return;
-    const size_t src = (size_t)jb.stream * rs.max_pts + i;
-    const int pt = jb.pt_ofs + i;
-    const float2 p = rs.xy[jb.src_buf][src];
-    const int mp = rs.mp[jb.src_buf][src];
-    prev_xy[pt] = p;
-    if (mp >= 0) {
-        const double *Xs = rs.xyz[jb.src_buf] + 3 * src;
-        const double X[3] = { Xs[0], Xs[1], Xs[2] };
-        double uv[2];
-        d_project_exact(jb.T_cam_w, cam, X, uv);
-        next_xy[pt] = make_float2((float)uv[0], (float)uv[1]);
-        has_mp[pt] = 1;
-        xyz[3 * (size_t)pt] = X[0]; xyz[3 * (size_t)pt + 1] = X[1]; xyz[3 * (size_t)pt + 2] = X[2];
-    } else {
-        next_xy[pt] = p;
-        has_mp[pt] = 0;
-        xyz[3 * (size_t)pt] = 0; xyz[3 * (size_t)pt + 1] = 0; xyz[3 * (size_t)pt + 2] = 1;
-    }
+    if (i < jb.npts) rt_gather_point(jb, rs, cam, i, prev_xy, next_xy, has_mp, xyz);
 }
 
-// one wave per job: survivors, in order, become the features of the new frame (other buffer);
-// an edge the pose optimisation classified as outlier loses its map point (:546-553).
-// The compacted (xy, mp) list is also left in the staging arena for the host (keyframes).
 __global__ void __launch_bounds__(64)
 k_rt_finish(RtJob *jobs, RtStore rs, const float2 *next_xy, const uint8_t *status, const uint8_t *outlier,
             const double *xyz, float2 *out_xy, int *out_mp)
 {
-    RtJob &jb = jobs[blockIdx.x];                      // (may be pinned host memory: fields read once)
-    const int lane = threadIdx.x;
-    const int srcb = jb.src_buf, dstb = srcb ^ 1, npts = jb.npts, pt_ofs = jb.pt_ofs;
-    const size_t sbase = (size_t)jb.stream * rs.max_pts;
-    int base = 0, n_edges = 0, n_out = 0;
-    for (int c0 = 0; c0 < npts; c0 += 64) {
-        const int i = c0 + lane;
-        const bool in = i < npts;
-        const int pt = pt_ofs + (in ? i : 0);
-        const bool ok = in && status[pt] != 0;
-        const unsigned long long bal = __ballot(ok);
-        int mp = -1;
-        bool edge = false, outl = false;
-        if (ok) {
-            mp = rs.mp[srcb][sbase + i];
-            edge = mp >= 0;
-            outl = edge && outlier[pt] != 0;
-            if (outl) mp = -1;
-            const int r = base + __popcll(bal & ((1ull << lane) - 1ull));
-            const float2 q = next_xy[pt];
-            rs.xy[dstb][sbase + r] = q;
-            rs.mp[dstb][sbase + r] = mp;
-            double *Xd = rs.xyz[dstb] + 3 * (sbase + r);
-            Xd[0] = xyz[3 * (size_t)pt]; Xd[1] = xyz[3 * (size_t)pt + 1]; Xd[2] = xyz[3 * (size_t)pt + 2];
-            out_xy[pt_ofs + r] = q;
-            out_mp[pt_ofs + r] = mp;
-        }
-        base += __popcll(bal);
-        n_edges += __popcll(__ballot(edge));
-        n_out += __popcll(__ballot(outl));
-    }
-    if (lane == 0) { jb.n_tracked = base; jb.n_edges = n_edges; jb.n_outlier = n_out; }
+    rt_finish_wave(jobs[blockIdx.x], rs, next_xy, status, outlier, xyz, out_xy, out_mp, threadIdx.x);
 }
 
 // host -> resident buffer (after a keyframe changed the frame's feature list or its map points)

@@ -17,6 +17,7 @@
 // recomputing border pixels.  Generic kernels cover tiny levels.
 #pragma once
 #include "dev_common.h"
+#include "k_rt.h"
 
 struct PyrJob {
     const uint8_t *src;   // level-0 source (device), tight or strided
@@ -330,12 +331,24 @@ __device__ __forceinline__ void pyr_store_rows(uint8_t *lvl, int pitch, int w, i
 
 template <bool DECIMATE>
 __global__ void __launch_bounds__(PF_THREADS)
-k_pyr_fused(const PyrJob *jobs, int njobs, uint8_t *pyr, PyrGeom g, int src_w, int src_h, PyrFusedPlan pl)
+k_pyr_fused(const PyrJob *jobs, int njobs, uint8_t *pyr, PyrGeom g, int src_w, int src_h, PyrFusedPlan pl, RtGatherArgs ga)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t pf_lds[];
     // Workgroup b runs on XCD b % 8 (observed dispatch order; only speed depends on it): keep the strips of
     // one image on one XCD, so the rows two neighbouring strips both read come out of that XCD's L2.
     const int bid = blockIdx.x;
+    // workgroups past the pyramid's own: the feature gather of resident tracking (k_rt.h) rides on this launch — it reads
+    // nothing the pyramid writes, and as a launch of its own it would stand between the pyramid and LK
+    const int pyr_blocks = ((njobs + 7) >> 3) * 8 * pl.nstrips;
+    if (bid >= pyr_blocks) {
+        const int gb = bid - pyr_blocks, gj = gb / ga.chunks;
+        if (gj < ga.njobs) {
+            const RtJob rj = ga.jobs[gj];                 // a copy: the array may be pinned host memory
+            const int i = (gb - gj * ga.chunks) * PF_THREADS + (int)threadIdx.x;
+            if (i < rj.npts) rt_gather_point(rj, ga.rs, ga.cam, i, ga.prev_xy, ga.next_xy, ga.has_mp, ga.xyz);
+        }
+        return;
+    }
     const int job = (bid / (8 * pl.nstrips)) * 8 + (bid & 7);
     const int strip = (bid >> 3) % pl.nstrips;
     if (job >= njobs) return;

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <ctime>
 #include <sys/prctl.h>
 #include <new>
@@ -183,13 +184,17 @@ void tm_end(svslam_ctx *c)
 }
 // pose-only LM: one wave per job by default, four when the context is in low-latency mode
 void launch_pose_only(svslam_ctx *c, int njobs, PoseJob *jobs, const double *cam, const double *xyz, const float2 *uv,
-                      const uint8_t *valid, uint8_t *outlier, double chi2_th, int rounds, int iters)
+                      const uint8_t *valid, uint8_t *outlier, double chi2_th, int rounds, int iters, const PoFuse *fz = nullptr)
 {
     if (c->d_lm_trace) (void)hipMemsetAsync(c->d_lm_trace, 0, sizeof(double) * LM_TRACE_STRIDE * (size_t)njobs, c->stream);
-    if (c->low_latency)
-        hipLaunchKernelGGL(k_pose_only<4>, dim3(njobs), dim3(256), 0, c->stream, jobs, cam, xyz, uv, valid, outlier, chi2_th, rounds, iters, c->d_lm_trace);
-    else
-        hipLaunchKernelGGL(k_pose_only<1>, dim3(njobs), dim3(64), 0, c->stream, jobs, cam, xyz, uv, valid, outlier, chi2_th, rounds, iters, c->d_lm_trace);
+    const PoFuse none = {};
+    if (c->low_latency) {
+        if (fz) hipLaunchKernelGGL((k_pose_only<4, true>), dim3(njobs), dim3(256), 0, c->stream, jobs, cam, xyz, uv, valid, outlier, chi2_th, rounds, iters, c->d_lm_trace, *fz);
+        else hipLaunchKernelGGL((k_pose_only<4, false>), dim3(njobs), dim3(256), 0, c->stream, jobs, cam, xyz, uv, valid, outlier, chi2_th, rounds, iters, c->d_lm_trace, none);
+    } else {
+        if (fz) hipLaunchKernelGGL((k_pose_only<1, true>), dim3(njobs), dim3(64), 0, c->stream, jobs, cam, xyz, uv, valid, outlier, chi2_th, rounds, iters, c->d_lm_trace, *fz);
+        else hipLaunchKernelGGL((k_pose_only<1, false>), dim3(njobs), dim3(64), 0, c->stream, jobs, cam, xyz, uv, valid, outlier, chi2_th, rounds, iters, c->d_lm_trace, none);
+    }
 }
 void tm_collect(svslam_ctx *c)
 {
@@ -367,14 +372,20 @@ int check_slot(svslam_ctx *c, int s)
 }
 
 // enqueue pyramid construction for n jobs whose PyrJob array is at device offset djobs
-int launch_pyramid(svslam_ctx *c, const PyrJob *djobs, int n, bool decimate, int src_w, int src_h)
+// ga (optional): the feature gather of resident tracking, riding on the fused launch as extra workgroups (gathered = true
+// says it did; with the per-level kernels the caller launches k_rt_gather itself)
+int launch_pyramid(svslam_ctx *c, const PyrJob *djobs, int n, bool decimate, int src_w, int src_h, const RtGatherArgs *ga = nullptr,
+                   bool *gathered = nullptr)
 {
     const PyrGeom &g = c->geom;
     tm_begin(c, FAM_PYR, n);
     if (c->pyr_fused) {
-        const dim3 grd(((n + 7) / 8) * 8 * c->pyr_plan.nstrips);      // jobs in groups of 8 (one per XCD), all strips of a job on its XCD
-        if (decimate) hipLaunchKernelGGL(k_pyr_fused<true>, grd, dim3(PF_THREADS), c->pyr_plan.lds_bytes, c->stream, djobs, n, c->d_pyr, g, src_w, src_h, c->pyr_plan);
-        else hipLaunchKernelGGL(k_pyr_fused<false>, grd, dim3(PF_THREADS), c->pyr_plan.lds_bytes, c->stream, djobs, n, c->d_pyr, g, src_w, src_h, c->pyr_plan);
+        RtGatherArgs a = {};
+        a.chunks = 1;
+        if (ga && ga->njobs > 0) { a = *ga; if (gathered) *gathered = true; }
+        const dim3 grd(((n + 7) / 8) * 8 * c->pyr_plan.nstrips + a.njobs * a.chunks);      // jobs in groups of 8 (one per XCD), all strips of a job on its XCD
+        if (decimate) hipLaunchKernelGGL(k_pyr_fused<true>, grd, dim3(PF_THREADS), c->pyr_plan.lds_bytes, c->stream, djobs, n, c->d_pyr, g, src_w, src_h, c->pyr_plan, a);
+        else hipLaunchKernelGGL(k_pyr_fused<false>, grd, dim3(PF_THREADS), c->pyr_plan.lds_bytes, c->stream, djobs, n, c->d_pyr, g, src_w, src_h, c->pyr_plan, a);
         tm_end(c);
         HIPCHK(c, hipGetLastError());
         return 0;
@@ -407,8 +418,11 @@ int launch_pyramid(svslam_ctx *c, const PyrJob *djobs, int n, bool decimate, int
     return 0;
 }
 
+// more (optional): called once the pyramid's own jobs are staged and before its launch; stages the caller's further inputs behind
+// them (the arena is not reset again) and may fill *ga to let the resident-tracking gather ride on the pyramid launch
+struct PyrMore { std::function<int(RtGatherArgs *)> stage; bool gathered = false; };
 int pyramid_common(svslam_ctx *c, int n, const int *slots, const void *const *imgs, const int *strides,
-                   int src_is_device, bool decimate, int src_w, int src_h, bool sync)
+                   int src_is_device, bool decimate, int src_w, int src_h, bool sync, PyrMore *more = nullptr)
 {
     if (n <= 0) return 0;
     if (n > c->lim.max_jobs) return fail(c, "pyramid: %d jobs > max_jobs %d", n, c->lim.max_jobs);
@@ -446,7 +460,9 @@ int pyramid_common(svslam_ctx *c, int n, const int *slots, const void *const *im
         }
     }
     if (!c->zero_copy && h2d(c, ojobs, c->ar.off)) return -1;
-    if (launch_pyramid(c, dpz<PyrJob>(c, ojobs), n, decimate, src_w, src_h)) return -1;
+    RtGatherArgs ga = {};
+    if (more && more->stage(&ga)) return -1;
+    if (launch_pyramid(c, dpz<PyrJob>(c, ojobs), n, decimate, src_w, src_h, more ? &ga : nullptr, more ? &more->gathered : nullptr)) return -1;
     if (sync) return d2h_sync(c, 0, 0);
     return 0;
 }
@@ -1997,67 +2013,76 @@ int svslam_rtrack_batch(svslam_ctx *c, int njobs, svslam_rtrack_job *jobs, const
         if (j.pt_ofs < 0 || j.pt_ofs + j.npts > total_pts) return fail(c, "rtrack: job %d point range out of bounds", i);
         slots[i] = j.next_slot;
     }
-    {
-        const bool dec = c->src_w > 0;
-        if (pyramid_common(c, njobs, slots.data(), next_imgs, strides, src_is_device, dec, dec ? c->src_w : c->geom.w[0],
-                           dec ? c->src_h : c->geom.h[0], false)) return -1;
-    }
     int maxn = 0;
     for (int i = 0; i < njobs; ++i) maxn = std::max(maxn, jobs[i].npts);
     const size_t T = (size_t)std::max(total_pts, 1);
-    size_t base = c->ar.off;
-    size_t olk = c->ar.take(sizeof(LkJob) * njobs);
-    size_t ocam = c->ar.take(32);
-    size_t opj = c->ar.take(sizeof(PoseJob) * njobs);
-    size_t ort = c->ar.take(sizeof(RtJob) * njobs);
-    size_t in_end = c->ar.off;
-    size_t oxy = c->ar.take(sizeof(float) * 2 * T);        // compacted survivors for the host
-    size_t ompo = c->ar.take(sizeof(int) * T);
-    size_t out_end = c->ar.off;
-    // device-only scratch of this call
-    size_t oprev = c->ar.take(sizeof(float) * 2 * T);
-    size_t onext = c->ar.take(sizeof(float) * 2 * T);
-    size_t omp = c->ar.take(T);
-    size_t oxyz = c->ar.take(sizeof(double) * 3 * T);
-    size_t ostat = c->ar.take(T);
-    size_t oerr = c->ar.take(sizeof(float) * T);
-    size_t oval = c->ar.take(T);
-    size_t oout = c->ar.take(T);
-    size_t ontr = c->ar.take(sizeof(int) * njobs);
-    if (c->ar.off > c->ar.cap) return fail(c, "rtrack: staging arena too small (%zu > %zu bytes)", c->ar.off, c->ar.cap);
-    LkJob *lj = hp<LkJob>(c, olk);
-    PoseJob *pj = hp<PoseJob>(c, opj);
-    RtJob *rj = hp<RtJob>(c, ort);
-    for (int i = 0; i < njobs; ++i) {
-        const svslam_rtrack_job &j = jobs[i];
-        lj[i].prev_slot = j.prev_slot; lj[i].next_slot = j.next_slot; lj[i].pt_ofs = j.pt_ofs; lj[i].npts = j.npts;
-        pj[i].pt_ofs = j.pt_ofs; pj[i].npts = j.npts;
-        memcpy(pj[i].pose, j.pose, 56);
-        pj[i].n_inlier = 0; pj[i].pad = 0;
-        rj[i].stream = j.stream; rj[i].pt_ofs = j.pt_ofs; rj[i].npts = j.npts; rj[i].src_buf = c->rt_which[(size_t)j.stream];
-        memcpy(rj[i].T_cam_w, j.T_cam_w, 56);
-        rj[i].n_tracked = rj[i].n_edges = rj[i].n_outlier = 0; rj[i].pad = 0;
+    size_t olk = 0, ocam = 0, opj = 0, ort = 0, in_end = 0, oxy = 0, ompo = 0, out_end = 0, oprev = 0, onext = 0, omp = 0, oxyz = 0, ostat = 0,
+           oerr = 0, oout = 0;
+    LkJob *lj = nullptr;
+    PoseJob *pj = nullptr;
+    RtJob *rj = nullptr;
+    // this call's inputs are staged behind the pyramid's jobs and before its launch, so that the gather can ride on it
+    PyrMore more;
+    more.stage = [&](RtGatherArgs *ga) -> int {
+        const size_t base = c->ar.off;
+        olk = c->ar.take(sizeof(LkJob) * njobs);
+        ocam = c->ar.take(32);
+        opj = c->ar.take(sizeof(PoseJob) * njobs);
+        ort = c->ar.take(sizeof(RtJob) * njobs);
+        in_end = c->ar.off;
+        oxy = c->ar.take(sizeof(float) * 2 * T);        // compacted survivors for the host
+        ompo = c->ar.take(sizeof(int) * T);
+        out_end = c->ar.off;
+        // device-only scratch of this call
+        oprev = c->ar.take(sizeof(float) * 2 * T);
+        onext = c->ar.take(sizeof(float) * 2 * T);
+        omp = c->ar.take(T);
+        oxyz = c->ar.take(sizeof(double) * 3 * T);
+        ostat = c->ar.take(T);
+        oerr = c->ar.take(sizeof(float) * T);
+        oout = c->ar.take(T);
+        if (c->ar.off > c->ar.cap) return fail(c, "rtrack: staging arena too small (%zu > %zu bytes)", c->ar.off, c->ar.cap);
+        lj = hp<LkJob>(c, olk);
+        pj = hp<PoseJob>(c, opj);
+        rj = hp<RtJob>(c, ort);
+        for (int i = 0; i < njobs; ++i) {
+            const svslam_rtrack_job &j = jobs[i];
+            lj[i].prev_slot = j.prev_slot; lj[i].next_slot = j.next_slot; lj[i].pt_ofs = j.pt_ofs; lj[i].npts = j.npts;
+            pj[i].pt_ofs = j.pt_ofs; pj[i].npts = j.npts;
+            memcpy(pj[i].pose, j.pose, 56);
+            pj[i].n_inlier = 0; pj[i].pad = 0;
+            rj[i].stream = j.stream; rj[i].pt_ofs = j.pt_ofs; rj[i].npts = j.npts; rj[i].src_buf = c->rt_which[(size_t)j.stream];
+            memcpy(rj[i].T_cam_w, j.T_cam_w, 56);
+            rj[i].n_tracked = rj[i].n_edges = rj[i].n_outlier = 0; rj[i].pad = 0;
+        }
+        memcpy(hp<void>(c, ocam), cam, 32);
+        if (!c->zero_copy && h2d(c, base, in_end)) return -1;
+        if (maxn > 0)
+            *ga = RtGatherArgs{ dpz<RtJob>(c, ort), c->rt, dpz<double>(c, ocam), dp<float2>(c, oprev), dp<float2>(c, onext), dp<uint8_t>(c, omp),
+                                dp<double>(c, oxyz), njobs, cdiv(maxn, PF_THREADS) };
+        return 0;
+    };
+    {
+        const bool dec = c->src_w > 0;
+        if (pyramid_common(c, njobs, slots.data(), next_imgs, strides, src_is_device, dec, dec ? c->src_w : c->geom.w[0],
+                           dec ? c->src_h : c->geom.h[0], false, &more)) return -1;
     }
-    memcpy(hp<void>(c, ocam), cam, 32);
-    if (!c->zero_copy && h2d(c, base, in_end)) return -1;
     if (maxn > 0) {
-        hipLaunchKernelGGL(k_rt_gather, dim3(cdiv(maxn, 256), njobs), dim3(256), 0, c->stream, dpz<RtJob>(c, ort), c->rt,
-                           dpz<double>(c, ocam), dp<float2>(c, oprev), dp<float2>(c, onext), dp<uint8_t>(c, omp), dp<double>(c, oxyz));
+        if (!more.gathered)
+            hipLaunchKernelGGL(k_rt_gather, dim3(cdiv(maxn, 256), njobs), dim3(256), 0, c->stream, dpz<RtJob>(c, ort), c->rt,
+                               dpz<double>(c, ocam), dp<float2>(c, oprev), dp<float2>(c, onext), dp<uint8_t>(c, omp), dp<double>(c, oxyz));
         tm_begin(c, FAM_LK, total_pts);
         launch_lk(c, njobs, maxn, dpz<LkJob>(c, olk), dp<float2>(c, oprev), dp<float2>(c, onext), dp<uint8_t>(c, ostat),
                   dp<float>(c, oerr), p);
         tm_end(c);
-        hipLaunchKernelGGL(k_track_filter, dim3(njobs), dim3(256), 0, c->stream,
-                           reinterpret_cast<const LkJobView *>(dpz<LkJob>(c, olk)), dp<float2>(c, onext),
-                           dp<uint8_t>(c, ostat), dp<uint8_t>(c, omp), dp<uint8_t>(c, oval), dp<int>(c, ontr),
-                           c->geom.w[0], c->geom.h[0]);
     }
+    // survivor filter, pose-only LM and the hand-over of the survivors in one launch (k_geom.h: k_pose_only<.., true>)
+    const PoFuse fz = { dp<uint8_t>(c, ostat), dp<uint8_t>(c, omp), c->geom.w[0], c->geom.h[0], dpz<RtJob>(c, ort), c->rt,
+                        dpz<float2>(c, oxy), dpz<int>(c, ompo) };
     tm_begin(c, FAM_POSE, njobs);
     launch_pose_only(c, njobs, dpz<PoseJob>(c, opj), dpz<double>(c, ocam), dp<double>(c, oxyz), dp<float2>(c, onext),
-                     dp<uint8_t>(c, oval), dp<uint8_t>(c, oout), chi2_th, 4, 10);
+                     nullptr, dp<uint8_t>(c, oout), chi2_th, 4, 10, &fz);
     tm_end(c);
-    hipLaunchKernelGGL(k_rt_finish, dim3(njobs), dim3(64), 0, c->stream, dpz<RtJob>(c, ort), c->rt, dp<float2>(c, onext),
-                       dp<uint8_t>(c, ostat), dp<uint8_t>(c, oout), dp<double>(c, oxyz), dpz<float2>(c, oxy), dpz<int>(c, ompo));
     HIPCHK(c, hipGetLastError());
     // pose jobs, rt jobs (+ the compacted survivors unless the caller keeps its map on the device and passes no buffers);
     // zero_copy: the kernels wrote them where the host reads them, only the completion is awaited
