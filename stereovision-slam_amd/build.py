@@ -21,6 +21,8 @@ ROOT = os.path.dirname(HERE)
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
              "-Wno-unused-value"]
+if os.environ.get("SVS_IEEE_DIV"):      # parity-debugging build: IEEE division / sqrt instead of estimate + Newton in the LM kernels
+    HIP_FLAGS.append("-DSVS_IEEE_DIV")
 
 
 def _newer(target, sources):

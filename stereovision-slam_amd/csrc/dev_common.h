@@ -206,8 +206,14 @@ __device__ __forceinline__ void d_se3_mul(const double *A, const double *B, doub
 // 1 / x: hardware estimate + two Newton steps (<= 1 ulp of the correctly rounded quotient).  The IEEE division expands to
 // a dozen dependent instructions; the LM kernels have several on the serial critical path of every trial.  0, inf, NaN
 // and denormals (estimate inf) keep the raw estimate, i.e. what the division returns.
+// -DSVS_IEEE_DIV (build.py: SVS_IEEE_DIV=1) is a parity-debugging build: every estimate-plus-Newton reciprocal / root of the
+// LM kernels (here, d_huber, d_ldlt6's pivots, the BA Cholesky's pivots) becomes the correctly rounded IEEE operation again,
+// so that a trajectory can be compared with the CPU oracle without the <= 1 ulp differences of the fast forms.
 __device__ __forceinline__ double d_rcp1(double x)
 {
+#ifdef SVS_IEEE_DIV
+    return 1.0 / x;
+#endif
     const double r0 = __builtin_amdgcn_rcp(x);
     double r = __builtin_fma(__builtin_fma(-x, r0, 1.0), r0, r0);
     r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
@@ -285,6 +291,7 @@ __device__ __forceinline__ void d_huber(double e2, double delta, double &rho0, d
 {
     double dsqr = delta * delta;
     if (e2 <= dsqr) { rho0 = e2; rho1 = 1.0; }
+#ifndef SVS_IEEE_DIV
     else if (e2 < 1e300) {
         // 1 / sqrt(e2): hardware estimate + two Newton steps, one correction of the root (e2 > delta^2: normal range)
         double y = __builtin_amdgcn_rsq(e2);
@@ -293,7 +300,9 @@ __device__ __forceinline__ void d_huber(double e2, double delta, double &rho0, d
         double sq = e2 * y;
         sq = __builtin_fma(__builtin_fma(-sq, sq, e2), 0.5 * y, sq);
         rho0 = 2 * sq * delta - dsqr; rho1 = delta * y;
-    } else { double sq = sqrt(e2); rho0 = 2 * sq * delta - dsqr; rho1 = delta / sq; }
+    }
+#endif
+    else { double sq = sqrt(e2); rho0 = 2 * sq * delta - dsqr; rho1 = delta / sq; }
 }
 #pragma clang fp contract(off)
 

@@ -589,9 +589,13 @@ __device__ __forceinline__ int ba_chol_solve(double *S, const int ld, const int 
             for (int m = 0; m < c; ++m) d -= Ld[c][m] * Ld[c][m];
             if (!(d > 0)) ok = 0;
             // rsqrt: hardware estimate + 2 Newton steps
+#ifdef SVS_IEEE_DIV
+            double y = 1.0 / sqrt(d);
+#else
             double y = __builtin_amdgcn_rsq(d);
             y = y * (1.5 - 0.5 * d * y * y);
             y = y * (1.5 - 0.5 * d * y * y);
+#endif
             inv[c] = y;
             Ld[c][c] = d * y;
 #pragma unroll

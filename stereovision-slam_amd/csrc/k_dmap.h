@@ -105,10 +105,10 @@ __device__ __forceinline__ int dm_exscan(int v, int *tmp, int tid, int *tot)
 
 // ---------------------------------------------------------------- keyframe insertion (tracked frames)
 __global__ void __launch_bounds__(DM_THREADS)
-k_dmap_begin(DmJob *jobs, DMap m, RtStore rs, DmEvicted *ev, int *ev_cursor, int ev_cap)
+k_dmap_begin(DmJob *jobs, DMap m, RtStore rs, DmEvicted *ev, int *ev_cursor, int ev_quota)
 {
     __shared__ int tmp[DM_THREADS];
-    __shared__ int s_base, s_room, s_cnt;
+    __shared__ int s_base, s_room;
     DmJob &jb = jobs[blockIdx.x];
     const int tid = threadIdx.x, s = jb.stream;
     if (tid == 0) {
@@ -149,27 +149,28 @@ k_dmap_begin(DmJob *jobs, DMap m, RtStore rs, DmEvicted *ev, int *ev_cursor, int
     __threadfence_block();
     // landmarks nothing can reach any more (no observation, outside the window, not carried by tracking) free their slot.
     // The reference keeps every landmark for saveSLAMOutputInFile (src/visual_odometry.cpp:226-304): id and last position
-    // of each go to the batch's evicted list first (one reservation per job; what a full list cannot take stays where it is until
-    // the stream's next keyframe — nothing is lost, the slots just stay taken that long).
+    // of each go to the batch's evicted list first.  A job hands over at most ev_quota landmarks per call (the list holds
+    // quota x jobs records, so the reservation below never overflows and WHICH landmarks a job frees depends on nothing but its
+    // own map: the first ev_quota candidates in (thread, slot) order); the rest stay where they are until the stream's next
+    // keyframe — nothing is lost, the slots just stay taken that long.
     int mine = 0;
     for (int l = tid; l < m.NL; l += DM_THREADS)
         mine += (m.lm_st[L + l] == 2 && m.lm_obs[L + l] == 0 && m.lm_stamp[L + l] != jb.stamp) ? 1 : 0;
     int tot;
-    (void)dm_exscan(mine, tmp, tid, &tot);
+    const int pos = dm_exscan(mine, tmp, tid, &tot);
     if (tid == 0) {
-        const int base = tot > 0 ? atomicAdd(ev_cursor, tot) : 0;
-        const int room = min(tot, max(0, ev_cap - base));
-        if (room < tot) atomicSub(ev_cursor, tot - room);
-        s_base = base; s_room = room; s_cnt = 0;
-        jb.ev_ofs = base; jb.ev_n = room;
+        const int room = min(tot, ev_quota);
+        s_base = room > 0 ? atomicAdd(ev_cursor, room) : 0; s_room = room;
+        jb.ev_ofs = s_base; jb.ev_n = room;
     }
     __syncthreads();
     if (s_room == 0) return;
+    int k = pos;
     for (int l = tid; l < m.NL; l += DM_THREADS)
         if (m.lm_st[L + l] == 2 && m.lm_obs[L + l] == 0 && m.lm_stamp[L + l] != jb.stamp) {
-            const int k = atomicAdd(&s_cnt, 1);
-            if (k >= s_room) continue;                     // no room left in the list: this one waits for the next keyframe
+            if (k >= s_room) break;                        // over the quota: this one waits for the next keyframe
             DmEvicted &e = ev[s_base + k];
+            ++k;
             e.id = m.lm_id[L + l];
             e.pos[0] = (float)m.lm_pos[3 * (L + l)]; e.pos[1] = (float)m.lm_pos[3 * (L + l) + 1]; e.pos[2] = (float)m.lm_pos[3 * (L + l) + 2];
             m.lm_st[L + l] = 0; m.lm_id[L + l] = -1;

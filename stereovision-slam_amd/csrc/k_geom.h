@@ -114,9 +114,13 @@ __device__ __forceinline__ bool d_ldlt6(const double *H, const double *b, double
         // reciprocal of the pivot: hardware estimate + two Newton steps (<= 1 ulp from the quotient; the six divisions sit
         // on the serial critical path of every LM trial).  A non-positive / denormal pivot gives inf or NaN here like the
         // division would downstream: the trial is rejected by the finiteness test on its chi2 either way.
+#ifdef SVS_IEEE_DIV
+        double inv = 1.0 / dk;
+#else
         double inv = __builtin_amdgcn_rcp(dk);
         inv = __builtin_fma(__builtin_fma(-dk, inv, 1.0), inv, inv);
         inv = __builtin_fma(__builtin_fma(-dk, inv, 1.0), inv, inv);
+#endif
         Dinv[k] = inv;
 #pragma unroll
         for (int i = k + 1; i < 6; ++i) {

@@ -18,7 +18,15 @@
 #include <vector>
 
 #include <dlfcn.h>
-#include <rccl/rccl.h>          // types only: the library is bound with dlopen when a shared-map communicator is asked for
+// RCCL is bound with dlopen when a shared-map communicator is asked for; the few types and constants of its C API used here
+// are declared below (values of rccl.h, the NCCL ABI), so that building this library needs no RCCL headers
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclSum = 0, ncclMax = 2 } ncclRedOp_t;
+typedef enum { ncclDouble = 8 } ncclDataType_t;
+}
 #include "../../include/svslam.h"
 #include "../host/thread_pool.h"
 #include <atomic>
@@ -69,6 +77,7 @@ struct svslam_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     PyrGeom geom;
+    std::vector<unsigned> dm_seen; unsigned dm_seen_gen = 0;     // svslam_dmap_keyframe_batch: streams of the current call (duplicate check)
     PyrFusedPlan pyr_plan;        // all levels in one launch (k_pyr_fused), when the geometry allows it
     bool pyr_fused = false;
     uint8_t *d_pyr = nullptr;
@@ -1332,6 +1341,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
@@ -1369,7 +1379,7 @@ RcclApi *rccl_api(std::string *why)
         SVS_RCCL_SYM(GetUniqueId, "ncclGetUniqueId"); SVS_RCCL_SYM(CommInitRank, "ncclCommInitRank");
         SVS_RCCL_SYM(CommDestroy, "ncclCommDestroy"); SVS_RCCL_SYM(AllReduce, "ncclAllReduce");
         SVS_RCCL_SYM(GroupStart, "ncclGroupStart"); SVS_RCCL_SYM(GroupEnd, "ncclGroupEnd");
-        SVS_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+        SVS_RCCL_SYM(GetErrorString, "ncclGetErrorString"); SVS_RCCL_SYM(CommAbort, "ncclCommAbort");
 #undef SVS_RCCL_SYM
     });
     if (!err.empty()) { if (why) *why = err; return nullptr; }
@@ -1422,8 +1432,23 @@ int svslam_sba_comm_destroy(svslam_ctx *c)
 
 // The whole optimize(iters) of the open shard.  trace (optional): 6 doubles per LM trial as svslam_lm_trace;
 // stats (optional, 4 doubles): trials, milliseconds in total, mean milliseconds per trial, all-reduced bytes per trial.
+static int sba_solve_impl(svslam_ctx *c, int iters, int *iters_done, double *lambda_out, double *trace, int trace_cap,
+                          int *n_trace, double *stats);
+// A rank that fails inside the LM loop (launch, copy, collective) would leave its peers waiting in their next all-reduce:
+// the communicator is aborted (ncclCommAbort), so the peers' collectives return with an error instead of hanging; the
+// context needs a new communicator (svslam_sba_comm_init) before the next shared-map solve.
 int svslam_sba_solve(svslam_ctx *c, int iters, int *iters_done, double *lambda_out, double *trace, int trace_cap,
                      int *n_trace, double *stats)
+{
+    const int rc = sba_solve_impl(c, iters, iters_done, lambda_out, trace, trace_cap, n_trace, stats);
+    if (rc != 0 && c->sbac.comm) {
+        RcclApi *r = rccl_api(nullptr);
+        if (r && r->CommAbort) { (void)r->CommAbort(c->sbac.comm); c->sbac.comm = nullptr; c->err += " (shared-map communicator aborted)"; }
+    }
+    return rc;
+}
+static int sba_solve_impl(svslam_ctx *c, int iters, int *iters_done, double *lambda_out, double *trace, int trace_cap,
+                          int *n_trace, double *stats)
 {
     if (!c->sba.open) return fail(c, "sba_solve: no shard is open");
     RcclApi *r = c->sbac.comm ? rccl_api(nullptr) : nullptr;
@@ -1451,6 +1476,9 @@ int svslam_sba_solve(svslam_ctx *c, int iters, int *iters_done, double *lambda_o
             double md = hio[osc + 1];
             for (int i = 0; i < n; ++i) md = std::max(md, std::fabs(hio[ohd + i]));
             lam = 1e-5 * md; ni = 2;
+            // the diagonal sits inside the range every trial all-reduces (S | bs | bp | hd | chi2) and no later phase rewrites
+            // it: zeroed here, it stays zero under the sums instead of growing by the rank count per trial
+            HIPCHK(c, hipMemsetAsync(dio + ohd, 0, sizeof(double) * (size_t)n, c->stream));
         }
         double rho = 0; int qmax = 0;
         for (;;) {
@@ -1541,6 +1569,11 @@ int svslam_dmap_keyframe_batch(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, 
     for (int i = 0; i < njobs; ++i) {
         svslam_dmap_job &j = jobs[i];
         if (j.stream < 0 || j.stream >= c->lim.max_streams) return fail(c, "dmap: job %d stream %d out of range", i, j.stream);
+        // two jobs of one call on the same stream would work on the same map arenas at once
+        if (c->dm_seen.size() != (size_t)c->lim.max_streams) c->dm_seen.assign((size_t)c->lim.max_streams, 0u);
+        if (i == 0 && ++c->dm_seen_gen == 0u) { std::fill(c->dm_seen.begin(), c->dm_seen.end(), 0u); c->dm_seen_gen = 1u; }
+        if (c->dm_seen[(size_t)j.stream] == c->dm_seen_gen) return fail(c, "dmap: stream %d appears twice in one call (job %d)", j.stream, i);
+        c->dm_seen[(size_t)j.stream] = c->dm_seen_gen;
         if (opt_only) {
             if (j.npts != c->rt_count[(size_t)j.stream]) return fail(c, "dmap: job %d says %d features, stream %d holds %d", i, j.npts, j.stream, c->rt_count[(size_t)j.stream]);
             continue;
@@ -1606,7 +1639,7 @@ int svslam_dmap_keyframe_batch(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, 
     auto bp_ = [&](size_t off) { return bab + off; };
     // (test hook SVSLAM_DMAP_EVICT_CAP: a smaller list for the whole call, to exercise the "waits for the next keyframe" path)
     static const int ev_cap_env = []{ const char *e = std::getenv("SVSLAM_DMAP_EVICT_CAP"); return e ? atoi(e) : 0; }();
-    const int ev_cap = ev_cap_env > 0 ? std::min(ev_cap_env, njobs * SVSLAM_DMAP_EVICT_PER_JOB) : njobs * SVSLAM_DMAP_EVICT_PER_JOB;
+    const int ev_cap = ev_cap_env > 0 ? std::max(njobs, std::min(ev_cap_env, njobs * SVSLAM_DMAP_EVICT_PER_JOB)) : njobs * SVSLAM_DMAP_EVICT_PER_JOB;
     size_t oev = c->ar.take(sizeof(DmEvicted) * (size_t)ev_cap);
     if (c->ar.off > c->ar.cap) return fail(c, "dmap: staging arena too small (%zu > %zu bytes); fewer jobs per call", c->ar.off, c->ar.cap);
     DmJob *hj = hp<DmJob>(c, ojobs);
@@ -1645,7 +1678,8 @@ int svslam_dmap_keyframe_batch(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, 
     int *d_evcur = defer ? dp<int>(c, oevc) + 1 : reinterpret_cast<int *>(bp_(oflag)) + 1;
     DmJob *dj = dp<DmJob>(c, ojobs);
     if (!opt_only) {
-    hipLaunchKernelGGL(k_dmap_begin, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, c->rt, dp<DmEvicted>(c, oev), d_evcur, ev_cap);
+    // every job may hand over ev_cap / njobs landmarks per call: what a job evicts does not depend on the other jobs' timing
+    hipLaunchKernelGGL(k_dmap_begin, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, c->rt, dp<DmEvicted>(c, oev), d_evcur, std::max(1, ev_cap / njobs));
     if (launch_gftt(c, njobs, dp<GfttJob>(c, ogj), m.f_xy, MC, 0.01, 20.0, dp<float2>(c, ocor), dp<int>(c, oncor))) return -1;   // src/frontend.cpp:24
     hipLaunchKernelGGL(k_dmap_stereo_prep, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, prm, dp<float2>(c, ocor), dp<int>(c, oncor), MC,
                        dp<LkJob>(c, olk), dp<float2>(c, oprev), dp<float2>(c, onext));

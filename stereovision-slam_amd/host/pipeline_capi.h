@@ -46,6 +46,8 @@ typedef struct svs_pipe_counters {
     long long ba_pairs, ba_trials;           /* block pairs of the Schur complements, LM trials: the flop accounting of bench.py */
     long long lm_total, lm_resident;         /* landmarks ever created / MapPoint objects the host still holds (the rest
                                                 were evicted to the 16-byte archive, Map::ReleaseRetired)              */
+    long long lm_full;                       /* device map: keyframes that ran out of landmark slots (max_lm = LIVE landmarks of a
+                                                stream there); their surplus points were not created                     */
 } svs_pipe_counters;
 
 void *svs_pipe_create(const svs_pipe_config *cfg, int nstreams, int device);

@@ -168,7 +168,9 @@ int svs_pipe_counters_get(void *p, svs_pipe_counters *out)
     out->ns_step = c.ns_step; out->ns_kernel_calls = c.ns_kernel_calls;
     out->corners_dropped = c.corners_dropped; out->ba_skipped = c.ba_skipped;
     out->ba_pairs = c.ba_pairs; out->ba_trials = c.ba_trials;
-    out->lm_total = out->lm_resident = 0;
+    out->lm_full = c.lm_full;
+    out->lm_total = c.lm_created_dev;       // (device map: the host Map allocates no ids; host map: lm_created_dev stays 0)
+    out->lm_resident = 0;
     svs::Pipeline<SVS_PIPE_KERNELS> &pp = *static_cast<PipeHandle *>(p)->pipe;
     for (int s = 0; s < pp.nstreams(); ++s) {
         out->lm_total += (long long)pp.stream(s).map.num_landmarks();

@@ -356,6 +356,10 @@ struct Counters {                      // workload accounting for the roofline (
     long long pyr_left = 0, pyr_right = 0;
     long long ns_step = 0, ns_kernel_calls = 0;   // wall time inside step() / inside the C-ABI calls
     long long corners_dropped = 0, ba_skipped = 0; // per-stream capacity events (Config::max_*)
+    // device-resident map: keyframes whose new landmarks did not all find a slot (there max_lm is the number of LIVE landmark
+    // slots of a stream — active, observed-inactive, tracked, evictions waiting for the hand-over list — not the size of one BA
+    // problem; the surplus points are not created and the run leaves the reference's), and the landmarks it did create
+    long long lm_full = 0, lm_created_dev = 0;
 };
 
 // BA job bookkeeping between gather and scatter (per stream, reused)
@@ -763,6 +767,8 @@ private:
             MS.push_back(DS[i]);
             cnt_.tri_pts += j.n_tri_in;
             if (j.flags & 4) cnt_.ba_skipped++;
+            if (j.flags & 2) cnt_.lm_full++;
+            cnt_.lm_created_dev += j.n_tri_ok;
             if (prm.ba_iters > 0 && i < defer_from) ApplyDeviceBa(st, j);
         }
         if (defer_from < n) {                  // the deferred batch: its jobs and streams wait for DmCollect

@@ -30,7 +30,7 @@ class Counters(C.Structure):
     _fields_ = [(n, C.c_longlong) for n in
                 ("frames", "keyframes", "track_pts", "pose_edges", "gftt_calls", "gftt_rects", "corners", "right_pts",
                  "tri_pts", "ba_calls", "ba_edges", "ba_kf", "ba_lm", "ba_iters", "pyr_left", "pyr_right", "ns_step",
-                 "ns_kernel_calls", "corners_dropped", "ba_skipped", "ba_pairs", "ba_trials", "lm_total", "lm_resident")]
+                 "ns_kernel_calls", "corners_dropped", "ba_skipped", "ba_pairs", "ba_trials", "lm_total", "lm_resident", "lm_full")]
 
 
 RESULT_DTYPE = np.dtype([("pose", np.float64, 7), ("status", np.int32), ("is_keyframe", np.int32),
