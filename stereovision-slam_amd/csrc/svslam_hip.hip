@@ -292,7 +292,9 @@ hipError_t wait_stream(svslam_ctx *c)
         const hipError_t e = hipEventQuery(c->done);
         if (e != hipErrorNotReady) return e;
         const long long dt = now_ns() - t0;
-        if (dt < 10000) continue;
+        // low-latency mode (a few cameras per GPU): the wait IS the frame time, so the thread keeps polling — a nap of 20 us
+        // plus its wake-up was a tenth of a lone camera's frame; beyond a few ms (nothing of that mode takes that long) it naps
+        if (dt < (c->low_latency ? 3000000LL : 10000LL)) continue;
         // back off with the age of the wait: a 100 us kernel is polled every ~20 us, a
         // multi-millisecond BA batch every ~150 us (overshoot stays below ~1/8 of the wait)
         static const long long nap_min = []{ const char *e = std::getenv("SVSLAM_POLL_MIN_US"); return e ? atoll(e) * 1000 : 20000LL; }();

@@ -30,19 +30,21 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
 # that bench.py reports (units_whole_process); KB -> bytes (x1024, the counter's documented unit)
 try:
     u = json.loads(open("gpurun_out/pmc_FETCH_SIZE_bench.json").read().strip().splitlines()[-1])["units_whole_process"]
-    fam = {"local_ba": (["k_local_ba_t<0>", "k_ba_build", "k_dmap_ba_gather", "k_dmap_ba_scatter"], "job", u["ba_calls"]),
+    fam = {"local_ba": (["k_local_ba_t<0", "k_ba_build", "k_dmap_ba_gather", "k_dmap_ba_scatter"], "job", u["ba_calls"]),
            "lk": (["k_lk"], "point", u["track_pts"] + u["right_pts"]),
-           "pose_only": (["k_pose_only<1>", "k_pose_only<0>"], "job", u["frames"]),
-           "pyramid": (["k_pyr_fused<false>", "k_pyr_fused<true>"], "image", u["pyr_left"] + u["pyr_right"]),
-           "gftt": (["k_gftt_eig3<false>", "k_gftt_select2"], "image", u["gftt_calls"]),
+           "pose_only": (["k_pose_only<"], "job", u["frames"]),
+           "pyramid": (["k_pyr_fused<"], "image", u["pyr_left"] + u["pyr_right"]),
+           "gftt": (["k_gftt_eig3<", "k_gftt_select2"], "image", u["gftt_calls"]),
            "triangulate": (["k_triangulate"], "point", u["tri_pts"])}
     per = {}
+    def tot(ctr, prefixes):       # kernels are matched by name prefix (template arguments vary with the build)
+        return sum(v.get("total_KB", 0.0) for k, v in out[ctr].items() if any(k.startswith(p_) for p_ in prefixes))
     for f, (ks, unit, n) in fam.items():
         # FETCH_SIZE counts half the bytes on gfx950 for every access width (tools/pmc_calib.sh: 0.500 x for byte,
         # dword, 8- and 16-byte reads of a 1 GiB buffer; WRITE_SIZE is exact): corrected here, raw value kept
-        fb_raw = sum(out["FETCH_SIZE"].get(k, {}).get("total_KB", 0.0) for k in ks) * 1024 / max(n, 1)
+        fb_raw = tot("FETCH_SIZE", ks) * 1024 / max(n, 1)
         fb = 2.0 * fb_raw
-        wb = sum(out["WRITE_SIZE"].get(k, {}).get("total_KB", 0.0) for k in ks) * 1024 / max(n, 1)
+        wb = tot("WRITE_SIZE", ks) * 1024 / max(n, 1)
         per[f] = {"unit": unit, "units_in_run": n, "kernels": ks, "fetch_bytes_raw": round(fb_raw), "fetch_bytes": round(fb), "write_bytes": round(wb), "bytes": round(fb + wb)}
     out["per_unit"] = per
     out["units_whole_process"] = u
