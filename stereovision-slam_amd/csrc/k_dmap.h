@@ -320,9 +320,13 @@ k_dmap_commit(DmJob *jobs, DMap m, const double *tri_xyz, const uint8_t *tri_ok,
 // ---------------------------------------------------------------- Backend::Optimize: the problem, in k_ba_build's input layout
 // Per job the BA arrays have fixed strides (max_kf poses, NL points, max_obs edges).  LDS: sort keys [NL] u64,
 // local index by slot [NL] i32, edge counts / starts [NL + 1] i32.
-#define DMG_THREADS 1024
-static inline size_t dmg_lds_bytes(int NL) { return (size_t)NL * 8 + (size_t)NL * 4 + ((size_t)NL + 2) * 4 + DMG_THREADS * 4 + 256; }
+// DMG_T threads per problem: 1024 for a few problems per call (the latency of the sort and the scans is the call's latency),
+// 512 for a batch (more problems per CU at once: the 1024-thread form took 836 us per ~300 problems beside the other groups'
+// kernels where this one takes 448)
+template <int DMG_T> static inline size_t dmg_lds_bytes_t(int NL) { return (size_t)NL * 8 + (size_t)NL * 4 + ((size_t)NL + 2) * 4 + DMG_T * 4 + 256; }
+static inline size_t dmg_lds_bytes(int NL) { return dmg_lds_bytes_t<1024>(NL); }      // the larger of the two
 
+template <int DMG_THREADS>
 __global__ void __launch_bounds__(DMG_THREADS)
 k_dmap_ba_gather(DmJob *jobs, DMap m, DmParams prm, BaDev *badev, double *poses, double *pts, unsigned int *packed, float2 *uv,
                  int *edge_ref, int *lm_slot_of, int max_kf, int tile_cap, size_t aux_stride)

@@ -623,8 +623,10 @@ int svslam_create(const svslam_limits *lim, svslam_ctx **out)
         HIPCHK(c, hipMemsetAsync(m.kf_frame, 0xff, KF * 8, c->stream));
         HIPCHK(c, hipMemsetAsync(m.lm_id, 0xff, LM * 4, c->stream));
         HIPCHK(c, hipMemsetAsync(m.lm_stamp, 0xff, LM * 4, c->stream));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_dmap_ba_gather), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)dmg_lds_bytes(lim->max_lm)));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_dmap_ba_gather<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)dmg_lds_bytes_t<1024>(lim->max_lm)));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_dmap_ba_gather<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)dmg_lds_bytes_t<512>(lim->max_lm)));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -1708,8 +1710,12 @@ int svslam_dmap_keyframe_batch(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, 
         const BaCams *b_cams = defer ? reinterpret_cast<const BaCams *>(bp_(obcams)) : dp<BaCams>(c, ocams);
         hipStream_t main_stream = c->stream;
         if (!defer) tm_begin(c, FAM_BA, njobs);
-        hipLaunchKernelGGL(k_dmap_ba_gather, dim3(njobs), dim3(DMG_THREADS), dmg_lds_bytes(NL), c->stream, dj, m, prm, b_bd, b_poses, b_pts,
-                           reinterpret_cast<unsigned int *>(bp_(opk)), reinterpret_cast<float2 *>(bp_(ouv)), b_ref, b_lms, MK, tile_cap, aux_stride);
+        if (njobs <= SVSLAM_LL_MAX_PROBLEMS)
+            hipLaunchKernelGGL(k_dmap_ba_gather<1024>, dim3(njobs), dim3(1024), dmg_lds_bytes_t<1024>(NL), c->stream, dj, m, prm, b_bd, b_poses, b_pts,
+                               reinterpret_cast<unsigned int *>(bp_(opk)), reinterpret_cast<float2 *>(bp_(ouv)), b_ref, b_lms, MK, tile_cap, aux_stride);
+        else
+            hipLaunchKernelGGL(k_dmap_ba_gather<512>, dim3(njobs), dim3(512), dmg_lds_bytes_t<512>(NL), c->stream, dj, m, prm, b_bd, b_poses, b_pts,
+                               reinterpret_cast<unsigned int *>(bp_(opk)), reinterpret_cast<float2 *>(bp_(ouv)), b_ref, b_lms, MK, tile_cap, aux_stride);
         if (defer) {
             // the solve leaves this call's stream: a copy of the jobs (the scatter needs streams, window slots) and of the
             // cameras goes with the problem; the second stream picks up behind the gather
