@@ -226,5 +226,12 @@ def test_device_map_with_the_backend_beside_the_frontend(svs):
         assert cnt["ba_calls"] >= cnt["keyframes"] - len(seeds) and cnt["ba_calls"] > 0, (name, cnt["ba_calls"], cnt["keyframes"])
         assert cnt["ba_trials"] >= cnt["ba_iters"] > 0 and cnt["ba_pairs"] > cnt["ba_edges"] / 4
     assert runs["off"][1]["ba_calls"] == 0
+    # with the backend off the device map must do what the host map does — no optimisation AND no
+    # observation removal (the gather / solve / scatter chain is skipped, not run with zero iterations)
+    pipe, out_h, cnt_h = _run(svs, pl, pl.default_config(W, H, device_map=0, backend_on=0), seeds, N, frames)
+    pipe.close()
+    for k in ("status", "is_keyframe", "n_features", "n_inliers", "keyframe_id"):
+        assert np.array_equal(out_h[k], runs["off"][0][k]), k
+    assert np.array_equal(out_h["pose"], runs["off"][0]["pose"])
     a_sync, a1, a4 = ate(runs["sync"][0]), ate(runs["lag1"][0]), ate(runs["lag4"][0])
     assert a1.mean() < 2.0 * a_sync.mean() + 0.05 and a4.mean() < 2.5 * a_sync.mean() + 0.05, (a_sync, a1, a4)
