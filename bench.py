@@ -192,10 +192,10 @@ def main():
                     help="keep every stream's map (window, features, landmarks, observations) on the HOST as in rounds 1-2; "
                          "default: the map lives in HBM and the keyframe path is one chain of kernels (svslam_dmap_*) — "
                          "bit-identical results, a fraction of the host CPU")
-    ap.add_argument("--full-res-streams", type=int, default=2048,
+    ap.add_argument("--full-res-streams", type=int, default=8192,
                     help="streams of the value_full_res leg: after the reported run the script runs itself once more with the "
                          "frames stored at the camera's 1241x376 (BASELINE's metric names that size) and the 1/2 decimation "
-                         "fused into the pyramid, same steps / warm-up (0 = skip; one GPU only)")
+                         "fused into the pyramid, at most 20 + 5 steps so that the full-size frame ring fits (0 = skip; one GPU only)")
     ap.add_argument("--full-res", action="store_true",
                     help="keep the frames in HBM at the camera's 1241x376 and fuse the reference's 1/2 "
                          "decimation (Dataset::NextFrame) into the pyramid's level 0 (SURVEY 8 row f3); 4x the "
@@ -602,8 +602,9 @@ def main():
         #      (src/dataset.cpp:126-129) into the pyramid's level 0: the same hot path plus the 4x larger frame read.
         if run_full_res:
             import subprocess
-            cmd = [sys.executable, os.path.abspath(__file__), "--full-res", "--streams", str(args.full_res_streams), "--steps", str(K),
-                   "--warmup", str(Wm), "--no-cpu-baseline", "--spread-windows", "0", "--host-input-steps", "0", "--solo-steps", "0",
+            # (at most 20 + 5 steps: a full-size frame ring of 8192 streams then fits the GPU's memory)
+            cmd = [sys.executable, os.path.abspath(__file__), "--full-res", "--streams", str(args.full_res_streams), "--steps", str(min(K, 20)),
+                   "--warmup", str(min(Wm, 5)), "--no-cpu-baseline", "--spread-windows", "0", "--host-input-steps", "0", "--solo-steps", "0",
                    "--full-res-streams", "0"]
             try:
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
@@ -613,7 +614,7 @@ def main():
                                          "checks": d["config"]["checks"],
                                          "how": "the same script run once more after the reported measurement: frames kept in HBM at "
                                                 "1241x376, 1/2 decimation fused into the pyramid kernel (SURVEY 8 row f3); fewer streams "
-                                                "because a frame is 4x the bytes"}
+                                                "and at most 20 + 5 steps because a frame is 4x the bytes"}
             except Exception as e:   # noqa: BLE001
                 out["value_full_res"] = {"error": repr(e)[:300]}
         print(json.dumps(out), flush=True)
