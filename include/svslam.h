@@ -86,7 +86,14 @@ int svslam_set_source_size(svslam_ctx *ctx, int src_w, int src_h);
  * the pose-only LM of EstimateCurrentPose (src/frontend.cpp:394-558) runs on four wavefronts per
  * job instead of one (about half the latency per frame, ~1.3x the arithmetic).  The two shapes
  * sum the normal equations in different orders: results agree to rounding, each is deterministic.
- * In this mode the blocking calls also wait inside the HIP runtime instead of sleep-polling.     */
+ * In this mode the blocking calls also wait inside the HIP runtime instead of sleep-polling.
+ * A local BA of at most a few problems (Backend::Optimize, src/backend.cpp:22-164) is then dealt over 4 / 8 / 16 workgroups per
+ * problem that meet at in-launch barriers.  Those need every workgroup resident at once, so the mode sizes itself from the
+ * device: shards x problems <= co-resident solver workgroups per CU x CUs (SVSLAM_LL_CUS=<n> tells it a smaller CU count, for
+ * a CU-masked process or a partition); calls with more problems — or a device without room for one — use one workgroup per
+ * problem, and a problem whose shards still do not all arrive (the CUs were busy with other work) is solved again that way
+ * inside the same call.  Restriction: the solver scratch is one per context — svslam_local_ba_submit / _batch are refused while
+ * a deferred local BA of the device map (svslam_dmap_params::ba_defer) is in flight on the context.                          */
 int svslam_set_low_latency(svslam_ctx *ctx, int on);
 /* test hook: read one level back (tight rows of *w bytes) */
 int svslam_pyramid_read(svslam_ctx *ctx, int slot, int level, uint8_t *out,
@@ -391,6 +398,9 @@ int svslam_debug_host_ns(svslam_ctx *ctx, long long *out8);
 /* test hook: shard descriptors of the last low-latency local-BA call, 8 ints per shard (landmarks, edges, blocks, tiles,
  * solver: 2 = resident kernel / 1 = streaming kernel, active poses, mask of shards with edges, iterations) for `nproblems` problems */
 int svslam_debug_ll_shards(svslam_ctx *ctx, int nproblems, int *out8, int *shards_per_problem);
+/* test hook: the low-latency solver's residency guard (svslam_set_low_latency): shards per problem (0 = batch solver only),
+ * problems one call may hand to it, CUs counted, co-resident solver workgroups per CU                                      */
+int svslam_debug_ll_limits(svslam_ctx *ctx, int *out4);
 int svslam_debug_clock_mhz(svslam_ctx *ctx, int blocks, double ms, double *mhz);
 
 /* ---- device memory helpers for HBM-resident inputs (bench, pipelining) --- */

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "svslam_device_count", "svslam_dmap_keyframe_batch", "svslam_dmap_ba_collect", "svslam_dmap_read", "svslam_dmap_evicted", "svslam_sba_comm_unique_id", "svslam_sba_comm_init", "svslam_sba_comm_destroy", "svslam_sba_solve",
     "svslam_dev_alloc", "svslam_dev_free", "svslam_dev_upload", "svslam_dev_download", "svslam_sync",
     "svslam_timing_enable", "svslam_timing_reset", "svslam_timing_get", "svslam_ba_profile",
-    "svslam_set_host_threads", "svslam_debug_host_ns", "svslam_debug_ll_shards", "svslam_debug_clock_mhz", "svslam_lm_trace",
+    "svslam_set_host_threads", "svslam_debug_host_ns", "svslam_debug_ll_shards", "svslam_debug_ll_limits", "svslam_debug_clock_mhz", "svslam_lm_trace",
 ]
 
 FAMILIES = {"pyramid": 0, "lk": 1, "gftt": 2, "triangulate": 3, "pose_only": 4, "local_ba": 5}

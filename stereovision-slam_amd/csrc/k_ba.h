@@ -877,7 +877,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
     const int tid = tid0, lane = tid & 63, wv = tid >> 6;
     const int nkf = jd.nkf, nlm = jd.nlm, nobs = jd.nobs, na = jd.na, np = 6 * jd.na, nblk = jd.nblk;
     if (nobs <= 0 || na <= 0) { if (tid == 0) jd.iters_done = 0; return; }
-    if (MODE == 2 && jd.reserved == 2) return;             // every shard of the problem fits the resident layout: k_ba_ll (k_ba_ll.h) takes it
+    if (MODE == 2 && jd.reserved >= 2) return;             // 3: dropped by the test hook (k_ll_test_drop); 2: every shard of the problem fits the resident layout: k_ba_ll (k_ba_ll.h) takes it
     long long *prof = (prof_all && job == 0) ? prof_all : nullptr;
     long long tprev = prof ? wall_clock64() : 0;
     // LDS carve (all dynamic): S[(np+1)*(np+1)] | bs[np] | xp[np] | Hpp[36*na] | bp[np] | red[W] | PT[12 na] | CT[32] | flag

@@ -95,7 +95,13 @@ struct svslam_ctx {
     long long *d_ba_prof = nullptr;
     // low-latency local BA (svslam_set_low_latency): a problem is dealt over ll.w workgroups (k_ba_split, k_local_ba_t<2>)
     struct { int w = 0; BaDev *shards = nullptr; double *xch = nullptr; unsigned int *cnt = nullptr; size_t xch_stride = 0; BaWork bw;
-             LlCaps caps = { 0, 0, 0 }; } ll;    // caps.B > 0: problems whose shards fit go to the resident kernel (k_ba_ll)
+             LlCaps caps = { 0, 0, 0 };          // caps.B > 0: problems whose shards fit go to the resident kernel (k_ba_ll)
+             // The shards of a problem meet at in-launch barriers, so all of them have to be resident at once: max_problems is
+             // what the occupancy of both solver kernels x the device's CUs allows (svslam_set_low_latency); calls with more
+             // problems take the batch solver.  A shard that still never arrives (the CUs were taken by something else) makes
+             // the problem give up after ~1 s; the call then solves it again with the batch solver (fallbacks counts those).
+             int max_problems = 0, cus = 0, blocks_per_cu = 0; bool force_batch = false; int test_drop = 0; long long fallbacks = 0;
+             std::vector<BaDev> saved; } ll;
     double *d_lm_trace = nullptr;            // svslam_lm_trace test hook: [max_jobs][LM_TRACE_STRIDE]
     // host-side wall time (ns): 0 h2d enqueue, 1 d2h enqueue, 2 stream wait, 3 launches, 4 staging memcpy/prep
     long long host_ns[8] = { 0 };
@@ -118,11 +124,15 @@ struct svslam_ctx {
     // live in a buffer of their own (the staging arena is recycled by every call), the solve runs on a second stream
     struct { unsigned char *buf = nullptr; size_t cap = 0; bool inflight = false; int njobs = 0; hipStream_t stream = nullptr;
              hipEvent_t gathered = nullptr, solved = nullptr, t0 = nullptr, t1 = nullptr;
-             size_t ojobs = 0, obd = 0, oposes = 0, opts = 0, ochi = 0, oref = 0, olms = 0, oflag = 0; DmParams prm; int MK = 0; } dmba;
+             size_t ojobs = 0, obd = 0, oposes = 0, opts = 0, ochi = 0, oref = 0, olms = 0, oflag = 0; DmParams prm; int MK = 0;
+             BaCams cams; int ba_iters = 0; } dmba;
     hipEvent_t done = nullptr;   // recorded after the last enqueue of a call; the stream may be shared
     // a submitted, not yet collected local-BA batch owns the staging arena
     struct { bool active = false; int njobs = 0, total_kf = 0, total_lm = 0, total_obs = 0;
-             size_t ojobs = 0, oposes = 0, opts = 0, ochi = 0, oflag = 0; } ba_pending;
+             size_t ojobs = 0, oposes = 0, opts = 0, ochi = 0, oflag = 0;
+             // what a repeat with the batch solver needs when the low-latency solver gives up (svslam_local_ba_collect)
+             bool ll_used = false; size_t ocams = 0, opk = 0, ouv = 0, osrt = 0, orecs = 0, oaux = 0, out_end = 0; int max_nlm = 0, max_nobs = 0, iters = 0;
+             double delta = 0; } ba_pending;
     // an open shared-map BA problem (svslam_sba_*): this rank's shard lives in the arena like a submitted batch
     struct { bool open = false; int nkf = 0, nlm = 0, nobs = 0, np = 0; size_t ojobs = 0, ocams = 0, oposes = 0, opts = 0, orecs = 0,
              oaux = 0, ochi = 0, oio = 0; double delta = 0; int launches = 0; } sba;
@@ -136,6 +146,8 @@ struct svslam_ctx {
     int ev_fam[8];
     long long ev_units[8];
 };
+
+static void ll_release(svslam_ctx *c);
 
 namespace {
 
@@ -235,7 +247,10 @@ template <int W> void launch_ba_ll_resident(svslam_ctx *c, int nshards, BaDev *s
                        recs, aux, delta, iters, chi, c->d_ba_prof, c->ll.caps,
                        SbaArgs{ 0, 0, 0.0, nullptr, c->d_lm_trace, 0, c->ll.xch, c->ll.cnt, parents, c->ll.xch_stride });
 }
-bool ba_ll_usable(const svslam_ctx *c, int njobs) { return c->low_latency && c->ll.w > 0 && njobs <= SVSLAM_LL_MAX_PROBLEMS; }
+// test hook (SVSLAM_LL_TEST_DROP_SHARD = n: the next n low-latency launches): shard 0 of problem 0 never runs, its peers give up at
+// their first exchange and the call falls back to the batch solver — the path a GPU without room for every shard takes
+__global__ void k_ll_test_drop(BaDev *shards) { shards[0].reserved = 3; }
+bool ba_ll_usable(const svslam_ctx *c, int njobs) { return c->low_latency && c->ll.w > 0 && !c->ll.force_batch && njobs <= c->ll.max_problems; }
 // tile capacity the shards of the low-latency solver are built with: what both of its kernels can hold
 int ba_ll_tile_cap(const svslam_ctx *c)
 {
@@ -263,6 +278,7 @@ void launch_ba_solver(svslam_ctx *c, int njobs, bool ll, BaDev *jobs, const BaCa
     hipLaunchKernelGGL(k_ba_build, dim3(njobs * W), dim3(BB_THREADS), bb_lds_bytes(max_nlm, max_nobs), c->stream, c->ll.shards, packed, uv, srt, recs, aux,
                        tile_cap, max_nlm, flag, 1 /* every keyframe active in every shard */, ec, 1 /* every landmark in the tile */);
     if (split_timing) { tm_end(c); tm_begin(c, FAM_DBG3, njobs); }
+    if (c->ll.test_drop > 0) { --c->ll.test_drop; hipLaunchKernelGGL(k_ll_test_drop, dim3(1), dim3(1), 0, c->stream, c->ll.shards); }
     // problems whose shards all fit LDS: the resident kernel; the others: the streaming one (each kernel skips the other's)
     if (c->ll.caps.B > 0) {
         if (W == 4) launch_ba_ll_resident<4>(c, njobs * W, c->ll.shards, cams, poses, pts, recs, aux, delta, iters, chi, jobs);
@@ -666,10 +682,7 @@ void svslam_destroy(svslam_ctx *c)
     }
     (void)hipFree(c->gw.keys); (void)hipFree(c->gw.counters);
     ba_work_free(c->bw);
-    ba_work_free(c->ll.bw);
-    if (c->ll.shards) (void)hipFree(c->ll.shards);
-    if (c->ll.xch) (void)hipFree(c->ll.xch);
-    if (c->ll.cnt) (void)hipFree(c->ll.cnt);
+    ll_release(c);
     if (c->d_ba_prof) (void)hipFree(c->d_ba_prof);
     if (c->d_lm_trace) (void)hipFree(c->d_lm_trace);
     (void)svslam_sba_comm_destroy(c);
@@ -718,6 +731,22 @@ int svslam_pyramid_batch(svslam_ctx *c, int n, const int *slots, const void *con
                           dec ? c->src_h : c->geom.h[0], true);
 }
 
+// co-resident workgroups of kernel `f` the device can hold: occupancy per CU x CUs
+static int ll_resident_blocks(const void *f, size_t lds, int cus)
+{
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f, BA_THREADS, lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return nb * cus;
+}
+static void ll_release(svslam_ctx *c)
+{
+    if (c->ll.shards) (void)hipFree(c->ll.shards);
+    if (c->ll.xch) (void)hipFree(c->ll.xch);
+    if (c->ll.cnt) (void)hipFree(c->ll.cnt);
+    ba_work_free(c->ll.bw);
+    c->ll.shards = nullptr; c->ll.xch = nullptr; c->ll.cnt = nullptr; c->ll.w = 0; c->ll.max_problems = 0;
+}
+
 int svslam_set_low_latency(svslam_ctx *c, int on)
 {
     c->low_latency = on != 0;
@@ -725,32 +754,57 @@ int svslam_set_low_latency(svslam_ctx *c, int on)
     // runtime instead of sleep-polling the event (SVSLAM_WAIT=poll|spin still overrides)
     if (!std::getenv("SVSLAM_WAIT")) c->wait_poll = !c->low_latency;
     { const char *z = std::getenv("SVSLAM_ZERO_COPY"); c->zero_copy = c->low_latency && !(z && atoi(z) == 0); }
-    // one local-BA problem over several workgroups (k_local_ba_t<2>): shard descriptors, exchange area, arrival counters and
-    // the per-shard solver scratch, once.  SVSLAM_LL_SHARDS = 4 | 8 | 16 (default); 0 keeps one workgroup per problem.
-    if (c->low_latency && !c->ll.shards && c->lim.max_kf > 0 && !c->ba_host_build && ba_tile_cap_ll(c->lim.max_kf) >= std::max(c->lim.max_kf, 64)) {
+    // one local-BA problem over several workgroups (k_ba_ll / k_local_ba_t<2>): shard descriptors, exchange area, arrival
+    // counters and the per-shard solver scratch, once.  SVSLAM_LL_SHARDS = 4 | 8 | 16 (default); 0 keeps one workgroup per problem.
+    if (c->low_latency && c->ll.w == 0 && c->lim.max_kf > 0 && !c->ba_host_build && ba_tile_cap_ll(c->lim.max_kf) >= std::max(c->lim.max_kf, 64)) {
         const char *e = std::getenv("SVSLAM_LL_SHARDS");
         int w = e ? atoi(e) : 16;
         if (w != 0 && w != 4 && w != 8 && w != 16) return fail(c, "SVSLAM_LL_SHARDS=%d (4, 8, 16 or 0)", w);
         if (w > 0) {
-            const size_t nsh = (size_t)SVSLAM_LL_MAX_PROBLEMS * w;
-            c->ll.xch_stride = ll_xch_doubles(6 * c->lim.max_kf, w);
-            HIPCHK(c, hipMalloc(&c->ll.shards, sizeof(BaDev) * nsh));
-            HIPCHK(c, hipMalloc(&c->ll.xch, sizeof(double) * c->ll.xch_stride * SVSLAM_LL_MAX_PROBLEMS));
-            HIPCHK(c, hipMalloc(&c->ll.cnt, sizeof(unsigned int) * LL_CNT_WORDS * SVSLAM_LL_MAX_PROBLEMS));
-            HIPCHK(c, hipMemset(c->ll.xch, 0, sizeof(double) * c->ll.xch_stride * SVSLAM_LL_MAX_PROBLEMS));
-            HIPCHK(c, hipMemset(c->ll.cnt, 0, sizeof(unsigned int) * LL_CNT_WORDS * SVSLAM_LL_MAX_PROBLEMS));
-            if (ba_work_alloc(c->ll.bw, (int)nsh, c->lim.max_kf, c->lim.max_lm, c->lim.max_obs) != hipSuccess)
-                return fail(c, "low-latency BA workspace allocation failed");
-            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_split), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)ba_split_lds_bytes(c->lim.max_lm, LL_MAX_W)));
-            c->ll.w = w;
             // the resident kernel (SVSLAM_LL_RESIDENT=0: every problem through the streaming kernel, A/B and its tests)
             const char *er = std::getenv("SVSLAM_LL_RESIDENT");
-            c->ll.caps = (er && atoi(er) == 0) ? LlCaps{ 0, 0, 0 } : ba_ll_caps(c->lim.max_kf);
-            if (c->ll.caps.B > 0)
+            const LlCaps caps = (er && atoi(er) == 0) ? LlCaps{ 0, 0, 0 } : ba_ll_caps(c->lim.max_kf);
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_split), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)ba_split_lds_bytes(c->lim.max_lm, LL_MAX_W)));
+            if (caps.B > 0)
                 for (const void *f : { reinterpret_cast<const void *>(k_ba_ll<4>), reinterpret_cast<const void *>(k_ba_ll<8>),
                                        reinterpret_cast<const void *>(k_ba_ll<16>) })
-                    HIPCHK(c, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ba_ll_lds_bytes(c->lim.max_kf, c->ll.caps)));
+                    HIPCHK(c, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ba_ll_lds_bytes(c->lim.max_kf, caps)));
+            // Guard of the in-launch barriers: every shard of every problem of a launch must be resident at
+            // the same time.  CUs of the device (SVSLAM_LL_CUS overrides: a CU-masked process, a partitioned device whose
+            // property still reports the whole chip) x the occupancy of the two solver kernels at their LDS sizes; if not even
+            // one problem fits at w shards the shard count is halved, and without a fit the batch solver keeps the problems.
+            int cus = 0;
+            HIPCHK(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+            if (const char *ec = std::getenv("SVSLAM_LL_CUS")) { const int v = atoi(ec); if (v > 0) cus = std::min(cus, v); }
+            int maxp = 0, per_cu = 0;
+            for (; w >= 4; w /= 2) {
+                const void *fr = w == 4 ? reinterpret_cast<const void *>(k_ba_ll<4>) : w == 8 ? reinterpret_cast<const void *>(k_ba_ll<8>) : reinterpret_cast<const void *>(k_ba_ll<16>);
+                const void *fs = w == 4 ? reinterpret_cast<const void *>(k_local_ba_t<2, 4>) : w == 8 ? reinterpret_cast<const void *>(k_local_ba_t<2, 8>) : reinterpret_cast<const void *>(k_local_ba_t<2, 16>);
+                int blocks = ll_resident_blocks(fs, ba_lds_bytes_ll(c->lim.max_kf), cus);
+                if (caps.B > 0) blocks = std::min(blocks, ll_resident_blocks(fr, ba_ll_lds_bytes(c->lim.max_kf, caps), cus));
+                per_cu = cus > 0 ? blocks / cus : 0;
+                maxp = std::min(SVSLAM_LL_MAX_PROBLEMS, blocks / w);
+                if (maxp >= 1) break;
+            }
+            c->ll.cus = cus; c->ll.blocks_per_cu = per_cu;
+            if (maxp < 1) return 0;               // no shard count fits: one workgroup per problem (the batch solver)
+            const size_t nsh = (size_t)SVSLAM_LL_MAX_PROBLEMS * w;
+            c->ll.xch_stride = ll_xch_doubles(6 * c->lim.max_kf, w);
+            hipError_t er_ = hipMalloc(&c->ll.shards, sizeof(BaDev) * nsh);
+            if (er_ == hipSuccess) er_ = hipMalloc(&c->ll.xch, sizeof(double) * c->ll.xch_stride * SVSLAM_LL_MAX_PROBLEMS);
+            if (er_ == hipSuccess) er_ = hipMalloc(&c->ll.cnt, sizeof(unsigned int) * LL_CNT_WORDS * SVSLAM_LL_MAX_PROBLEMS);
+            if (er_ == hipSuccess) er_ = hipMemset(c->ll.xch, 0, sizeof(double) * c->ll.xch_stride * SVSLAM_LL_MAX_PROBLEMS);
+            if (er_ == hipSuccess) er_ = hipMemset(c->ll.cnt, 0, sizeof(unsigned int) * LL_CNT_WORDS * SVSLAM_LL_MAX_PROBLEMS);
+            if (er_ == hipSuccess) er_ = ba_work_alloc(c->ll.bw, (int)nsh, c->lim.max_kf, c->lim.max_lm, c->lim.max_obs);
+            if (er_ != hipSuccess) {              // nothing half-built stays behind: a later call starts over
+                ll_release(c);
+                return fail(c, "low-latency BA workspace allocation failed: %s", hipGetErrorString(er_));
+            }
+            c->ll.caps = caps;
+            c->ll.w = w;
+            c->ll.max_problems = maxp;
+            if (const char *et = std::getenv("SVSLAM_LL_TEST_DROP_SHARD")) c->ll.test_drop = atoi(et);   // test hook, see launch_ba_solver
         }
     }
     return 0;
@@ -1048,6 +1102,9 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
 {
     if (njobs <= 0) return 0;
     if (njobs > c->lim.max_jobs) return fail(c, "local_ba: %d jobs > max_jobs", njobs);
+    // the solver scratch (c->bw, the low-latency exchange area, the LM trace) is one per context: a deferred local BA of the
+    // device map that is still running on the context's second stream owns it
+    if (c->dmba.inflight) return fail(c, "local_ba: a deferred local BA of the device map is in flight on this context: call svslam_dmap_ba_collect first");
     for (int i = 0; i < njobs; ++i) {
         const svslam_ba_job &j = jobs[i];
         if (j.nkf < 0 || j.nkf > c->lim.max_kf || j.nlm < 0 || j.nlm > c->lim.max_lm || j.nobs < 0 ||
@@ -1199,6 +1256,15 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
     c->ba_pending.active = true; c->ba_pending.njobs = njobs;
     c->ba_pending.total_kf = total_kf; c->ba_pending.total_lm = total_lm; c->ba_pending.total_obs = total_obs;
     c->ba_pending.ojobs = ojobs; c->ba_pending.oposes = oposes; c->ba_pending.opts = opts; c->ba_pending.ochi = ochi;
+    c->ba_pending.ll_used = !c->ba_host_build && use_ll && all_sorted;
+    if (c->ba_pending.ll_used) {
+        c->ba_pending.ocams = ocams; c->ba_pending.opk = opk_o; c->ba_pending.ouv = ouv_o; c->ba_pending.osrt = osrt_o; c->ba_pending.orecs = orecs;
+        c->ba_pending.oaux = oaux; c->ba_pending.out_end = out_end; c->ba_pending.max_nlm = max_nlm; c->ba_pending.max_nobs = max_nobs;
+        c->ba_pending.iters = iters; c->ba_pending.delta = huber_delta;
+        // the descriptors as uploaded, re-tiled for the batch solver (larger tiles: the aux room reserved for the smaller ones holds them)
+        c->ll.saved.assign(dj, dj + njobs);        // (dj: the host arena; the read-back below overwrites it)
+        for (int i = 0; i < njobs; ++i) c->ll.saved[(size_t)i].lay_ntile = ba_tile_bound(jobs[i].nlm, jobs[i].nobs, jobs[i].nkf, ba_tile_cap(c->lim.max_kf));
+    }
     return 0;
 }
 
@@ -1214,8 +1280,27 @@ int svslam_local_ba_collect(svslam_ctx *c, int njobs, svslam_ba_job *jobs, int t
     if (const int fl = hp<int>(c, c->ba_pending.oflag)[0])
         return fail(c, "local_ba: the device structure build overflowed a capacity (code %d)", fl);
     const BaDev *dj = hp<BaDev>(c, c->ba_pending.ojobs);
+    bool gave_up = false;
+    for (int i = 0; i < njobs; ++i) gave_up = gave_up || dj[i].iters_done < 0;
+    if (gave_up) {
+        // a shard of the low-latency solver never became resident; the problems' inputs are untouched in the device arena
+        // (a problem that gives up writes nothing back): the whole batch once more with one workgroup per problem
+        if (!c->ba_pending.ll_used || (int)c->ll.saved.size() != njobs) return fail(c, "local_ba: a problem reports iters_done < 0 outside the low-latency solver");
+        const auto &bp = c->ba_pending;
+        memcpy(hp<void>(c, bp.ojobs), c->ll.saved.data(), sizeof(BaDev) * (size_t)njobs);
+        hp<int>(c, bp.oflag)[0] = 0;
+        if (h2d(c, bp.ojobs, bp.ojobs + sizeof(BaDev) * (size_t)njobs)) return -1;
+        if (h2d(c, bp.oflag, bp.oflag + sizeof(int) * 4)) return -1;
+        launch_ba_solver(c, njobs, false, dp<BaDev>(c, bp.ojobs), dp<BaCams>(c, bp.ocams), dp<double>(c, bp.oposes), dp<double>(c, bp.opts),
+                         dp<unsigned int>(c, bp.opk), dp<float2>(c, bp.ouv), dp<int>(c, bp.osrt), dp<BaRec>(c, bp.orecs), dp<int>(c, bp.oaux),
+                         dp<double>(c, bp.ochi), dp<int>(c, bp.oflag), bp.max_nlm, bp.max_nobs, bp.delta, bp.iters, false);
+        HIPCHK(c, hipGetLastError());
+        if (d2h_sync(c, bp.ojobs, bp.out_end)) return -1;
+        if (const int fl = hp<int>(c, bp.oflag)[0]) return fail(c, "local_ba: the device structure build overflowed a capacity (code %d)", fl);
+        c->ll.fallbacks += njobs;
+    }
     for (int i = 0; i < njobs; ++i) {
-        if (dj[i].iters_done < 0) return fail(c, "local_ba: job %d: a workgroup of the low-latency solver never arrived (GPU oversubscribed?)", i);
+        if (dj[i].iters_done < 0) return fail(c, "local_ba: job %d reports iters_done < 0 from the batch solver", i);
         jobs[i].iters_done = dj[i].iters_done;
         jobs[i].reserved = (int)(((unsigned)std::min(dj[i].ntrial, 255) << 24) | ((unsigned)dj[i].ncontrib & 0x00ffffffu));   // accounting (svslam.h)
     }
@@ -1548,13 +1633,17 @@ int svslam_sba_close(svslam_ctx *c, double *poses, double *pts, double *edge_chi
 }
 
 // ------------------------------------------------------------------ the keyframe path on the device-resident map
-int svslam_dmap_keyframe_batch(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, const void *const *left_imgs,
-                               const void *const *right_imgs, const int *strides, int src_is_device,
-                               const double cam_l[4], const double ext_l[7], const double cam_r[4], const double ext_r[7],
-                               const svslam_dmap_params *p)
+// fb_mode: 0 the call as the caller made it; 1 / 2: the batch-solver repeat of local BAs the low-latency solver gave up on
+// (dmap_ll_fallback) — optimise-only jobs; 1 also rebuilds the resident feature list of the job's keyframe (k_dmap_refresh ran
+// before the outlier observations were removed), 2 refreshes positions only (a deferred BA that landed frames later)
+static int dmap_keyframe_impl(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, const void *const *left_imgs,
+                              const void *const *right_imgs, const int *strides, int src_is_device,
+                              const double cam_l[4], const double ext_l[7], const double cam_r[4], const double ext_r[7],
+                              const svslam_dmap_params *p, int fb_mode)
 {
     if (njobs <= 0) return 0;
     if (!c->dm_all) return fail(c, "dmap: context created without device_map");
+    if (c->dmba.inflight) return fail(c, "dmap: a deferred local BA is in flight: call svslam_dmap_ba_collect first");
     static_assert(sizeof(DmJob) == sizeof(svslam_dmap_job), "job layout");
     static_assert(sizeof(DmEvicted) == sizeof(svslam_dmap_evicted_rec), "evicted record layout");
     c->evicted.clear();
@@ -1616,7 +1705,6 @@ int svslam_dmap_keyframe_batch(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, 
     size_t otidx = c->ar.take(sizeof(int) * P), oxyz = c->ar.take(sizeof(double) * 3 * P), ook = c->ar.take(P), oslot = c->ar.take(sizeof(int) * P);
     // the local-BA problem and the solver's scratch: in the arena, or — deferred — in the buffer that outlives this call
     const bool defer = p->ba_defer != 0 && p->ba_iters > 0 && !opt_only;
-    if (c->dmba.inflight) return fail(c, "dmap: a deferred local BA is in flight: call svslam_dmap_ba_collect first");
     Arena bar;                                    // offsets only (take()): base pointer chosen below
     bar.cap = ~(size_t)0;
     Arena &A = defer ? bar : c->ar;
@@ -1657,7 +1745,8 @@ int svslam_dmap_keyframe_batch(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, 
         if (opt_only) {          // what k_dmap_begin would have initialised
             hj[i].ok = 1; hj[i].dead = 0; hj[i].flags = 0; hj[i].n_features = hj[i].npts; hj[i].n_corners = hj[i].n_right_ok = hj[i].n_tri_in = hj[i].n_tri_ok = 0;
             hj[i].ba_nkf = hj[i].ba_nlm = hj[i].ba_nobs = hj[i].ba_iters = hj[i].ba_npair = hj[i].ba_ntrial = 0; hj[i].ev_ofs = hj[i].ev_n = 0;
-            hj[i].kf_slot = -1; hj[i].remove_slot = -1; hj[i].pad0 = 0;
+            if (fb_mode != 1) hj[i].kf_slot = -1;
+            hj[i].remove_slot = -1; hj[i].pad0 = 0;
         }
         gj[i].slot = hj[i].slot_cur; gj[i].nrect = hj[i].npts;
         gj[i].rect_ofs = (int)(((size_t)hj[i].stream * m.KW + hj[i].kf_slot) * NF);
@@ -1736,12 +1825,14 @@ int svslam_dmap_keyframe_batch(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, 
             HIPCHK(c, rec_rc);
             c->dmba.inflight = true; c->dmba.njobs = njobs; c->dmba.ojobs = objobs; c->dmba.obd = obd; c->dmba.oposes = oposes; c->dmba.opts = opts;
             c->dmba.ochi = ochi; c->dmba.oref = oref; c->dmba.olms = olms; c->dmba.oflag = oflag; c->dmba.prm = prm; c->dmba.MK = MK;
+            c->dmba.cams = *cams; c->dmba.ba_iters = p->ba_iters;
         } else {
             hipLaunchKernelGGL(k_dmap_ba_scatter, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, prm, b_bd, b_poses, b_pts, b_chi, b_ref, b_lms, MK);
             tm_end(c);
         }
     }
-    if (opt_only) {
+    if (opt_only && fb_mode == 1) hipLaunchKernelGGL(k_dmap_refresh, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, c->rt);
+    else if (opt_only) {
         size_t ol3 = c->ar.take(sizeof(int) * 3 * n);
         if (c->ar.off > c->ar.cap) return fail(c, "dmap: staging arena too small");
         int *l3 = hp<int>(c, ol3);
@@ -1771,8 +1862,70 @@ int svslam_dmap_keyframe_batch(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, 
     memcpy(jobs, hj, sizeof(DmJob) * n);
     for (int i = 0; i < njobs && !opt_only; ++i) c->rt_count[(size_t)jobs[i].stream] = jobs[i].n_features;
     for (int i = 0; i < njobs; ++i)
-        if (jobs[i].ba_iters < 0) return fail(c, "dmap: job %d: a workgroup of the low-latency BA solver never arrived (GPU oversubscribed?)", i);
+        if (jobs[i].ba_iters < 0 && fb_mode != 0) return fail(c, "dmap: job %d: the batch solver reported a low-latency failure", i);
     return 0;
+}
+
+// Local BAs of `jobs` whose low-latency solve gave up (ba_iters < 0: a shard of the problem never became resident — the CUs were
+// taken by something else; nothing was written back) are solved again with the batch solver, one workgroup per problem, which
+// has no inter-workgroup barrier: optimise-only jobs over the same windows, their BA outputs copied into the caller's jobs.
+static int dmap_ll_fallback(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, const double cam_l[4], const double ext_l[7],
+                            const double cam_r[4], const double ext_r[7], const svslam_dmap_params *p, int fb_mode)
+{
+    std::vector<int> bad;
+    for (int i = 0; i < njobs; ++i) if (jobs[i].ba_iters < 0) bad.push_back(i);
+    if (bad.empty()) return 0;
+    const int nb = (int)bad.size();
+    std::vector<svslam_dmap_job> oj((size_t)nb);
+    for (int k = 0; k < nb; ++k) {
+        oj[(size_t)k] = jobs[bad[(size_t)k]];
+        oj[(size_t)k].is_init = 2;
+        oj[(size_t)k].npts = c->rt_count[(size_t)oj[(size_t)k].stream];
+    }
+    std::vector<DmEvicted> keep;
+    keep.swap(c->evicted);                         // (the repeat frees nothing; the caller still reads this call's list)
+    svslam_dmap_params q = *p;
+    q.ba_defer = 0;
+    if (q.ba_iters <= 0) q.ba_iters = 10;
+    std::vector<const void *> nul((size_t)nb, nullptr);
+    std::vector<int> st((size_t)nb, 0);
+    c->ll.force_batch = true;
+    const int rc = dmap_keyframe_impl(c, nb, oj.data(), nul.data(), nul.data(), st.data(), 1, cam_l, ext_l, cam_r, ext_r, &q, fb_mode);
+    c->ll.force_batch = false;
+    c->evicted.swap(keep);
+    if (rc) return rc;
+    for (int k = 0; k < nb; ++k) {
+        svslam_dmap_job &d = jobs[bad[(size_t)k]];
+        const svslam_dmap_job &o = oj[(size_t)k];
+        d.ba_nkf = o.ba_nkf; d.ba_nlm = o.ba_nlm; d.ba_nobs = o.ba_nobs; d.ba_iters = o.ba_iters; d.ba_npair = o.ba_npair; d.ba_ntrial = o.ba_ntrial;
+        d.flags |= o.flags & 4;
+        memcpy(d.win_pose, o.win_pose, sizeof(d.win_pose)); memcpy(d.win_slot, o.win_slot, sizeof(d.win_slot));
+        if (fb_mode == 1) memcpy(d.pose, o.pose, sizeof(d.pose));
+    }
+    c->ll.fallbacks += nb;
+    return 0;
+}
+
+int svslam_dmap_keyframe_batch(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, const void *const *left_imgs,
+                               const void *const *right_imgs, const int *strides, int src_is_device,
+                               const double cam_l[4], const double ext_l[7], const double cam_r[4], const double ext_r[7],
+                               const svslam_dmap_params *p)
+{
+    if (njobs <= 0) return 0;
+    const bool was_inflight = c->dmba.inflight;
+    const int rc = dmap_keyframe_impl(c, njobs, jobs, left_imgs, right_imgs, strides, src_is_device, cam_l, ext_l, cam_r, ext_r, p, 0);
+    if (rc != 0) {
+        // a failure behind the point where the deferred solve was armed must not leave it armed: the caller never learns
+        // that it has to collect, and every later keyframe call would be refused
+        if (!was_inflight && c->dmba.inflight) {
+            const std::string keep_err = c->err;
+            if (c->dmba.stream) (void)hipStreamSynchronize(c->dmba.stream);
+            c->dmba.inflight = false;
+            c->err = keep_err;
+        }
+        return rc;
+    }
+    return dmap_ll_fallback(c, njobs, jobs, cam_l, ext_l, cam_r, ext_r, p, 1);
 }
 
 int svslam_dmap_ba_collect(svslam_ctx *c, int njobs, svslam_dmap_job *jobs_out, int *njobs_inflight)
@@ -1817,9 +1970,13 @@ int svslam_dmap_ba_collect(svslam_ctx *c, int njobs, svslam_dmap_job *jobs_out, 
     HIPCHK(c, hipGetLastError());
     if (d2h_sync(c, 0, 0)) return -1;
     memcpy(jobs_out, hj, sizeof(DmJob) * n);
-    for (int i = 0; i < njobs; ++i)
-        if (jobs_out[i].ba_iters < 0) return fail(c, "dmap: job %d: a workgroup of the low-latency BA solver never arrived (GPU oversubscribed?)", i);
-    return 0;
+    {   // problems the low-latency solver gave up on: once more with the batch solver (the map has not moved since the gather:
+        // the host collects before the next keyframe)
+        svslam_dmap_params q{};
+        q.num_features = c->dmba.prm.num_features; q.num_features_init = c->dmba.prm.num_features_init; q.num_active_keyframes = c->dmba.prm.num_active;
+        q.ba_iters = c->dmba.ba_iters; q.max_triangulation_depth = c->dmba.prm.zmax; q.chi2_th = c->dmba.prm.chi2_th;
+        return dmap_ll_fallback(c, njobs, jobs_out, c->dmba.prm.cam_l, c->dmba.cams.ext[0], c->dmba.prm.cam_r, c->dmba.cams.ext[1], &q, 2);
+    }
 }
 
 int svslam_dmap_evicted(svslam_ctx *c, const svslam_dmap_evicted_rec **recs, int *n)
@@ -1862,12 +2019,18 @@ int svslam_set_host_threads(svslam_ctx *c, int n)
 // low-latency path (one problem over several workgroups)
 int svslam_debug_host_ns(svslam_ctx *c, long long *out8)
 {
+    c->host_ns[7] = c->ll.fallbacks; c->ll.fallbacks = 0;      // slot 7: problems the low-latency solver gave up on, repeated by the batch solver
     for (int i = 0; i < 8; ++i) { out8[i] = c->host_ns[i]; c->host_ns[i] = 0; }
     return 0;
 }
 
 // test hook: the shard descriptors of the last low-latency local-BA call (k_ba_split / k_ba_build): 8 ints per shard —
 // landmarks, edges, blocks, tiles, solver (2: resident kernel k_ba_ll, 1: streaming k_local_ba_t<2>), active poses, mask of shards with edges, iterations
+int svslam_debug_ll_limits(svslam_ctx *c, int *out4)
+{
+    out4[0] = c->ll.w; out4[1] = c->ll.max_problems; out4[2] = c->ll.cus; out4[3] = c->ll.blocks_per_cu;
+    return 0;
+}
 int svslam_debug_ll_shards(svslam_ctx *c, int nproblems, int *out8, int *shards_per_problem)
 {
     if (shards_per_problem) *shards_per_problem = c->ll.w;

@@ -92,6 +92,19 @@ def _parse_cpulist(txt):
     return out
 
 
+def device_numa_node(device_index):
+    """NUMA node the GPU hangs off (sysfs, via the device's PCI address); -1 when it cannot be told (no GPU, no sysfs entry)"""
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            return -1
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        return int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+    except (OSError, ValueError, AttributeError, RuntimeError, AssertionError):
+        return -1
+
+
 def device_numa_cpus(device_index, physical_only=True):
     """CPUs of the NUMA node the GPU hangs off (sysfs, via the device's PCI address); with
     physical_only the first hardware thread of each core.  Empty set when it cannot be told."""

@@ -53,7 +53,8 @@ public:
     int set_low_latency(int on)
     {
         low_latency_ = on;
-        if (ba_ctx_ && svslam_set_low_latency(ba_ctx_, on) != 0) return -1;
+        ba_failed_ = false;
+        if (ba_ctx_ && svslam_set_low_latency(ba_ctx_, on) != 0) { ba_failed_ = true; return -1; }   // last_error() then reports the backend context's reason
         return svslam_set_low_latency(ctx_, on);
     }
 

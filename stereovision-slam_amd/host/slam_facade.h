@@ -255,10 +255,17 @@ struct FrontendOptions {            // the hyper-parameters Frontend::Frontend()
     // Not a key of the reference's config files: `device_map: 0` in the YAML (or this field) selects the host map.
     // A kernel provider without a device map (the CPU twin of the tests) ignores it.
     int device_map = 1;
+    // Kernel shapes for ONE camera (svslam_set_low_latency): pose-only LM on four waves, a keyframe's local BA dealt over
+    // up to 16 workgroups.  The facade is one stream by construction, like the reference's VisualOdometry::Step
+    // (src/visual_odometry.cpp:109-156), so this is its default; `low_latency: 0` in the YAML (or this field) selects the
+    // batch shapes (least total work — what a host that runs hundreds of streams through one context wants).  The two
+    // shapes sum in different orders: results agree to rounding, each is deterministic.
+    int low_latency = 1;
     static FrontendOptions FromConfig(const ConfigFile &c)
     {
         FrontendOptions o;
         o.device_map = (int)c.Num("device_map", o.device_map);
+        o.low_latency = (int)c.Num("low_latency", o.low_latency);
         o.num_features = (int)c.Num("num_features", o.num_features);
         o.num_features_init = (int)c.Num("num_features_init", o.num_features_init);
         o.num_features_tracking = (int)c.Num("num_features_tracking", o.num_features_tracking);
@@ -323,6 +330,8 @@ public:
         return true;
     }
     Pipeline<K> *pipeline() { return pipe_.get(); }
+    K *kernels() { return kernels_.get(); }
+    bool LowLatency() const { return opt_.low_latency != 0; }
 
 private:
     void create(int w, int h)
@@ -352,6 +361,7 @@ private:
         lim.max_streams = dmap ? 1 : 0; lim.device_map = dmap ? 1 : 0;
         kernels_.reset(new K(lim));
         if (kernels_->set_source_size(w, h) != 0) throw SLAMException(std::string("source size: ") + kernels_->last_error());
+        if (kernels_->set_low_latency(opt_.low_latency ? 1 : 0) != 0) throw SLAMException(std::string("low-latency shapes: ") + kernels_->last_error());
         pipe_.reset(new Pipeline<K>(cfg, *kernels_, 1, 1));
         wire_backend(); wire_map();
     }

@@ -713,7 +713,7 @@ private:
             dm_left_[i] = left[DS[i]]; dm_right_[i] = right[DS[i]];
             strides_[i] = strides ? strides[DS[i]] : (cfg_.src_width > 0 ? cfg_.src_width : cfg_.width);
         });
-        svslam_dmap_params prm;
+        svslam_dmap_params prm{};
         prm.num_features = cfg_.num_features; prm.num_features_init = cfg_.num_features_init;
         prm.num_active_keyframes = cfg_.num_active_keyframes; prm.ba_iters = (backend_enabled_ && cfg_.backend_on >= 1) ? 10 : 0;   // src/backend.cpp:163
         prm.max_triangulation_depth = cfg_.max_triangulation_depth; prm.chi2_th = cfg_.chi2_th;
@@ -1370,6 +1370,7 @@ public:
     void OptimizeNowOnDevice()
     {
         if (!backend_enabled_) return;
+        DmCollect();                      // a deferred local BA (backend_on 2) lands first, like BackendCollect() in the host-map form
         std::vector<int> MS;
         for (int s = 0; s < nstreams(); ++s) if (!streams_[s]->map.active_keyframes_.empty()) MS.push_back(s);
         const int n = (int)MS.size();
@@ -1381,7 +1382,7 @@ public:
             std::memset(&j, 0, sizeof(j));
             j.stream = MS[i]; j.is_init = 2; j.npts = streams_[MS[i]]->dev_feat; j.kf_slot = -1; j.remove_slot = -1;
         }
-        svslam_dmap_params prm;
+        svslam_dmap_params prm{};
         prm.num_features = cfg_.num_features; prm.num_features_init = cfg_.num_features_init;
         prm.num_active_keyframes = cfg_.num_active_keyframes; prm.ba_iters = 10;
         prm.max_triangulation_depth = cfg_.max_triangulation_depth; prm.chi2_th = cfg_.chi2_th;
@@ -1395,13 +1396,7 @@ public:
             Stream &st = *streams_[MS[i]];
             const svslam_dmap_job &j = jobs_dm_[i];
             if (j.flags & 4) { cnt_.ba_skipped++; continue; }
-            cnt_.ba_calls++; cnt_.ba_edges += j.ba_nobs; cnt_.ba_kf += j.ba_nkf; cnt_.ba_lm += j.ba_nlm; cnt_.ba_iters += j.ba_iters;
-            cnt_.ba_pairs += j.ba_npair; cnt_.ba_trials += j.ba_ntrial;
-            for (int a = 0; a < j.ba_nkf; ++a)
-                for (Frame *kf : st.map.active_keyframes_)
-                    if (kf->dslot == j.win_slot[a]) { kf->pose = SE3(j.win_pose[a]); break; }
-            for (Frame *kf : st.map.active_keyframes_)
-                if (kf->keyframe_id != 0 && kf->prev_keyframe) kf->relative_pose_pkf = kf->pose * kf->prev_keyframe->pose.inverse();
+            ApplyDeviceBa(st, j);
         }
     }
     // the hooks the reference fires at the end of InsertKeyframe / StereoInit (src/frontend.cpp:618-640,

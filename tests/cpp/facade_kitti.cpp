@@ -39,7 +39,19 @@ int main(int argc, char **argv)
         if (n == pause_from && vo.backend()) { vo.backend()->PauseRequest(); CHECK(vo.backend()->IsPaused()); }
         if (n == pause_to && vo.backend()) { vo.backend()->Resume(); CHECK(!vo.backend()->IsPaused()); }
         if (!vo.step()) break;
-        if (!said_map) { std::printf("map: %s\n", vo.frontend()->pipeline()->MapOnDevice() ? "device" : "host"); said_map = true; }
+        if (!said_map) {
+            std::printf("map: %s\n", vo.frontend()->pipeline()->MapOnDevice() ? "device" : "host");
+            // the kernel shapes the facade selected (FrontendOptions::low_latency, default 1: one camera)
+#ifdef FACADE_ORACLE
+            std::printf("shape: %s\n", vo.frontend()->LowLatency() ? "low-latency" : "batch");
+#else
+            int lim[4] = { 0, 0, 0, 0 };
+            svslam_debug_ll_limits(vo.frontend()->kernels()->ctx(), lim);
+            std::printf("shape: %s; local BA over %d workgroups per problem, up to %d problems per call (%d CUs x %d resident)\n",
+                        vo.frontend()->LowLatency() ? "low-latency" : "batch", lim[0], lim[1], lim[2], lim[3]);
+#endif
+            said_map = true;
+        }
         Frame::Ptr f = vo.frontend()->GetLastFrame();
         CHECK(f && f->id_ == (unsigned long)n);
         nkf += f->is_keyframe_ ? 1 : 0;
@@ -66,6 +78,13 @@ int main(int argc, char **argv)
         vo.backend()->Stop();
         CHECK(!vo.backend()->IsRunning());
     }
+#ifndef FACADE_ORACLE
+    {   // which solver took the keyframes' local BAs: slot 6 = problems the low-latency solver took, 7 = of those, repeated by the batch solver
+        long long ns[8];
+        svslam_debug_host_ns(vo.frontend()->kernels()->ctx(), ns);
+        std::printf("local BA: %lld problems on the low-latency solver, %lld repeated by the batch solver\n", ns[6], ns[7]);
+    }
+#endif
     CHECK(vo.saveSLAMOutputInFile(argv[2]));
     // the shared Backend / Map handles outlive a frontend without dangling into it, and a backend
     // attached AFTER the first frame still optimises (the reference wires them in any order before run())

@@ -277,6 +277,36 @@ def test_stream_sharding_over_gloo_world2(tmp_path):
     assert outs[0]["z"] < -1.0 and outs[1]["z"] < -1.0       # both ranks tracked ~0.85 m/frame forward
 
 
+@pytest.mark.parametrize("world", [8])
+def test_bench_launch_contract_dry_run_over_gloo(world):
+    """`bench.py --gpus 8 --dry-run` under the driver's launcher (torch.distributed.run, one process per rank; gloo, no GPU):
+    the communicator spans 8 ranks, the streams are partitioned disjointly and completely, the reported time is the
+    SLOWEST rank's (ranks sleep 1 / 2 / 3 ms per step), exactly K steps are timed, one JSON line comes from rank 0."""
+    port = str(29700 + (os.getpid() % 200))
+    K, S = 25, 12
+    env = {k: v for k, v in os.environ.items() if not k.startswith(("TORCHELASTIC", "MASTER_")) and k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                        "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", str(K), "--warmup", "3",
+                        "--streams", str(S), "--dry-run"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                    # rank 0 only
+    d = __import__("json").loads(lines[0])
+    assert d["dry_run"] is True and d["n_gpus"] == world and d["ranks_seen"] == world and d["steps"] == K and d["warmup"] == 3
+    assert d["scaling"] == "weak" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    rows = d["ranks"]
+    assert [x["rank"] for x in rows] == list(range(world)) and [x["device"] for x in rows] == list(range(world))
+    seeds = set()
+    for x in rows:
+        mine = set(range(x["first_stream_seed"], x["first_stream_seed"] + x["streams"]))
+        assert len(mine) == S and not (mine & seeds)
+        seeds |= mine
+    assert seeds == set(range(0x5EED0000, 0x5EED0000 + S * world))     # disjoint and complete: global stream ids 0 .. S * world - 1
+    assert 3.0 <= d["ms_per_step"] < 12.0                     # the 3-ms ranks set the time (max over ranks), not the 1-ms ones
+    assert d["value"] == pytest.approx(S * K * world / (d["ms_per_step"] * 1e-3 * K), rel=1e-3)
+
+
 def test_numa_pinning_helpers_degrade_gracefully():
     """dist.pin_to_device_numa: cpulist parsing, and no GPU / no sysfs entry means "leave the affinity alone"."""
     sdist = importlib.import_module("stereovision-slam_amd.dist")

@@ -82,7 +82,7 @@ def _run_facade(exe, cfg, out):
     return meta, poses, cams, r.stdout
 
 
-def _check(meta, poses, cams, frames, pl, make_pipeline):
+def _check(meta, poses, cams, frames, pl, make_pipeline, low_latency=0):
     # Dataset::initialize: K halved, baseline = |K^-1 t| (src/dataset.cpp:63-77)
     assert [float(v) for v in cams[0][1:6]] == pytest.approx([FX / 2, FX / 2, CX / 2, CY / 2, 0.0], abs=1e-6)
     assert [float(v) for v in cams[1][1:6]] == pytest.approx([FX / 2, FX / 2, CX / 2, CY / 2, B], abs=1e-6)
@@ -93,7 +93,8 @@ def _check(meta, poses, cams, frames, pl, make_pipeline):
     # against the batched pipeline on the same frames up to the pause (Backend::PauseRequest at frame 8 has
     # no counterpart in the C API): identical metadata and poses, bit for bit — same host code, same kernels
     half = (0.5 * FX, 0.5 * FX, 0.5 * CX, 0.5 * CY)
-    p = make_pipeline(pl.default_config(620, 188, cam=half, baseline=B, src_width=1241, src_height=376, resident_track=0))
+    p = make_pipeline(pl.default_config(620, 188, cam=half, baseline=B, src_width=1241, src_height=376, resident_track=0,
+                                        low_latency=low_latency))
     kf_before_pause = int(meta[:8, 2].sum())
     for i in range(8):
         r = p.step([frames[i][0]], [frames[i][1]])
@@ -142,7 +143,13 @@ def test_facade_on_kitti_layout_sequence_gpu(svs, tmp_path):
     exe = _build(tmp_path, False)
     meta, poses, cams, out = _run_facade(exe, cfg, str(tmp_path))
     assert "map: device" in out
-    _check(meta, poses, cams, frames, pl, lambda c: pl.Pipeline(c, nstreams=1))
+    # one camera by construction: the facade selects the low-latency kernel shapes — pose-only on four
+    # waves, every keyframe's local BA on the multi-workgroup solver (none repeated by the batch solver on an idle GPU)
+    print([l for l in out.splitlines() if l.startswith(("shape", "local BA"))])
+    assert "shape: low-latency; local BA over 16 workgroups per problem" in out
+    ll = [l.split() for l in out.splitlines() if l.startswith("local BA:")][0]
+    assert int(ll[2]) >= 1 and int(ll[8]) == 0, ll
+    _check(meta, poses, cams, frames, pl, lambda c: pl.Pipeline(c, nstreams=1), low_latency=1)
     gt = np.array([svs.synth_gt(42, f) for f in range(len(frames))])
     assert pl.ate_rmse(poses, gt) < 0.1
     files = {f: open(os.path.join(str(tmp_path), f)).read() for f in ("keyframes.txt", "landmarks.pcd")}
@@ -157,3 +164,13 @@ def test_facade_on_kitti_layout_sequence_gpu(svs, tmp_path):
     assert pick(out) == pick(out_h)
     for f, txt in files.items():
         assert open(os.path.join(out_h_dir, f)).read() == txt, f
+    # `low_latency: 0`: the batch shapes — the results of the batched pipeline's default configuration, bit for bit, and
+    # within rounding of the low-latency run (another summation order)
+    cfg_b = os.path.join(str(tmp_path), "config_batch.yaml")
+    open(cfg_b, "w").write(open(cfg).read() + "low_latency: 0\n")
+    out_b_dir = os.path.join(str(tmp_path), "batch"); os.makedirs(out_b_dir)
+    meta_b, poses_b, cams_b, out_b = _run_facade(exe, cfg_b, out_b_dir)
+    assert "shape: batch" in out_b and "local BA: 0 problems on the low-latency solver" in out_b
+    _check(meta_b, poses_b, cams_b, frames, pl, lambda c: pl.Pipeline(c, nstreams=1), low_latency=0)
+    assert np.array_equal(meta_b[:, :4], meta[:, :4])
+    assert np.abs(poses_b - poses).max() < 1e-3

@@ -21,11 +21,16 @@ def _rss():
     return int(open("/proc/self/statm").read().split()[1]) * os.sysconf("SC_PAGE_SIZE")
 
 
-def test_config4_eight_streams_ten_thousand_frames(svs):
+# The shape DESIGN quotes for config 4 (a few cameras per GPU): map in HBM + low-latency kernel shapes, at the full 10 000
+# frames; the host-resident map with the batch shapes (rounds 1-3) stays at a reduced length.
+@pytest.mark.parametrize("shape,frames", [("device_map_low_latency", 10000), ("host_map_batch_shapes", 2500)])
+def test_config4_eight_streams_ten_thousand_frames(svs, shape, frames):
     pl = importlib.import_module("stereovision-slam_amd.pipeline")
-    S, N, CH = 8, int(os.environ.get("SVS_LONG_FRAMES", "10000")), 500
+    S, N, CH = 8, int(os.environ.get("SVS_LONG_FRAMES", str(frames))), 500
     seeds = [0xC0F40000 + i for i in range(S)]
-    pipe = pl.Pipeline(pl.default_config(W, H, host_threads=2), nstreams=S)
+    product = shape == "device_map_low_latency"
+    cfg = pl.default_config(W, H, host_threads=2, device_map=1, low_latency=1) if product else pl.default_config(W, H, host_threads=2)
+    pipe = pl.Pipeline(cfg, nstreams=S)
     ctx = svs.Context.borrow(pipe.kernel_ctx(), W, H)
     img = W * H
     dl = ctx.dev_alloc(S * CH * img); dr = ctx.dev_alloc(S * CH * img)
@@ -41,8 +46,11 @@ def test_config4_eight_streams_ten_thousand_frames(svs):
         poses[f0:f0 + n] = r["pose"]; status[f0:f0 + n] = r["status"]
         rss_at[f0 + n] = _rss()
     cnt = pipe.counters()
+    hc = ctx.host_counters()
     ctx.dev_free(dl); ctx.dev_free(dr)
     pipe.close()
+    if product:      # every keyframe's local BA went to the multi-workgroup solver, none had to be repeated
+        assert hc[6] == cnt["ba_calls"] and hc[7] == 0, (hc, cnt["ba_calls"])
     assert (status != 3).all(), "a stream was LOST at frame %d" % int(np.argmax((status == 3).any(1)))
     assert cnt["corners_dropped"] == 0 and cnt["ba_skipped"] == 0
     rel = []
@@ -55,14 +63,14 @@ def test_config4_eight_streams_ten_thousand_frames(svs):
     first = min(k for k in rss_at if k >= min(1000, N // 2))
     growth = (rss_at[N] - rss_at[first]) / max(1, (N - first) * S)
     fps = N * S / t_run
-    line = {"streams": S, "frames_per_stream": N, "frames_per_s": round(fps, 1), "ms_per_frame_per_stream": round(1e3 * t_run / N, 4),
+    line = {"shape": shape, "streams": S, "frames_per_stream": N, "frames_per_s": round(fps, 1), "ms_per_frame_per_stream": round(1e3 * t_run / N, 4),
             "keyframes": int(cnt["keyframes"]), "ba_calls": int(cnt["ba_calls"]),
             "ate_over_path_pct_mean": round(100 * float(np.mean(rel)), 4), "ate_over_path_pct_max": round(100 * float(np.max(rel)), 4),
             "rss_growth_bytes_per_frame_per_stream": round(growth, 1), "rss_mb_end": round(rss_at[N] / 1e6, 1)}
     print("config4 long run:", json.dumps(line))
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):
-        with open(os.path.join(out, "r3_config4_long_run.json"), "w") as f:
+        with open(os.path.join(out, "config4_long_run_%s.json" % shape), "w") as f:
             f.write(json.dumps(line) + "\n")
     # Drift of a stereo VO WITHOUT loop closure (SURVEY: LoopClosure is out of scope) grows faster than the path
     # (heading random walk): 0.06-0.21 % over 1.3 km and 0.3 % over 2.6 km in round 1, ~1 % over these 8.5 km.
@@ -70,12 +78,14 @@ def test_config4_eight_streams_ten_thousand_frames(svs):
     # two streams go through the twin as well (numeric-J BA like g2o, one thread each).
     assert max(rel) <= 0.02, rel
     assert growth <= 700.0, growth
+    if not product:
+        return
     twin_rel = _twin_drift(svs, pl, seeds[:2], N)
     line["twin_ate_over_path_pct"] = [round(100 * v, 4) for v in twin_rel]
     line["hip_ate_over_path_pct_same_streams"] = [round(100 * v, 4) for v in rel[:2]]
     print("config4 long run:", json.dumps(line))
     if os.path.isdir(out):
-        with open(os.path.join(out, "r3_config4_long_run.json"), "w") as f:
+        with open(os.path.join(out, "config4_long_run_%s.json" % shape), "w") as f:
             f.write(json.dumps(line) + "\n")
     # per-stream drift scatters by a factor ~1.5 between two valid runs of the same stream (chaotic in
     # each other); the bound says "same regime", the distribution test (test_gpu_ate_distribution) says "same mean"

@@ -1,0 +1,182 @@
+"""The one-camera product path as a PIPELINE: the map of every stream in HBM (device_map = 1) together
+with the low-latency kernel shapes (low_latency = 1: pose-only on four waves, a keyframe's local BA dealt over 16
+workgroups by k_ba_split / k_ba_ll, three launches per tracked frame, zero-copy job structs, spin wait), with the backend
+inside the keyframe's call (mode 1) and beside the following frames on the context's second stream (mode 2, the result
+landing 1 or 6 frames late) — the configuration of every figure in profiles/r*_latency_small_S.txt.
+
+  * mode 1 equals the HOST-map low-latency run bit for bit (same kernels, the map's home is the only difference) and the
+    batch-shape device-map run within the LM tolerances (another summation order of the same sums);
+  * mode 2 is reproducible run to run although k_ba_ll's inter-workgroup barriers then run beside the frontend's kernels;
+  * the low-latency solver really took the problems (svslam_debug_host_ns slot 6, svslam_debug_ll_shards: resident kernel);
+  * the residency guard of the in-launch barriers: a device with few CUs (SVSLAM_LL_CUS) gets fewer shards / problems per
+    call or the batch solver, and a shard that never arrives (test hook) costs a repeat with the batch solver, not the call.
+"""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+W, H = 620, 188
+KEYS = ("status", "is_keyframe", "n_features", "n_inliers", "keyframe_id")
+
+
+def _frames(svs, seeds, n):
+    return [[svs.synth_pair(s, f) for s in seeds] for f in range(n)]
+
+
+def _run(pl, svs, frames, nstreams, **cfg_kw):
+    cfg = pl.default_config(W, H, **cfg_kw)
+    p = pl.Pipeline(cfg, nstreams=nstreams)
+    est = np.zeros((len(frames), nstreams, 7)); meta = []
+    for pairs in frames:
+        r = p.step([x[0] for x in pairs], [x[1] for x in pairs])
+        est[len(meta)] = r["pose"]; meta.append(r.copy())
+    p.flush()
+    ctx = svs.Context.borrow(p.kernel_ctx(), W, H)
+    ns = (C.c_longlong * 8)()
+    ctx.L.svslam_debug_host_ns(ctx.h, ns)
+    lim = (C.c_int * 4)()
+    ctx.L.svslam_debug_ll_limits(ctx.h, lim)
+    sh = (C.c_int * (8 * 16))()
+    spp = C.c_int(0)
+    solver = None
+    if ctx.L.svslam_debug_ll_shards(ctx.h, 1, sh, C.byref(spp)) == 0:
+        solver = [sh[8 * v + 4] for v in range(spp.value)]
+    cnt = p.counters()
+    p.close()
+    return est, meta, {"ll_problems": int(ns[6]), "ll_fallbacks": int(ns[7]), "limits": list(lim), "solver": solver, "counters": cnt}
+
+
+@pytest.mark.parametrize("S", [1, 8])
+def test_device_map_low_latency_backend_inside_the_keyframe(svs, S):
+    pl = importlib.import_module("stereovision-slam_amd.pipeline")
+    seeds, N = [500 + i for i in range(S)], 48
+    fr = _frames(svs, seeds, N)
+    ed, md, info = _run(pl, svs, fr, S, device_map=1, low_latency=1, backend_on=1)
+    eh, mh, info_h = _run(pl, svs, fr, S, device_map=0, low_latency=1, backend_on=1)
+    eb, mb, info_b = _run(pl, svs, fr, S, device_map=1, low_latency=0, backend_on=1)
+    kf = info["counters"]["keyframes"]
+    assert kf >= 4 * S and info["counters"]["ba_calls"] == kf
+    # the multi-workgroup solver took every keyframe's problem (S <= 8 problems per call), on its resident kernel, no repeat
+    assert info["limits"][0] == 16 and info["limits"][1] == 8
+    assert info["ll_problems"] == kf and info["ll_fallbacks"] == 0, info
+    assert info["solver"] is not None and all(v in (0, 2) for v in info["solver"]) and 2 in info["solver"], info["solver"]
+    assert info_b["ll_problems"] == 0
+    # host-resident map, same shapes: bit for bit
+    assert info_h["ll_problems"] == info_h["counters"]["ba_calls"]
+    for f in range(N):
+        for k in KEYS:
+            assert np.array_equal(md[f][k], mh[f][k]), (f, k)
+    assert np.array_equal(ed, eh), np.abs(ed - eh).max()
+    # batch shapes (one wave per pose-only job, one workgroup per BA problem): the same sums in another order.  The LM
+    # tolerances of the kernel tests (t 1e-6 m, q 1e-7) hold per call; over frames the differences feed back through LK's
+    # stopping rule, so: exact metadata and tight poses on the first frames, the ATE-level bound over the whole run
+    for f in range(8):
+        for k in KEYS:
+            assert np.array_equal(md[f][k], mb[f][k]), (f, k)
+    assert np.allclose(ed[:8, :, 4:], eb[:8, :, 4:], atol=5e-5) and np.allclose(ed[:8, :, :4], eb[:8, :, :4], atol=5e-6), np.abs(ed[:8] - eb[:8]).max()
+    assert np.allclose(ed[..., 4:], eb[..., 4:], atol=5e-2), np.abs(ed - eb).max()
+    for s, sd in enumerate(seeds):
+        gt = np.array([svs.synth_gt(sd, f) for f in range(N)])
+        assert pl.ate_rmse(ed[:, s], gt) < 0.1
+
+
+@pytest.mark.parametrize("S,lag", [(1, 1), (1, 6), (8, 1), (8, 6)])
+def test_device_map_low_latency_backend_beside_the_frontend(svs, S, lag):
+    """backend mode 2: the local BA runs on the context's second stream while the next frames are tracked; k_ba_ll's
+    barriers then share the GPU with the frontend's kernels.  Two runs must agree bit for bit, the result must land
+    (every keyframe optimised once flush() returns) and the trajectory must stay at the mode-1 level."""
+    pl = importlib.import_module("stereovision-slam_amd.pipeline")
+    seeds, N = [600 + i for i in range(S)], 60
+    fr = _frames(svs, seeds, N)
+    e1, m1, i1 = _run(pl, svs, fr, S, device_map=1, low_latency=1, backend_on=2, backend_lag=lag)
+    e2, m2, i2 = _run(pl, svs, fr, S, device_map=1, low_latency=1, backend_on=2, backend_lag=lag)
+    assert np.array_equal(e1, e2), np.abs(e1 - e2).max()
+    for f in range(N):
+        for k in KEYS:
+            assert np.array_equal(m1[f][k], m2[f][k]), (f, k)
+    kf = i1["counters"]["keyframes"]
+    assert kf >= 4 * S and i1["counters"]["ba_calls"] == kf
+    assert i1["ll_problems"] == kf and i1["ll_fallbacks"] == 0, i1
+    es, ms, _ = _run(pl, svs, fr, S, device_map=1, low_latency=1, backend_on=1)
+    for s, sd in enumerate(seeds):
+        gt = np.array([svs.synth_gt(sd, f) for f in range(N)])
+        a2, a1 = pl.ate_rmse(e1[:, s], gt), pl.ate_rmse(es[:, s], gt)
+        assert a2 < 0.15 and abs(a2 - a1) < 5e-2, (a2, a1)
+    assert all((m["status"] != 3).all() for m in m1)
+
+
+def test_low_latency_guard_follows_the_cu_count(svs, monkeypatch):
+    """the shards of a problem must all be resident: with 8 CUs (SVSLAM_LL_CUS, what a CU-masked process would say) 16
+    shards do not fit — the mode falls to 8 shards and one problem per call; with 2 CUs nothing fits and the batch
+    solver keeps the problems.  Results stay those of the same solver family (LM tolerances)."""
+    pl = importlib.import_module("stereovision-slam_amd.pipeline")
+    seeds, N = [700, 701], 30
+    fr = _frames(svs, seeds, N)
+    ref, mref, iref = _run(pl, svs, fr, 2, device_map=1, low_latency=1)
+    assert iref["limits"][:2] == [16, 8] and iref["limits"][2] >= 64
+    monkeypatch.setenv("SVSLAM_LL_CUS", "8")
+    e8, m8, i8 = _run(pl, svs, fr, 2, device_map=1, low_latency=1)
+    assert i8["limits"][0] == 8 and i8["limits"][1] == 1 and i8["limits"][2] == 8, i8["limits"]
+    # two keyframes in one call (the start-up, and whenever both streams make one in the same frame) go to the batch solver
+    assert 0 < i8["ll_problems"] < i8["counters"]["ba_calls"], i8
+    monkeypatch.setenv("SVSLAM_LL_CUS", "2")
+    e2, m2, i2 = _run(pl, svs, fr, 2, device_map=1, low_latency=1)
+    assert i2["limits"][0] == 0 and i2["limits"][1] == 0 and i2["ll_problems"] == 0, i2
+    for e in (e8, e2):
+        assert np.allclose(e[:6, :, 4:], ref[:6, :, 4:], atol=5e-5), np.abs(e[:6] - ref[:6]).max()
+        assert np.allclose(e[..., 4:], ref[..., 4:], atol=5e-2)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_a_shard_that_never_arrives_costs_a_repeat_not_the_call(svs, monkeypatch, mode):
+    """test hook SVSLAM_LL_TEST_DROP_SHARD: shard 0 of the first two low-latency launches never runs (what an oversubscribed
+    GPU does to a workgroup); its peers give up after their timeout, the call repeats the problem with the batch solver
+    (one workgroup per problem, no barrier) and goes on.  Against a run whose first two keyframes use the batch solver
+    anyway the trajectory must agree at LM-tolerance level."""
+    pl = importlib.import_module("stereovision-slam_amd.pipeline")
+    seeds, N = [800], 24
+    fr = _frames(svs, seeds, N)
+    monkeypatch.setenv("SVSLAM_LL_TEST_DROP_SHARD", "2")
+    kw = dict(device_map=1, low_latency=1, backend_on=mode, backend_lag=1)
+    ed, md, idr = _run(pl, svs, fr, 1, **kw)
+    monkeypatch.delenv("SVSLAM_LL_TEST_DROP_SHARD")
+    assert idr["ll_fallbacks"] == 2, idr
+    assert idr["counters"]["ba_calls"] == idr["counters"]["keyframes"] >= 3
+    er, mr, ir = _run(pl, svs, fr, 1, **kw)
+    assert ir["ll_fallbacks"] == 0
+    for f in range(N):
+        assert np.array_equal(md[f]["status"], mr[f]["status"]) and np.array_equal(md[f]["is_keyframe"], mr[f]["is_keyframe"]), f
+    assert np.allclose(ed[:8, :, 4:], er[:8, :, 4:], atol=5e-5), np.abs(ed[:8] - er[:8]).max()
+    assert np.allclose(ed[..., 4:], er[..., 4:], atol=5e-2)
+    # the same hook through the flat ABI (svslam_local_ba_batch): poses / positions of the repeat = the batch solver's
+    import common
+    rng = np.random.default_rng(5)
+    pr = common.make_ba_problem(rng, nkf=8, nlm=400)
+    o = np.lexsort((pr["okf"], pr["olm"]))          # (landmark, keyframe) order: what the low-latency path takes
+    job = (pr["poses0"], pr["pts0"], pr["okf"][o], pr["olm"][o], pr["ori"][o], pr["ouv"][o])
+    mk = lambda: svs.Context(W, H, max_slots=1, max_jobs=2, max_kf=11, max_lm=2048, max_obs=16384)
+    outs = []
+    for drop in (1, 0):
+        if drop:
+            monkeypatch.setenv("SVSLAM_LL_TEST_DROP_SHARD", "1")
+        ctx = mk()
+        ctx.low_latency(True)
+        if drop:
+            monkeypatch.delenv("SVSLAM_LL_TEST_DROP_SHARD")
+        ctx.host_counters()
+        outs.append(ctx.local_ba([job], common.CAM, common.EXT_L, common.CAM, common.EXT_R, 5.991, 10)[0])
+        hc = ctx.host_counters()
+        assert (hc[6], hc[7]) == ((1, 1) if drop else (1, 0)), hc
+        ctx.close()
+    ctx = mk()
+    batch = ctx.local_ba([job], common.CAM, common.EXT_L, common.CAM, common.EXT_R, 5.991, 10)[0]
+    ctx.close()
+    for a, b in zip(outs[0][:3], batch[:3]):    # the repeat IS the batch solver: poses, positions, per-edge chi2 bit for bit
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+    assert outs[0][3] == batch[3]
+    for a, b in zip(outs[1][:2], batch[:2]):    # and the low-latency solver agrees with it to rounding
+        assert np.allclose(np.asarray(a), np.asarray(b), atol=1e-6)

@@ -140,7 +140,10 @@ def _cpu_rank_main():
     rk.close()
 
 
-def test_shared_map_ba_world2_gloo_equals_one_rank_and_the_oracle(tmp_path, orc):
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_shared_map_ba_over_gloo_equals_one_rank_and_the_oracle(tmp_path, orc, world):
+    """BASELINE config 5 at the world sizes of one node (2, 4, 8 ranks; gloo on the CPU): landmarks dealt over the ranks, the
+    reduced camera system all-reduced per LM trial — every rank must end with the one-rank answer (= the oracle's)"""
     sdist = importlib.import_module("stereovision-slam_amd.dist")
     sba = importlib.import_module("stereovision-slam_amd.shared_ba")
     poses, pts, okf, olm, ori, ouv = _problem()
@@ -154,17 +157,22 @@ def test_shared_map_ba_world2_gloo_equals_one_rank_and_the_oracle(tmp_path, orc)
     assert np.allclose(rel(one.poses())[:, 4:], rel(po)[:, 4:], atol=1e-6)
     assert abs(np.where(one.chi2 <= 5.991 ** 2, one.chi2, 2 * 5.991 * np.sqrt(one.chi2) - 5.991 ** 2).sum() -
                np.where(co <= 5.991 ** 2, co, 2 * 5.991 * np.sqrt(co) - 5.991 ** 2).sum()) < 1e-6 * co.sum()
-    # two ranks, landmarks dealt round-robin, reduced system all-reduced over gloo
+    # `world` ranks, landmarks dealt round-robin, reduced system all-reduced over gloo
     out = str(tmp_path / "sba")
-    env = dict(os.environ, SBA_OUT=out, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29533", os.path.abspath(__file__), "--rank-main"], env=env, capture_output=True, text=True, timeout=600)
+    port = str(29533 + world)
+    env = dict(os.environ, SBA_OUT=out, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                        "--master-port", port, os.path.abspath(__file__), "--rank-main"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
-    a, b = np.load(out + ".0.npz"), np.load(out + ".1.npz")
-    assert int(a["it"]) == int(b["it"]) == it1 and float(a["lam"]) == float(b["lam"])
-    assert np.array_equal(a["poses"], b["poses"])                      # every rank solves the same reduced system
+    res = [np.load(out + ".%d.npz" % k) for k in range(world)]
+    a = res[0]
+    X = np.zeros_like(pts); seen = np.zeros(len(pts), int)
+    for b in res:
+        assert int(b["it"]) == it1 and float(b["lam"]) == float(a["lam"])
+        assert np.array_equal(a["poses"], b["poses"])                  # every rank solves the same reduced system
+        X[b["mine"]] = b["pts"]; seen[b["mine"]] += 1
+    assert (seen == 1).all()                                           # the shards partition the landmarks
     assert np.allclose(a["poses"], one.poses(), atol=1e-9) and abs(float(a["lam"]) - lam1) <= 1e-9 * lam1
-    X = np.zeros_like(pts); X[a["mine"]] = a["pts"]; X[b["mine"]] = b["pts"]
     assert np.allclose(X, one.X, atol=1e-9)
 
 

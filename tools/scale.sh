@@ -19,4 +19,10 @@ assert d["ranks_seen"] == n, "the communicator spanned %s ranks, not %d" % (d["r
 assert d["rank_exchange"].startswith("RCCL") or d["rank_exchange"].startswith("gloo"), d["rank_exchange"]
 assert d["value"] > 0 and d["scaling"] == "weak"
 print("scale.sh: %d rank(s) seen over %s; %.0f frames/s" % (n, d["rank_exchange"].split(":")[0], d["value"]), file=sys.stderr)
+# one line per rank: which device it drove, the device's NUMA node, the CPUs the rank may use / pinned itself to, its streams
+for r in d.get("ranks", []):
+    print("scale.sh: rank %(rank)d device %(device)d numa_node %(numa_node)d cpus_allowed %(cpus_allowed)d cpus_pinned %(cpus_pinned)d "
+          "streams %(streams)d from seed 0x%(first_stream_seed)X" % r, file=sys.stderr)
+devs = [r["device"] for r in d.get("ranks", [])]
+assert len(set(devs)) == len(devs), "two ranks drove the same device: %s" % devs
 PY
