@@ -21,6 +21,10 @@ ROOT = os.path.dirname(HERE)
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
              "-Wno-unused-value"]
+# development: extra compiler flags for an A/B variant (tools/ab.sh), output directory of the variant
+HIP_FLAGS += os.environ.get("SVS_EXTRA_HIP_FLAGS", "").split()
+if os.environ.get("SVS_LIB_DIR"):
+    LIB = os.path.abspath(os.environ["SVS_LIB_DIR"])
 if os.environ.get("SVS_IEEE_DIV"):      # parity-debugging build: IEEE division / sqrt instead of estimate + Newton in the LM kernels
     HIP_FLAGS.append("-DSVS_IEEE_DIV")
 

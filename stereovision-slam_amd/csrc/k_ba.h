@@ -404,21 +404,41 @@ __device__ __forceinline__ int ba_opaque(int v) { asm volatile("" : "+v"(v)); re
 
 // projection of landmark X seen from table pose PT through table camera CT
 struct BaProj { double q[3], p[3], zi, ex, ey; };
+// EID (round 5): both cameras' extrinsic rotations are the identity — the reference's rig always is (Camera::pose_ of the right
+// camera is a pure translation, src/dataset.cpp:63-77).  The products with the zeros and ones of Re are then left out; every
+// remaining operation keeps the operands and the fused / unfused form it has in the general code (a term with a zero factor
+// adds an exact zero there), so the results are the general code's bit for bit, at ~3/4 of its arithmetic.
+template <bool EID>
 __device__ __forceinline__ void ba_project(const double *PT, const double *CT, const double *X, float u, float v, BaProj &o)
 {
 #pragma unroll
     for (int r = 0; r < 3; ++r) o.q[r] = PT[3 * r] * X[0] + PT[3 * r + 1] * X[1] + PT[3 * r + 2] * X[2] + PT[9 + r];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) o.p[r] = CT[3 * r] * o.q[0] + CT[3 * r + 1] * o.q[1] + CT[3 * r + 2] * o.q[2] + CT[9 + r];
+    for (int r = 0; r < 3; ++r)
+        o.p[r] = EID ? o.q[r] + CT[9 + r] : CT[3 * r] * o.q[0] + CT[3 * r + 1] * o.q[1] + CT[3 * r + 2] * o.q[2] + CT[9 + r];
     o.zi = 1.0 / o.p[2];
     const double px = CT[12] * o.p[0] + CT[14] * o.p[2], py = CT[13] * o.p[1] + CT[15] * o.p[2];
     o.ex = (double)u - px * o.zi; o.ey = (double)v - py * o.zi;
 }
 // M = d(e)/d(p) * Re (2x3) and the pose Jacobian Jp = M [I | -q^] (2x6), g2o_types.h:188-215
+template <bool EID>
 __device__ __forceinline__ void ba_jac_pose(const double *CT, const BaProj &o, double *M, double *jp)
 {
     const double zi2 = o.zi * o.zi;
     const double e00 = -CT[12] * o.zi, e02 = CT[12] * o.p[0] * zi2, e11 = -CT[13] * o.zi, e12 = CT[13] * o.p[1] * zi2;
+    if (EID) {
+        // M = [e00 0 e02; 0 e11 e12]
+        M[0] = e00; M[1] = 0; M[2] = e02; M[3] = 0; M[4] = e11; M[5] = e12;
+        jp[0] = e00; jp[1] = 0; jp[2] = e02;
+        jp[3] = e02 * o.q[1];
+        jp[4] = e00 * o.q[2] - e02 * o.q[0];
+        jp[5] = -(e00 * o.q[1]);
+        jp[6] = 0; jp[7] = e11; jp[8] = e12;
+        jp[9] = e12 * o.q[1] - e11 * o.q[2];
+        jp[10] = -(e12 * o.q[0]);
+        jp[11] = e11 * o.q[0];
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         M[c] = e00 * CT[c] + e02 * CT[6 + c];
@@ -436,15 +456,26 @@ __device__ __forceinline__ void ba_jac_pose(const double *CT, const BaProj &o, d
 
 // one edge linearised: residual, robust weight, Jp (2x6), Jl = M R (2x3)
 struct BaLin { double ex, ey, w, rho, jp[12], jl[6]; };
+template <bool EID>
 __device__ __forceinline__ void ba_linearize(const double *PT, const double *CT, const double *X, float u, float v,
                                              double delta, BaLin &L)
 {
     BaProj o;
-    ba_project(PT, CT, X, u, v, o);
+    ba_project<EID>(PT, CT, X, u, v, o);
     L.ex = o.ex; L.ey = o.ey;
     d_huber(o.ex * o.ex + o.ey * o.ey, delta, L.rho, L.w);
     double M[6];
-    ba_jac_pose(CT, o, M, L.jp);
+    ba_jac_pose<EID>(CT, o, M, L.jp);
+    if (EID) {
+        // the general form is fma(M2, R2c, fma(M0, R0c, round(M1 R1c))): with M1 = 0 (row 0) the inner term is round(M0 R0c),
+        // with M0 = 0 (row 1) it is round(M1 R1c)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            L.jl[c] = __builtin_fma(M[2], PT[6 + c], M[0] * PT[c]);
+            L.jl[3 + c] = __builtin_fma(M[5], PT[6 + c], M[4] * PT[3 + c]);
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -480,11 +511,11 @@ __device__ __forceinline__ int ba_row_sum32(double *v, int lane)
 // lanes of a DPP row.  (Wider groups for the diagonal pairs — 32 / 64 lanes with row_bcast
 // reductions — pushed the kernel into VGPR spills and were slower.)
 template <int LANES>
-__device__ __forceinline__ void ba_schur_task(int a, int b2, int rg, int c0, int c1, int gl, int it0,
+__device__ __forceinline__ void ba_schur_task(int a, int b2_, int rg, int c0, int c1, int gl, int it0,
                                               const int *Pit, const int *__restrict__ pitem, const double *Wt,
                                               const double *Dl, const double *Bl, double *S, double *bs, int ld)
 {
-    const bool diag = a == b2;
+    const bool diag = a == b2_;
     double acc[12], accb[2];
 #pragma unroll
     for (int z = 0; z < 12; ++z) acc[z] = 0;
@@ -521,27 +552,32 @@ __device__ __forceinline__ void ba_schur_task(int a, int b2, int rg, int c0, int
             for (int cc = 0; cc < 6; ++cc)
                 acc[r * 6 + cc] += yy[r * 3] * ww[cc * 3] + yy[r * 3 + 1] * ww[cc * 3 + 1] + yy[r * 3 + 2] * ww[cc * 3 + 2];
     }
-    double red14[14];
+    // The 14 sums of the group's lanes by a recursive-halving butterfly (round 5; every sum used to walk its own 3- or 4-step
+    // DPP tree: 14 x 3 f64 adds in DPP form + a 14-way select per retiring lane).  At each step a lane keeps the half of its
+    // values that `sel` names and adds the partner's copy of it — 8 + 4 + 2 (+ 1) adds, the lane ends with the totals of
+    // entries 2 c, 2 c + 1 (8 lanes) or of entry c (16 lanes), c from the lane's selector bits.  A value still meets its
+    // partners in the order xor 1, xor 2, half mirror (, mirror) and fp addition is commutative: the same association tree as
+    // before, bit-identical sums.
+    double v[16];
 #pragma unroll
-    for (int z = 0; z < 14; ++z) {
-        double v = z < 12 ? acc[z] : accb[z - 12];
-        v += dpp_f64<SVS_DPP_XOR1>(v);
-        v += dpp_f64<SVS_DPP_XOR2>(v);
-        v += dpp_f64<SVS_DPP_HALF_MIRROR>(v);
-        if (LANES == 16) v += dpp_f64<SVS_DPP_MIRROR>(v);
-        red14[z] = v;
-    }
-    // every lane of the group holds the 14 sums; lane l retires entry l (and l + 8 in 8-lane groups)
+    for (int z = 0; z < 12; ++z) v[z] = acc[z];
+    v[12] = accb[0]; v[13] = accb[1]; v[14] = 0; v[15] = 0;
+    const bool b0 = gl & 1, b1 = gl & 2, b2 = gl & 4, b3 = gl & 8;
+    // selectors invariant under the later steps' permutations (half mirror flips bits 0..2, mirror bits 0..3)
+    const bool s0 = b0 != b2, s1 = b1 != b2, s2 = LANES == 16 ? (b2 != b3) : b2, s3 = b3;
+    ba_bfly<SVS_DPP_XOR1, 8>(v, s0);
+    ba_bfly<SVS_DPP_XOR2, 4>(v, s1);
+    ba_bfly<SVS_DPP_HALF_MIRROR, 2>(v, s2);
+    if (LANES == 16) ba_bfly<SVS_DPP_MIRROR, 1>(v, s3);
+    const int code = (s0 ? 8 : 0) + (s1 ? 4 : 0) + (s2 ? 2 : 0) + ((LANES == 16 && s3) ? 1 : 0);
 #pragma unroll
     for (int g = 0; g < 16 / LANES; ++g) {
-        double mine = red14[LANES * g];
-#pragma unroll
-        for (int z = 1; z < LANES; ++z) if (LANES * g + z < 14) mine = (gl == z) ? red14[LANES * g + z] : mine;
-        const int e = LANES * g + gl;
+        const double mine = v[g];
+        const int e = code + g;
         if (e < 12) {
             const int r = 2 * rg + e / 6, cc = e % 6;
-            S[(size_t)(6 * a + r) * ld + 6 * b2 + cc] -= mine;
-            if (!diag) S[(size_t)(6 * b2 + cc) * ld + 6 * a + r] -= mine;
+            S[(size_t)(6 * a + r) * ld + 6 * b2_ + cc] -= mine;
+            if (!diag) S[(size_t)(6 * b2_ + cc) * ld + 6 * a + r] -= mine;
         } else if (e < 14 && diag) bs[6 * a + 2 * rg + (e - 12)] -= mine;
     }
 }
@@ -864,8 +900,15 @@ __device__ __forceinline__ double ll_ld(const double *p)
                                                              __HIP_MEMORY_SCOPE_AGENT));
 }
 
-template <int MODE, int LLW>
-__global__ void __launch_bounds__(BA_THREADS, BA_MIN_WAVES_PER_SIMD)
+// A/B knob (tools/ab.sh): cap the kernel's registers below the 256 its two waves per SIMD may use, so that a wave of another
+// kernel fits beside them on the SIMD (amdgpu_num_vgpr takes half of the unified count on gfx90a+)
+#ifdef BA_NUM_VGPR
+#define BA_VGPR_ATTR __attribute__((amdgpu_num_vgpr(BA_NUM_VGPR)))
+#else
+#define BA_VGPR_ATTR
+#endif
+template <int MODE, int LLW, bool EID = false>
+__global__ void __launch_bounds__(BA_THREADS, BA_MIN_WAVES_PER_SIMD) BA_VGPR_ATTR
 k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_all, const BaRec *recs_all,
              const int *aux_all, BaWork wk, double delta, int iters, double *edge_chi2_all, long long *prof_all,
              int tile_cap, SbaArgs sba)
@@ -1034,7 +1077,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
             const double Xn[3] = { Xq[0], Xq[1], Xq[2] };
             const int kc = (unsigned)rc.lmkc >> 24;
             BaProj o;
-            ba_project(PTab2 + BA_PT * (kc >> 1), CTab + BA_CT * (kc & 1), X, rc.u, rc.v, o);
+            ba_project<EID>(PTab2 + BA_PT * (kc >> 1), CTab + BA_CT * (kc & 1), X, rc.u, rc.v, o);
             err[2 * i] = o.ex; err[2 * i + 1] = o.ey;
             double r0, r1;
             d_huber(o.ex * o.ex + o.ey * o.ey, delta, r0, r1);
@@ -1072,12 +1115,12 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                 const int kc = (unsigned)rc.lmkc >> 24;
                 const double *CT = CTab + BA_CT * (kc & 1);
                 BaProj o;
-                ba_project(tab + BA_PT * a, CT, X, rc.u, rc.v, o);
+                ba_project<EID>(tab + BA_PT * a, CT, X, rc.u, rc.v, o);
                 double r0, w;
                 d_huber(o.ex * o.ex + o.ey * o.ey, delta, r0, w);
                 acc[27] += r0;
                 double M[6], jp[12];
-                ba_jac_pose(CT, o, M, jp);
+                ba_jac_pose<EID>(CT, o, M, jp);
                 int t = 0;
 #pragma unroll
                 for (int r = 0; r < 6; ++r) {
@@ -1150,7 +1193,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                     const BaRec rc = recL[i];
                     const int kc = (unsigned)rc.lmkc >> 24;
                     BaLin L;
-                    ba_linearize(PTab + BA_PT * (kc >> 1), CTab + BA_CT * (kc & 1), X, rc.u, rc.v, delta, L);
+                    ba_linearize<EID>(PTab + BA_PT * (kc >> 1), CTab + BA_CT * (kc & 1), X, rc.u, rc.v, delta, L);
                     h0 += L.w * (L.jl[0] * L.jl[0] + L.jl[3] * L.jl[3]);
                     h3 += L.w * (L.jl[1] * L.jl[1] + L.jl[4] * L.jl[4]);
                     h5 += L.w * (L.jl[2] * L.jl[2] + L.jl[5] * L.jl[5]);
@@ -1230,7 +1273,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                             const BaRec rn = recL[min(i + 1, nobs - 1)];
                             const int kc = (unsigned)rc.lmkc >> 24;
                             BaLin L;
-                            ba_linearize(PT, CTab + BA_CT * (kc & 1), X, rc.u, rc.v, delta, L);
+                            ba_linearize<EID>(PT, CTab + BA_CT * (kc & 1), X, rc.u, rc.v, delta, L);
                             const double wl0 = L.w * L.jl[0], wl1 = L.w * L.jl[1], wl2 = L.w * L.jl[2],
                                          wl3 = L.w * L.jl[3], wl4 = L.w * L.jl[4], wl5 = L.w * L.jl[5];
 #pragma unroll
@@ -1310,7 +1353,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                         const BaRec rc = recL[i];
                         const int kc = (unsigned)rc.lmkc >> 24;
                         BaLin L;
-                        ba_linearize(PTab + BA_PT * (kc >> 1), CTab + BA_CT * (kc & 1), X, rc.u, rc.v, delta, L);
+                        ba_linearize<EID>(PTab + BA_PT * (kc >> 1), CTab + BA_CT * (kc & 1), X, rc.u, rc.v, delta, L);
                         const double wl0 = L.w * L.jl[0], wl1 = L.w * L.jl[1], wl2 = L.w * L.jl[2],
                                      wl3 = L.w * L.jl[3], wl4 = L.w * L.jl[4], wl5 = L.w * L.jl[5];
 #pragma unroll
@@ -1495,7 +1538,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                         const BaRec rn = recL[min(i + 1, nobs - 1)];
                         const int kc = (unsigned)rc.lmkc >> 24;
                         BaLin L;
-                        ba_linearize(PTab + BA_PT * (kc >> 1), CTab + BA_CT * (kc & 1), X, rc.u, rc.v, delta, L);
+                        ba_linearize<EID>(PTab + BA_PT * (kc >> 1), CTab + BA_CT * (kc & 1), X, rc.u, rc.v, delta, L);
                         const double *x6 = xp + 6 * (kc >> 1);
                         double t0 = 0, t1 = 0;
 #pragma unroll
@@ -1631,7 +1674,8 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
     }
     __syncthreads();
     if (MODE == 2 && ll_failed) {                          // a shard never arrived: nothing is written back
-        if (tid == 0) { jd.iters_done = -1; if (ll_leader) sba.parents[ll_prob].iters_done = -1; }
+        // (every shard says so, not only the leader: the shard that never arrived may be the leader)
+        if (tid == 0) { jd.iters_done = -1; sba.parents[ll_prob].iters_done = -1; }
         return;
     }
     if (MODE == 1) {
@@ -1651,7 +1695,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
             const double Xn[3] = { Xq[0], Xq[1], Xq[2] };
             const int kc = (unsigned)rc.lmkc >> 24;
             BaProj o;
-            ba_project(PTab2 + BA_PT * (kc >> 1), CTab + BA_CT * (kc & 1), X, rc.u, rc.v, o);
+            ba_project<EID>(PTab2 + BA_PT * (kc >> 1), CTab + BA_CT * (kc & 1), X, rc.u, rc.v, o);
             edge_chi2[lm_edges[i]] = o.ex * o.ex + o.ey * o.ey;
             rc = rn; rn = rnn; X[0] = Xn[0]; X[1] = Xn[1]; X[2] = Xn[2];
         }

@@ -45,7 +45,7 @@ static inline LlCaps ba_ll_caps(int max_kf)
     return c;
 }
 
-template <int LLW>
+template <int LLW, bool EID = false>
 __global__ void __launch_bounds__(BA_THREADS, BA_MIN_WAVES_PER_SIMD)
 k_ba_ll(BaDev *shards, const BaCams *camsp, double *poses_all, double *pts_all, const BaRec *recs_all, const int *aux_all,
         double delta, int iters, double *edge_chi2_all, long long *prof_all, LlCaps cap, SbaArgs sba)
@@ -213,7 +213,7 @@ k_ba_ll(BaDev *shards, const BaCams *camsp, double *poses_all, double *pts_all, 
                     const BaRec rc = rec[e];
                     const int kc = (unsigned)rc.lmkc >> 24;
                     BaLin L;
-                    ba_linearize(PT, CTab + BA_CT * (kc & 1), X, rc.u, rc.v, delta, L);
+                    ba_linearize<EID>(PT, CTab + BA_CT * (kc & 1), X, rc.u, rc.v, delta, L);
                     const double wl0 = L.w * L.jl[0], wl1 = L.w * L.jl[1], wl2 = L.w * L.jl[2],
                                  wl3 = L.w * L.jl[3], wl4 = L.w * L.jl[4], wl5 = L.w * L.jl[5];
 #pragma unroll
@@ -246,12 +246,12 @@ k_ba_ll(BaDev *shards, const BaCams *camsp, double *poses_all, double *pts_all, 
                     const double *CT = CTab + BA_CT * (kc & 1);
                     const double X[3] = { Xs[3 * j], Xs[3 * j + 1], Xs[3 * j + 2] };
                     BaProj o;
-                    ba_project(PT, CT, X, rc.u, rc.v, o);
+                    ba_project<EID>(PT, CT, X, rc.u, rc.v, o);
                     double r0, w;
                     d_huber(o.ex * o.ex + o.ey * o.ey, delta, r0, w);
                     acc[27] += r0;
                     double M[6], jp[12];
-                    ba_jac_pose(CT, o, M, jp);
+                    ba_jac_pose<EID>(CT, o, M, jp);
                     int t = 0;
 #pragma unroll
                     for (int r = 0; r < 6; ++r) {
@@ -527,7 +527,8 @@ k_ba_ll(BaDev *shards, const BaCams *camsp, double *poses_all, double *pts_all, 
     }
     __syncthreads();
     if (ll_failed) {
-        if (tid == 0) { jd.iters_done = -1; if (ll_leader) sba.parents[ll_prob].iters_done = -1; }
+        // (every shard says so, not only the leader: the shard that never arrived may be the leader)
+        if (tid == 0) { jd.iters_done = -1; sba.parents[ll_prob].iters_done = -1; }
         return;
     }
     // per-edge chi2 of the last evaluated state (g2o reports the errors of its last computeActiveErrors)
@@ -539,7 +540,7 @@ k_ba_ll(BaDev *shards, const BaCams *camsp, double *poses_all, double *pts_all, 
         const double *last_pts = LLX(slast);
         const double X[3] = { last_pts[3 * j], last_pts[3 * j + 1], last_pts[3 * j + 2] };
         BaProj o;
-        ba_project(LLT(slast) + BA_PT * (kc >> 1), CTab + BA_CT * (kc & 1), X, rc.u, rc.v, o);
+        ba_project<EID>(LLT(slast) + BA_PT * (kc >> 1), CTab + BA_CT * (kc & 1), X, rc.u, rc.v, o);
         edge_chi2[g_lm_edges[i]] = o.ex * o.ex + o.ey * o.ey;
     }
     for (int j = tid; j < nlm; j += BA_THREADS) {

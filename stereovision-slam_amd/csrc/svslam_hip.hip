@@ -91,6 +91,9 @@ struct svslam_ctx {
     GfttWork gw;
     // BA scratch
     BaWork bw;
+    int bw_jobs = 0;          // problems per call the BA scratch holds
+    bool ba_eid = false;      // the current BA call's cameras have identity extrinsic rotations (the reference's rig): the solver
+                              // kernels' EID instantiations leave the products with Re's zeros and ones out (k_ba.h: ba_project)
     std::unique_ptr<svs::ThreadPool> pool;   // host-side per-problem preparation
     long long *d_ba_prof = nullptr;
     // low-latency local BA (svslam_set_low_latency): a problem is dealt over ll.w workgroups (k_ba_split, k_local_ba_t<2>)
@@ -231,6 +234,13 @@ void tm_collect(svslam_ctx *c)
     c->nev = 0;
 }
 
+// both extrinsics are pure translations: quaternion exactly (0, 0, 0, 1)
+static bool ba_ext_identity(const double *ext_l, const double *ext_r)
+{
+    static const bool off = []{ const char *e = std::getenv("SVSLAM_BA_GENERIC_EXT"); return e && atoi(e) != 0; }();   // A/B and parity tests: the general code
+    for (const double *e : { ext_l, ext_r }) if (!(e[0] == 0.0 && e[1] == 0.0 && e[2] == 0.0 && e[3] == 1.0)) return false;
+    return !off;
+}
 // The local-BA solver of a batch whose structure the device builds: the batch kernel (one workgroup per problem), or — in
 // low-latency mode, for a few problems with landmark-major edges — every problem dealt over ll.w workgroups.
 template <int W> void launch_ba_ll_t(svslam_ctx *c, int nshards, BaDev *shards, const BaCams *cams, double *poses, double *pts, const BaRec *recs,
@@ -243,9 +253,13 @@ template <int W> void launch_ba_ll_t(svslam_ctx *c, int nshards, BaDev *shards, 
 template <int W> void launch_ba_ll_resident(svslam_ctx *c, int nshards, BaDev *shards, const BaCams *cams, double *poses, double *pts, const BaRec *recs,
                                             const int *aux, double delta, int iters, double *chi, BaDev *parents)
 {
-    hipLaunchKernelGGL((k_ba_ll<W>), dim3(nshards), dim3(BA_THREADS), ba_ll_lds_bytes(c->lim.max_kf, c->ll.caps), c->stream, shards, cams, poses, pts,
-                       recs, aux, delta, iters, chi, c->d_ba_prof, c->ll.caps,
-                       SbaArgs{ 0, 0, 0.0, nullptr, c->d_lm_trace, 0, c->ll.xch, c->ll.cnt, parents, c->ll.xch_stride });
+    const SbaArgs sa{ 0, 0, 0.0, nullptr, c->d_lm_trace, 0, c->ll.xch, c->ll.cnt, parents, c->ll.xch_stride };
+    if (c->ba_eid)
+        hipLaunchKernelGGL((k_ba_ll<W, true>), dim3(nshards), dim3(BA_THREADS), ba_ll_lds_bytes(c->lim.max_kf, c->ll.caps), c->stream, shards, cams, poses, pts,
+                           recs, aux, delta, iters, chi, c->d_ba_prof, c->ll.caps, sa);
+    else
+        hipLaunchKernelGGL((k_ba_ll<W, false>), dim3(nshards), dim3(BA_THREADS), ba_ll_lds_bytes(c->lim.max_kf, c->ll.caps), c->stream, shards, cams, poses, pts,
+                           recs, aux, delta, iters, chi, c->d_ba_prof, c->ll.caps, sa);
 }
 // test hook (SVSLAM_LL_TEST_DROP_SHARD = n: the next n low-latency launches): shard 0 of problem 0 never runs, its peers give up at
 // their first exchange and the call falls back to the batch solver — the path a GPU without room for every shard takes
@@ -267,8 +281,13 @@ void launch_ba_solver(svslam_ctx *c, int njobs, bool ll, BaDev *jobs, const BaCa
         hipLaunchKernelGGL(k_ba_build, dim3(njobs), dim3(BB_THREADS), bb_lds_bytes(max_nlm, max_nobs), c->stream, jobs, packed, uv, srt, recs, aux,
                            tile_cap, max_nlm, flag, 0, ec, 0);
         if (split_timing) { tm_end(c); tm_begin(c, FAM_DBG3, njobs); }
-        hipLaunchKernelGGL((k_local_ba_t<0, 1>), dim3(njobs), dim3(BA_THREADS), ba_lds_bytes(c->lim.max_kf), c->stream, jobs, cams, poses, pts, recs, aux,
-                           c->bw, delta, iters, chi, c->d_ba_prof, tile_cap, SbaArgs{ 0, 0, 0.0, nullptr, c->d_lm_trace, 0, nullptr, nullptr, nullptr, 0 });
+        const SbaArgs sa{ 0, 0, 0.0, nullptr, c->d_lm_trace, 0, nullptr, nullptr, nullptr, 0 };
+        if (c->ba_eid)
+            hipLaunchKernelGGL((k_local_ba_t<0, 1, true>), dim3(njobs), dim3(BA_THREADS), ba_lds_bytes(c->lim.max_kf), c->stream, jobs, cams, poses, pts, recs, aux,
+                               c->bw, delta, iters, chi, c->d_ba_prof, tile_cap, sa);
+        else
+            hipLaunchKernelGGL((k_local_ba_t<0, 1, false>), dim3(njobs), dim3(BA_THREADS), ba_lds_bytes(c->lim.max_kf), c->stream, jobs, cams, poses, pts, recs, aux,
+                               c->bw, delta, iters, chi, c->d_ba_prof, tile_cap, sa);
         return;
     }
     const int W = c->ll.w;
@@ -590,9 +609,13 @@ int svslam_create(const svslam_limits *lim, svslam_ctx **out)
     if (lim->max_kf > 0) {
         if (6 * lim->max_kf > BA_MAX_NP) return fail(c, "max_kf %d too large (<= %d)", lim->max_kf, BA_MAX_NP / 6);
         if (ba_tile_cap(lim->max_kf) < std::max(lim->max_kf, 64) || ba_lds_bytes(lim->max_kf) > 160 * 1024) return fail(c, "max_kf %d: reduced system does not fit LDS", lim->max_kf);
-        if (ba_work_alloc(c->bw, lim->max_jobs, lim->max_kf, lim->max_lm, lim->max_obs) != hipSuccess)
+        // per-problem solver scratch (0.5 MB + 0.2 KB per landmark slot): one per job of the largest BA call — with the map on the
+        // device that is a keyframe chunk (or the 64 problems a host-side BA call may bring), not max_jobs
+        c->bw_jobs = lim->device_map ? (int)std::max<size_t>(std::min<size_t>(SVSLAM_DMAP_CHUNK, (size_t)std::max(1, lim->max_streams)), std::min<size_t>(J, 64)) : lim->max_jobs;
+        if (ba_work_alloc(c->bw, c->bw_jobs, lim->max_kf, lim->max_lm, lim->max_obs) != hipSuccess)
             return fail(c, "BA workspace allocation failed");
-        for (const void *f : { reinterpret_cast<const void *>(k_local_ba_t<0, 1>), reinterpret_cast<const void *>(k_local_ba_t<1, 1>) })
+        for (const void *f : { reinterpret_cast<const void *>(k_local_ba_t<0, 1, false>), reinterpret_cast<const void *>(k_local_ba_t<0, 1, true>),
+                               reinterpret_cast<const void *>(k_local_ba_t<1, 1>) })
             HIPCHK(c, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ba_lds_bytes(lim->max_kf)));
         if (ba_tile_cap_ll(lim->max_kf) >= std::max(lim->max_kf, 64))
             for (const void *f : { reinterpret_cast<const void *>(k_local_ba_t<2, 4>), reinterpret_cast<const void *>(k_local_ba_t<2, 8>),
@@ -767,8 +790,9 @@ int svslam_set_low_latency(svslam_ctx *c, int on)
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_split), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)ba_split_lds_bytes(c->lim.max_lm, LL_MAX_W)));
             if (caps.B > 0)
-                for (const void *f : { reinterpret_cast<const void *>(k_ba_ll<4>), reinterpret_cast<const void *>(k_ba_ll<8>),
-                                       reinterpret_cast<const void *>(k_ba_ll<16>) })
+                for (const void *f : { reinterpret_cast<const void *>(k_ba_ll<4, false>), reinterpret_cast<const void *>(k_ba_ll<8, false>),
+                                       reinterpret_cast<const void *>(k_ba_ll<16, false>), reinterpret_cast<const void *>(k_ba_ll<4, true>),
+                                       reinterpret_cast<const void *>(k_ba_ll<8, true>), reinterpret_cast<const void *>(k_ba_ll<16, true>) })
                     HIPCHK(c, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ba_ll_lds_bytes(c->lim.max_kf, caps)));
             // Guard of the in-launch barriers: every shard of every problem of a launch must be resident at
             // the same time.  CUs of the device (SVSLAM_LL_CUS overrides: a CU-masked process, a partitioned device whose
@@ -779,7 +803,7 @@ int svslam_set_low_latency(svslam_ctx *c, int on)
             if (const char *ec = std::getenv("SVSLAM_LL_CUS")) { const int v = atoi(ec); if (v > 0) cus = std::min(cus, v); }
             int maxp = 0, per_cu = 0;
             for (; w >= 4; w /= 2) {
-                const void *fr = w == 4 ? reinterpret_cast<const void *>(k_ba_ll<4>) : w == 8 ? reinterpret_cast<const void *>(k_ba_ll<8>) : reinterpret_cast<const void *>(k_ba_ll<16>);
+                const void *fr = w == 4 ? reinterpret_cast<const void *>(k_ba_ll<4, false>) : w == 8 ? reinterpret_cast<const void *>(k_ba_ll<8, false>) : reinterpret_cast<const void *>(k_ba_ll<16, false>);
                 const void *fs = w == 4 ? reinterpret_cast<const void *>(k_local_ba_t<2, 4>) : w == 8 ? reinterpret_cast<const void *>(k_local_ba_t<2, 8>) : reinterpret_cast<const void *>(k_local_ba_t<2, 16>);
                 int blocks = ll_resident_blocks(fs, ba_lds_bytes_ll(c->lim.max_kf), cus);
                 if (caps.B > 0) blocks = std::min(blocks, ll_resident_blocks(fr, ba_ll_lds_bytes(c->lim.max_kf, caps), cus));
@@ -1102,6 +1126,7 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
 {
     if (njobs <= 0) return 0;
     if (njobs > c->lim.max_jobs) return fail(c, "local_ba: %d jobs > max_jobs", njobs);
+    if (njobs > c->bw_jobs) return fail(c, "local_ba: %d problems in one call, this context's solver scratch holds %d (a context with the map on the device takes 64 per host-side call)", njobs, c->bw_jobs);
     // the solver scratch (c->bw, the low-latency exchange area, the LM trace) is one per context: a deferred local BA of the
     // device map that is still running on the context's second stream owns it
     if (c->dmba.inflight) return fail(c, "local_ba: a deferred local BA of the device map is in flight on this context: call svslam_dmap_ba_collect first");
@@ -1116,6 +1141,7 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
     const long long t_prep0 = now_ns();
     if (arena_busy(c)) return -1;
     c->ar.reset();
+    c->ba_eid = ba_ext_identity(ext_l, ext_r);
     static_assert(sizeof(BaJob) == sizeof(svslam_ba_job), "job layout");
     const size_t TO = (size_t)std::max(total_obs, 1);
     const bool use_ll = !c->ba_host_build && ba_ll_usable(c, njobs);
@@ -1245,7 +1271,7 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
                          dp<unsigned int>(c, opk_o), dp<float2>(c, ouv_o), dp<int>(c, osrt_o), dp<BaRec>(c, orecs), dp<int>(c, oaux),
                          dp<double>(c, ochi), dp<int>(c, oflag), max_nlm, max_nobs, huber_delta, iters, c->timing_split);
     else
-        hipLaunchKernelGGL((k_local_ba_t<0, 1>), dim3(njobs), dim3(BA_THREADS), ba_lds_bytes(c->lim.max_kf), c->stream,
+        hipLaunchKernelGGL((k_local_ba_t<0, 1, false>), dim3(njobs), dim3(BA_THREADS), ba_lds_bytes(c->lim.max_kf), c->stream,
                            dp<BaDev>(c, ojobs), dp<BaCams>(c, ocams), dp<double>(c, oposes), dp<double>(c, opts),
                            dp<BaRec>(c, orecs), dp<int>(c, oaux), c->bw, huber_delta, iters, dp<double>(c, ochi), c->d_ba_prof,
                            tile_cap, SbaArgs{ 0, 0, 0.0, nullptr, c->d_lm_trace, 0, nullptr, nullptr, nullptr, 0 });
@@ -1687,6 +1713,7 @@ static int dmap_keyframe_impl(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, c
                            dec ? c->src_h : c->geom.h[0], false)) return -1;
     }
     const int NF = m.NF, NL = m.NL, MO = c->lim.max_obs, MK = c->lim.max_kf, MC = p->num_features;
+    c->ba_eid = ba_ext_identity(ext_l, ext_r);
     const bool use_ll = ba_ll_usable(c, njobs);
     const int tile_cap = use_ll ? ba_ll_tile_cap(c) : ba_tile_cap(MK);
     const size_t aux_stride = ba_aux_layout(MK, NL, MO, MO, MK, 0, ba_tile_bound(NL, MO, MK, tile_cap)).total + ba_pitem_bound(MO, MK) +
