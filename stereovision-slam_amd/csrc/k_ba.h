@@ -372,6 +372,13 @@ __device__ __forceinline__ void d_inv3(const double *A, double *Ai)
     Ai[6] = c2 * id; Ai[7] = (A[1] * A[6] - A[0] * A[7]) * id; Ai[8] = (A[0] * A[4] - A[1] * A[3]) * id;
 }
 
+// Accumulations of two / three products: nested FMAs into the accumulator (round 5).  `x += a * b + c * d` compiles to
+// mul, fmac, add — the sum of the products is rounded before it meets x; the nested form is one instruction shorter per
+// entry (there are ~70 such entries per linearised edge and 42 per Schur item) and rounds once less.
+#define BA_ACC2(x, a, b, c, d) x = __builtin_fma(a, b, __builtin_fma(c, d, x))
+#define BA_ACC3(x, a, b, c, d, e, f) x = __builtin_fma(a, b, __builtin_fma(c, d, __builtin_fma(e, f, x)))
+#define BA_SUB2(x, a, b, c, d) x = __builtin_fma(-(a), b, __builtin_fma(-(c), d, x))
+
 // 6x3 blocks (18 doubles = 144 B, 16-B aligned) moved as 9 x 16-byte accesses
 __device__ __forceinline__ void ld_block18(const double *p, double *o)
 {
@@ -538,8 +545,8 @@ __device__ __forceinline__ void ba_schur_task(int a, int b2_, int rg, int c0, in
         }
         if (diag) {
             const double g0 = Bl[3 * lq], g1 = Bl[3 * lq + 1], g2 = Bl[3 * lq + 2];
-            accb[0] += yy[0] * g0 + yy[1] * g1 + yy[2] * g2;
-            accb[1] += yy[3] * g0 + yy[4] * g1 + yy[5] * g2;
+            BA_ACC3(accb[0], yy[0], g0, yy[1], g1, yy[2], g2);
+            BA_ACC3(accb[1], yy[3], g0, yy[4], g1, yy[5], g2);
         }
         {
             const double *w2 = Wt + 18 * bw;
@@ -550,7 +557,7 @@ __device__ __forceinline__ void ba_schur_task(int a, int b2_, int rg, int c0, in
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int cc = 0; cc < 6; ++cc)
-                acc[r * 6 + cc] += yy[r * 3] * ww[cc * 3] + yy[r * 3 + 1] * ww[cc * 3 + 1] + yy[r * 3 + 2] * ww[cc * 3 + 2];
+                BA_ACC3(acc[r * 6 + cc], yy[r * 3], ww[cc * 3], yy[r * 3 + 1], ww[cc * 3 + 1], yy[r * 3 + 2], ww[cc * 3 + 2]);
     }
     // The 14 sums of the group's lanes by a recursive-halving butterfly (round 5; every sum used to walk its own 3- or 4-step
     // DPP tree: 14 x 3 f64 adds in DPP form + a 14-way select per retiring lane).  At each step a lane keeps the half of its
@@ -1126,8 +1133,8 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                 for (int r = 0; r < 6; ++r) {
                     const double w0 = w * jp[r], w1 = w * jp[6 + r];
 #pragma unroll
-                    for (int c = r; c < 6; ++c) { acc[t] += w0 * jp[c] + w1 * jp[6 + c]; ++t; }
-                    acc[21 + r] -= w0 * o.ex + w1 * o.ey;
+                    for (int c = r; c < 6; ++c) { BA_ACC2(acc[t], w0, jp[c], w1, jp[6 + c]); ++t; }
+                    BA_SUB2(acc[21 + r], w0, o.ex, w1, o.ey);
                 }
                 rc = rn; rn = rnn; X[0] = Xn[0]; X[1] = Xn[1]; X[2] = Xn[2];
             }
@@ -1279,13 +1286,13 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
 #pragma unroll
                             for (int r = 0; r < 6; ++r) {
                                 const double p0 = L.jp[r], p1 = L.jp[6 + r];
-                                ww[r * 3 + 0] += p0 * wl0 + p1 * wl3;
-                                ww[r * 3 + 1] += p0 * wl1 + p1 * wl4;
-                                ww[r * 3 + 2] += p0 * wl2 + p1 * wl5;
+                                BA_ACC2(ww[r * 3 + 0], p0, wl0, p1, wl3);
+                                BA_ACC2(ww[r * 3 + 1], p0, wl1, p1, wl4);
+                                BA_ACC2(ww[r * 3 + 2], p0, wl2, p1, wl5);
                             }
-                            b3[0] -= wl0 * L.ex + wl3 * L.ey; b3[1] -= wl1 * L.ex + wl4 * L.ey; b3[2] -= wl2 * L.ex + wl5 * L.ey;
-                            h[0] += wl0 * L.jl[0] + wl3 * L.jl[3]; h[1] += wl0 * L.jl[1] + wl3 * L.jl[4]; h[2] += wl0 * L.jl[2] + wl3 * L.jl[5];
-                            h[3] += wl1 * L.jl[1] + wl4 * L.jl[4]; h[4] += wl1 * L.jl[2] + wl4 * L.jl[5]; h[5] += wl2 * L.jl[2] + wl5 * L.jl[5];
+                            BA_SUB2(b3[0], wl0, L.ex, wl3, L.ey); BA_SUB2(b3[1], wl1, L.ex, wl4, L.ey); BA_SUB2(b3[2], wl2, L.ex, wl5, L.ey);
+                            BA_ACC2(h[0], wl0, L.jl[0], wl3, L.jl[3]); BA_ACC2(h[1], wl0, L.jl[1], wl3, L.jl[4]); BA_ACC2(h[2], wl0, L.jl[2], wl3, L.jl[5]);
+                            BA_ACC2(h[3], wl1, L.jl[1], wl4, L.jl[4]); BA_ACC2(h[4], wl1, L.jl[2], wl4, L.jl[5]); BA_ACC2(h[5], wl2, L.jl[2], wl5, L.jl[5]);
                             rc = rn;
                         }
                         double D[9] = { h[0] + lambda, h[1], h[2], h[1], h[3] + lambda, h[4], h[2], h[4], h[5] + lambda }, Di[9];
@@ -1297,8 +1304,8 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                             const double y0 = x0 * Di[0] + x1 * Di[1] + x2 * Di[2], y1 = x0 * Di[1] + x1 * Di[4] + x2 * Di[5],
                                          y2 = x0 * Di[2] + x1 * Di[5] + x2 * Di[8];
 #pragma unroll
-                            for (int cc = r; cc < 6; ++cc) { acc[t] += y0 * ww[cc * 3] + y1 * ww[cc * 3 + 1] + y2 * ww[cc * 3 + 2]; ++t; }
-                            acc[21 + r] += y0 * b3[0] + y1 * b3[1] + y2 * b3[2];
+                            for (int cc = r; cc < 6; ++cc) { BA_ACC3(acc[t], y0, ww[cc * 3], y1, ww[cc * 3 + 1], y2, ww[cc * 3 + 2]); ++t; }
+                            BA_ACC3(acc[21 + r], y0, b3[0], y1, b3[1], y2, b3[2]);
                         }
                         e0 = ne0; e1 = ne1; X[0] = Xn[0]; X[1] = Xn[1]; X[2] = Xn[2];
                     }
@@ -1359,13 +1366,13 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
 #pragma unroll
                         for (int a = 0; a < 6; ++a) {
                             const double p0 = L.jp[a], p1 = L.jp[6 + a];
-                            wacc[a * 3 + 0] += p0 * wl0 + p1 * wl3;
-                            wacc[a * 3 + 1] += p0 * wl1 + p1 * wl4;
-                            wacc[a * 3 + 2] += p0 * wl2 + p1 * wl5;
+                            BA_ACC2(wacc[a * 3 + 0], p0, wl0, p1, wl3);
+                            BA_ACC2(wacc[a * 3 + 1], p0, wl1, p1, wl4);
+                            BA_ACC2(wacc[a * 3 + 2], p0, wl2, p1, wl5);
                         }
-                        b3[0] -= wl0 * L.ex + wl3 * L.ey; b3[1] -= wl1 * L.ex + wl4 * L.ey; b3[2] -= wl2 * L.ex + wl5 * L.ey;
-                        h[0] += wl0 * L.jl[0] + wl3 * L.jl[3]; h[1] += wl0 * L.jl[1] + wl3 * L.jl[4]; h[2] += wl0 * L.jl[2] + wl3 * L.jl[5];
-                        h[3] += wl1 * L.jl[1] + wl4 * L.jl[4]; h[4] += wl1 * L.jl[2] + wl4 * L.jl[5]; h[5] += wl2 * L.jl[2] + wl5 * L.jl[5];
+                        BA_SUB2(b3[0], wl0, L.ex, wl3, L.ey); BA_SUB2(b3[1], wl1, L.ex, wl4, L.ey); BA_SUB2(b3[2], wl2, L.ex, wl5, L.ey);
+                        BA_ACC2(h[0], wl0, L.jl[0], wl3, L.jl[3]); BA_ACC2(h[1], wl0, L.jl[1], wl3, L.jl[4]); BA_ACC2(h[2], wl0, L.jl[2], wl3, L.jl[5]);
+                        BA_ACC2(h[3], wl1, L.jl[1], wl4, L.jl[4]); BA_ACC2(h[4], wl1, L.jl[2], wl4, L.jl[5]); BA_ACC2(h[5], wl2, L.jl[2], wl5, L.jl[5]);
                     }
                     double *wd = Wt + 18 * bq;
                     if (MODE == 2) ll_ba[bq] = (int)((unsigned)recL[e0].lmkc >> 25);      // the block's pose (back-substitution from the stored blocks)
@@ -1545,10 +1552,10 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                         for (int a = 0; a < 6; ++a) { t0 += L.jp[a] * x6[a]; t1 += L.jp[6 + a] * x6[a]; }
                         const double wl0 = L.w * L.jl[0], wl1 = L.w * L.jl[1], wl2 = L.w * L.jl[2],
                                      wl3 = L.w * L.jl[3], wl4 = L.w * L.jl[4], wl5 = L.w * L.jl[5];
-                        b3[0] -= wl0 * L.ex + wl3 * L.ey; b3[1] -= wl1 * L.ex + wl4 * L.ey; b3[2] -= wl2 * L.ex + wl5 * L.ey;
-                        g3[0] += wl0 * t0 + wl3 * t1; g3[1] += wl1 * t0 + wl4 * t1; g3[2] += wl2 * t0 + wl5 * t1;
-                        h[0] += wl0 * L.jl[0] + wl3 * L.jl[3]; h[1] += wl0 * L.jl[1] + wl3 * L.jl[4]; h[2] += wl0 * L.jl[2] + wl3 * L.jl[5];
-                        h[3] += wl1 * L.jl[1] + wl4 * L.jl[4]; h[4] += wl1 * L.jl[2] + wl4 * L.jl[5]; h[5] += wl2 * L.jl[2] + wl5 * L.jl[5];
+                        BA_SUB2(b3[0], wl0, L.ex, wl3, L.ey); BA_SUB2(b3[1], wl1, L.ex, wl4, L.ey); BA_SUB2(b3[2], wl2, L.ex, wl5, L.ey);
+                        BA_ACC2(g3[0], wl0, t0, wl3, t1); BA_ACC2(g3[1], wl1, t0, wl4, t1); BA_ACC2(g3[2], wl2, t0, wl5, t1);
+                        BA_ACC2(h[0], wl0, L.jl[0], wl3, L.jl[3]); BA_ACC2(h[1], wl0, L.jl[1], wl3, L.jl[4]); BA_ACC2(h[2], wl0, L.jl[2], wl3, L.jl[5]);
+                        BA_ACC2(h[3], wl1, L.jl[1], wl4, L.jl[4]); BA_ACC2(h[4], wl1, L.jl[2], wl4, L.jl[5]); BA_ACC2(h[5], wl2, L.jl[2], wl5, L.jl[5]);
                         rc = rn;
                     }
                     if (e1 > e0) {
