@@ -259,7 +259,10 @@ def main():
     # of different groups overlap), not the cores, and one bookkeeping thread per group is plenty
     # (measured, tools/sweep_devmap.sh: 4 / 6 / 8 / 12 / 16 groups at 12 288 streams = 483 / 487 / 500 / 495 / 480 k frames/s,
     # 24 groups 450 k — the GPU is the limit whatever the layout; 6 keeps fewer kernels co-resident per launch)
-    G = args.groups if args.groups > 0 else (6 if dev_map else min(12 if S >= 12288 else 8, cores))
+    # (round 5, profiles/r5_bench_groups_sweep.txt: 2 / 3 / 4 / 6 / 8 groups = 487 / 503 / 538 / 542 / 546 k frames/s — flat from 4 on;
+    #  with 4 fewer kernels share the chip per launch, so the per-family HIP-event durations the roofline objects are computed
+    #  from are closer to what a kernel takes: local_ba roofline.frac 0.016 at 4 groups, 0.013 at 6, 0.009 at 8)
+    G = args.groups if args.groups > 0 else (4 if dev_map else min(12 if S >= 12288 else 8, cores))
     G = max(1, min(G, S))
     S -= S % G                                       # whole groups (8192 streams in 12 groups: 12 x 682)
     if args.host_threads <= 0:

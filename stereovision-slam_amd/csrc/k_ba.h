@@ -489,7 +489,46 @@ __device__ __forceinline__ void ba_linearize(const double *PT, const double *CT,
         for (int c = 0; c < 3; ++c)
             L.jl[3 * r + c] = M[3 * r] * PT[c] + M[3 * r + 1] * PT[3 + c] + M[3 * r + 2] * PT[6 + c];
 }
-
+// The pose normal equations of one edge: acc[0..20] += upper triangle of Jp^T w Jp, acc[21..26] -= Jp^T w e.
+// EID: the products with Jp's two zeros (row 0 column 1, row 1 column 0) are exact zeros and are left out.
+template <bool EID>
+__device__ __forceinline__ void ba_acc_pose(double *acc, const double *jp, double w, double ex, double ey)
+{
+    int t = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const double w0 = w * jp[r], w1 = w * jp[6 + r];
+#pragma unroll
+        for (int c = r; c < 6; ++c) {
+            if (EID && r == 0) { if (c != 1) acc[t] = __builtin_fma(w0, jp[c], acc[t]); }
+            else if (EID && r == 1) acc[t] = __builtin_fma(w1, jp[6 + c], acc[t]);
+            else BA_ACC2(acc[t], w0, jp[c], w1, jp[6 + c]);
+            ++t;
+        }
+        if (EID && r == 0) acc[21] = __builtin_fma(-w0, ex, acc[21]);
+        else if (EID && r == 1) acc[22] = __builtin_fma(-w1, ey, acc[22]);
+        else BA_SUB2(acc[21 + r], w0, ex, w1, ey);
+    }
+}
+// W (6x3) += Jp^T w Jl of one edge, wl = w Jl.  EID: Jp's row 0 has a zero in column 1, its row 1 in column 0 — the
+// products with them are exact zeros and are left out (the nested-FMA form adds them to the accumulator one by one)
+template <bool EID>
+__device__ __forceinline__ void ba_acc_w(double *ww, const double *jp, double wl0, double wl1, double wl2, double wl3, double wl4, double wl5)
+{
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const double p0 = jp[r], p1 = jp[6 + r];
+        if (EID && r == 0) {
+            ww[0] = __builtin_fma(p0, wl0, ww[0]); ww[1] = __builtin_fma(p0, wl1, ww[1]); ww[2] = __builtin_fma(p0, wl2, ww[2]);
+        } else if (EID && r == 1) {
+            ww[3] = __builtin_fma(p1, wl3, ww[3]); ww[4] = __builtin_fma(p1, wl4, ww[4]); ww[5] = __builtin_fma(p1, wl5, ww[5]);
+        } else {
+            BA_ACC2(ww[r * 3 + 0], p0, wl0, p1, wl3);
+            BA_ACC2(ww[r * 3 + 1], p0, wl1, p1, wl4);
+            BA_ACC2(ww[r * 3 + 2], p0, wl2, p1, wl5);
+        }
+    }
+}
 // Recursive-halving butterfly over the 16 lanes of a DPP row (k_geom.h:po_bfly): 32 values per lane in, the
 // row totals of values 2 code, 2 code + 1 out in v[0], v[1] (code = 8 s0 + 4 s1 + 2 s2 + s3; 30 adds, not 32 x 4)
 template <int CTRL, int HALF>
@@ -1128,14 +1167,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                 acc[27] += r0;
                 double M[6], jp[12];
                 ba_jac_pose<EID>(CT, o, M, jp);
-                int t = 0;
-#pragma unroll
-                for (int r = 0; r < 6; ++r) {
-                    const double w0 = w * jp[r], w1 = w * jp[6 + r];
-#pragma unroll
-                    for (int c = r; c < 6; ++c) { BA_ACC2(acc[t], w0, jp[c], w1, jp[6 + c]); ++t; }
-                    BA_SUB2(acc[21 + r], w0, o.ex, w1, o.ey);
-                }
+                ba_acc_pose<EID>(acc, jp, w, o.ex, o.ey);
                 rc = rn; rn = rnn; X[0] = Xn[0]; X[1] = Xn[1]; X[2] = Xn[2];
             }
         }
@@ -1283,13 +1315,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                             ba_linearize<EID>(PT, CTab + BA_CT * (kc & 1), X, rc.u, rc.v, delta, L);
                             const double wl0 = L.w * L.jl[0], wl1 = L.w * L.jl[1], wl2 = L.w * L.jl[2],
                                          wl3 = L.w * L.jl[3], wl4 = L.w * L.jl[4], wl5 = L.w * L.jl[5];
-#pragma unroll
-                            for (int r = 0; r < 6; ++r) {
-                                const double p0 = L.jp[r], p1 = L.jp[6 + r];
-                                BA_ACC2(ww[r * 3 + 0], p0, wl0, p1, wl3);
-                                BA_ACC2(ww[r * 3 + 1], p0, wl1, p1, wl4);
-                                BA_ACC2(ww[r * 3 + 2], p0, wl2, p1, wl5);
-                            }
+                            ba_acc_w<EID>(ww, L.jp, wl0, wl1, wl2, wl3, wl4, wl5);
                             BA_SUB2(b3[0], wl0, L.ex, wl3, L.ey); BA_SUB2(b3[1], wl1, L.ex, wl4, L.ey); BA_SUB2(b3[2], wl2, L.ex, wl5, L.ey);
                             BA_ACC2(h[0], wl0, L.jl[0], wl3, L.jl[3]); BA_ACC2(h[1], wl0, L.jl[1], wl3, L.jl[4]); BA_ACC2(h[2], wl0, L.jl[2], wl3, L.jl[5]);
                             BA_ACC2(h[3], wl1, L.jl[1], wl4, L.jl[4]); BA_ACC2(h[4], wl1, L.jl[2], wl4, L.jl[5]); BA_ACC2(h[5], wl2, L.jl[2], wl5, L.jl[5]);
@@ -1363,13 +1389,7 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                         ba_linearize<EID>(PTab + BA_PT * (kc >> 1), CTab + BA_CT * (kc & 1), X, rc.u, rc.v, delta, L);
                         const double wl0 = L.w * L.jl[0], wl1 = L.w * L.jl[1], wl2 = L.w * L.jl[2],
                                      wl3 = L.w * L.jl[3], wl4 = L.w * L.jl[4], wl5 = L.w * L.jl[5];
-#pragma unroll
-                        for (int a = 0; a < 6; ++a) {
-                            const double p0 = L.jp[a], p1 = L.jp[6 + a];
-                            BA_ACC2(wacc[a * 3 + 0], p0, wl0, p1, wl3);
-                            BA_ACC2(wacc[a * 3 + 1], p0, wl1, p1, wl4);
-                            BA_ACC2(wacc[a * 3 + 2], p0, wl2, p1, wl5);
-                        }
+                        ba_acc_w<EID>(wacc, L.jp, wl0, wl1, wl2, wl3, wl4, wl5);
                         BA_SUB2(b3[0], wl0, L.ex, wl3, L.ey); BA_SUB2(b3[1], wl1, L.ex, wl4, L.ey); BA_SUB2(b3[2], wl2, L.ex, wl5, L.ey);
                         BA_ACC2(h[0], wl0, L.jl[0], wl3, L.jl[3]); BA_ACC2(h[1], wl0, L.jl[1], wl3, L.jl[4]); BA_ACC2(h[2], wl0, L.jl[2], wl3, L.jl[5]);
                         BA_ACC2(h[3], wl1, L.jl[1], wl4, L.jl[4]); BA_ACC2(h[4], wl1, L.jl[2], wl4, L.jl[5]); BA_ACC2(h[5], wl2, L.jl[2], wl5, L.jl[5]);

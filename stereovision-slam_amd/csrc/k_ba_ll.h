@@ -216,13 +216,7 @@ k_ba_ll(BaDev *shards, const BaCams *camsp, double *poses_all, double *pts_all, 
                     ba_linearize<EID>(PT, CTab + BA_CT * (kc & 1), X, rc.u, rc.v, delta, L);
                     const double wl0 = L.w * L.jl[0], wl1 = L.w * L.jl[1], wl2 = L.w * L.jl[2],
                                  wl3 = L.w * L.jl[3], wl4 = L.w * L.jl[4], wl5 = L.w * L.jl[5];
-#pragma unroll
-                    for (int r = 0; r < 6; ++r) {
-                        const double p0 = L.jp[r], p1 = L.jp[6 + r];
-                        BA_ACC2(wacc[r * 3 + 0], p0, wl0, p1, wl3);
-                        BA_ACC2(wacc[r * 3 + 1], p0, wl1, p1, wl4);
-                        BA_ACC2(wacc[r * 3 + 2], p0, wl2, p1, wl5);
-                    }
+                    ba_acc_w<EID>(wacc, L.jp, wl0, wl1, wl2, wl3, wl4, wl5);
                     BA_SUB2(b3[0], wl0, L.ex, wl3, L.ey); BA_SUB2(b3[1], wl1, L.ex, wl4, L.ey); BA_SUB2(b3[2], wl2, L.ex, wl5, L.ey);
                     BA_ACC2(h[0], wl0, L.jl[0], wl3, L.jl[3]); BA_ACC2(h[1], wl0, L.jl[1], wl3, L.jl[4]); BA_ACC2(h[2], wl0, L.jl[2], wl3, L.jl[5]);
                     BA_ACC2(h[3], wl1, L.jl[1], wl4, L.jl[4]); BA_ACC2(h[4], wl1, L.jl[2], wl4, L.jl[5]); BA_ACC2(h[5], wl2, L.jl[2], wl5, L.jl[5]);
@@ -252,14 +246,7 @@ k_ba_ll(BaDev *shards, const BaCams *camsp, double *poses_all, double *pts_all, 
                     acc[27] += r0;
                     double M[6], jp[12];
                     ba_jac_pose<EID>(CT, o, M, jp);
-                    int t = 0;
-#pragma unroll
-                    for (int r = 0; r < 6; ++r) {
-                        const double w0 = w * jp[r], w1 = w * jp[6 + r];
-#pragma unroll
-                        for (int c = r; c < 6; ++c) { BA_ACC2(acc[t], w0, jp[c], w1, jp[6 + c]); ++t; }
-                        BA_SUB2(acc[21 + r], w0, o.ex, w1, o.ey);
-                    }
+                    ba_acc_pose<EID>(acc, jp, w, o.ex, o.ey);
                 }
             }
         }
