@@ -153,11 +153,23 @@ __device__ __forceinline__ bool d_ldlt6(const double *H, const double *b, double
 
 #define PO_MAX_EDGES 512       // per job: 64 * PO_WAVES threads x (8 / PO_WAVES) register slots
 
-__device__ __forceinline__ void po_error(const double *cam, const double *T, const double *P,
+// (Rt: the pose as rotation matrix (9, row major) + translation (3) — po_pose_table — so that the rig-frame point is nine
+// FMAs per edge instead of the quaternion sandwich's two dozen operations; round 5)
+__device__ __forceinline__ void po_pose_table(const double *T, double *Rt)
+{
+    d_quat_to_R(T, Rt);
+    Rt[9] = T[4]; Rt[10] = T[5]; Rt[11] = T[6];
+}
+__device__ __forceinline__ void po_act(const double *Rt, const double *P, double *pc)
+{
+#pragma unroll
+    for (int r = 0; r < 3; ++r) pc[r] = Rt[3 * r] * P[0] + Rt[3 * r + 1] * P[1] + Rt[3 * r + 2] * P[2] + Rt[9 + r];
+}
+__device__ __forceinline__ void po_error(const double *cam, const double *Rt, const double *P,
                                          double u, double v, double &e0, double &e1)
 {
     double pc[3];
-    d_se3_act(T, P, pc);
+    po_act(Rt, P, pc);
     double px = cam[0] * pc[0] + cam[2] * pc[2];
     double py = cam[1] * pc[1] + cam[3] * pc[2];
     const double iz = d_rcp1(pc[2]);            // one reciprocal instead of two divisions (<= 1 ulp apart)
@@ -353,13 +365,15 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
                 PO_TICK(5);
 #pragma unroll
                 for (int i = 0; i < 32; ++i) acc[i] = 0;
+                double Rt[12];
+                po_pose_table(T, Rt);
 #pragma unroll
                 for (int s = 0; s < SLOTS; ++s) {
                     if (!(((vmask & ~omask) >> s) & 1)) continue;
                     double Pq[3], mu_, mv_;
                     edge(s, Pq, mu_, mv_);
                     double pc[3];
-                    d_se3_act(T, Pq, pc);
+                    po_act(Rt, Pq, pc);
                     double X = pc[0], Y = pc[1], Z = pc[2];
                     double px = cam[0] * X + cam[2] * Z, py = cam[1] * Y + cam[3] * Z;
                     const double iz = d_rcp1(Z);
@@ -372,14 +386,22 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
                     double fx = cam[0], fy = cam[1];
                     double J0[6] = { -fx * Zinv, 0, fx * X * Zinv2, fx * X * Y * Zinv2, -fx - fx * X * X * Zinv2, fx * Y * Zinv };
                     double J1[6] = { 0, -fy * Zinv, fy * Y * Zinv2, fy + fy * Y * Y * Zinv2, -fy * X * Y * Zinv2, -fy * X * Zinv };
+                    // H += w J^T J, b -= w J^T e by nested FMAs into the accumulators (round 5: `acc += w * (a * b + c * d)` was
+                    // mul, fma, fma per entry), the products with the two structural zeros of the Jacobian (J0[1], J1[0]:
+                    // g2o_types.h:159-162) left out: 50 instead of 81 instructions per edge
                     int k = 0;
 #pragma unroll
                     for (int a = 0; a < 6; ++a) {
+                        const double w0 = w * J0[a], w1 = w * J1[a];       // (w0 of a = 1 and w1 of a = 0 are never used)
 #pragma unroll
-                        for (int c = a; c < 6; ++c) { acc[k] += w * (J0[a] * J0[c] + J1[a] * J1[c]); ++k; }
+                        for (int c = a; c < 6; ++c) {
+                            if (a != 0 && c != 0) acc[k] = __builtin_fma(w1, J1[c], acc[k]);        // row 1 of J: zero in column 0
+                            if (a != 1 && c != 1) acc[k] = __builtin_fma(w0, J0[c], acc[k]);        // row 0 of J: zero in column 1
+                            ++k;
+                        }
+                        if (a != 0) acc[21 + a] = __builtin_fma(-w1, ey, acc[21 + a]);
+                        if (a != 1) acc[21 + a] = __builtin_fma(-w0, ex, acc[21 + a]);
                     }
-#pragma unroll
-                    for (int a = 0; a < 6; ++a) acc[21 + a] -= w * (J0[a] * ex + J1[a] * ey);
                 }
                 PO_TICKV(0, acc[0] + acc[27]);
                 po_block_sum32<WAVES>(acc, s_red, tid);
@@ -423,12 +445,14 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
                     have_eval = true;
                     PO_TICKV(3, T[0] + T[6]);
                     double tchi = 0;
+                    double Rtn[12];
+                    po_pose_table(T, Rtn);
 #pragma unroll
                     for (int s = 0; s < SLOTS; ++s) {
                         if (!(((vmask & ~omask) >> s) & 1)) continue;
                         double Pq[3], mu_, mv_, ea, eb;
                         edge(s, Pq, mu_, mv_);
-                        po_error(cam, T, Pq, mu_, mv_, ea, eb);
+                        po_error(cam, Rtn, Pq, mu_, mv_, ea, eb);
                         double e2 = ea * ea + eb * eb, w, rr = e2;
                         if (robust) d_huber(e2, 1.0, rr, w);
                         tchi += rr;
@@ -466,6 +490,8 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
         }
         // classify (src/frontend.cpp:495-525)
         int co = 0;
+        double RtT[12], RtE[12];
+        po_pose_table(T, RtT); po_pose_table(Te, RtE);
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
             if (!((vmask >> s) & 1)) continue;
@@ -473,8 +499,8 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
             double Pq[3], mu_, mv_, ea = 0, eb = 0;
             edge(s, Pq, mu_, mv_);
             // an outlier of this round: its error at the round's result; an active edge: at the last evaluated trial
-            if (was) po_error(cam, T, Pq, mu_, mv_, ea, eb);
-            else if (have_eval) po_error(cam, Te, Pq, mu_, mv_, ea, eb);
+            if (was) po_error(cam, RtT, Pq, mu_, mv_, ea, eb);
+            else if (have_eval) po_error(cam, RtE, Pq, mu_, mv_, ea, eb);
             double chi2 = ea * ea + eb * eb;
             const bool now = chi2 > chi2_th;
             co += (now ? 1 : 0) + (now != was ? 1 << 16 : 0);           // outliers | flags changed << 16 (<= 512 edges)
