@@ -274,13 +274,6 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
     __shared__ __attribute__((aligned(16))) double s_red[4 * WAVES * 32];
     __shared__ double s_one[2][4 * WAVES];
     __shared__ int s_int[WAVES];
-    // WAVES == 4 (one camera per GPU): LM trials are evaluated four at a time — see "speculative trials" below.  Every wave
-    // then needs every edge: positions and pixels of the job in LDS, the active flags as one bit per edge, four candidate
-    // records per step (double-buffered)
-    constexpr bool SPEC = WAVES == 4;
-    __shared__ double s_edge[SPEC ? 5 * PO_MAX_EDGES : 1];
-    __shared__ unsigned long long s_act[SPEC ? PO_MAX_EDGES / 64 : 1];
-    __shared__ double s_cand[SPEC ? 2 * 4 * 12 : 1];
     PoseJob &jb = jobs[blockIdx.x];                    // (may be pinned host memory, svslam_hip.hip:dpz — every field is read once)
     const int tid = threadIdx.x;
     const int n = jb.npts, jb_pt_ofs = jb.pt_ofs;
@@ -342,18 +335,6 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
             u_ = (double)m.x; v_ = (double)m.y;
         }
     };
-    if (SPEC) {
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-            const int e = s * NT + tid;
-            if (e < n) {
-                double Pq[3], mu_, mv_;
-                edge(s, Pq, mu_, mv_);
-                s_edge[e] = Pq[0]; s_edge[PO_MAX_EDGES + e] = Pq[1]; s_edge[2 * PO_MAX_EDGES + e] = Pq[2];
-                s_edge[3 * PO_MAX_EDGES + e] = mu_; s_edge[4 * PO_MAX_EDGES + e] = mv_;
-            }
-        }
-    }
     double Te[7] = { 0, 0, 0, 1, 0, 0, 0 };        // pose of the last evaluated LM trial
     bool have_eval = false;
     bool robust = true;
@@ -376,14 +357,6 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
         for (int i = 0; i < 7; ++i) T[i] = T0[i];
         int nact = 0;
         nact = po_block_sum_i32<WAVES>(__builtin_popcount(vmask & ~omask), s_int, tid);
-        if (SPEC) {                             // this round's active edges, one bit each (edge e = s NT + tid: word s WAVES + wave)
-#pragma unroll
-            for (int s = 0; s < SLOTS; ++s) {
-                const unsigned long long m = __ballot((((vmask & ~omask) >> s) & 1u) != 0u);
-                if ((tid & 63) == 0) s_act[s * WAVES + (tid >> 6)] = m;
-            }
-            __syncthreads();
-        }
         if (nact > 0) {
             double lambda = 0, ni = 2;
             for (int it = 0; it < iters; ++it) {
@@ -452,86 +425,6 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
                 }
                 double rho = 0; int qmax = 0;
                 double x[6] = { 0, 0, 0, 0, 0, 0 };
-                if (SPEC) {
-                    // ---- speculative trials (round 5).  A trial's cost is a chain of wave-uniform f64 operations (6x6 LDL^T,
-                    // exp, compose, the rho test: ~1.3 of its ~1.7 us) that all four waves repeated, and at convergence most
-                    // trials are rejections that come in bursts (lambda x nu, nu x 2 until one is accepted or rho == 0).  What
-                    // a burst will try next does not depend on the outcome of its trials, so wave w evaluates the trial that
-                    // FOLLOWS w rejections: its own lambda, its own solve, its own pose, the residuals of ALL active edges
-                    // (from LDS, summed inside the wave: no block reduction).  The four verdicts meet in LDS and every thread
-                    // replays g2o's sequential decisions over them in order — accept, reject and go on, or leave the loop —
-                    // discarding what lies behind the trial that ends the burst.  Same trials, same order, same arithmetic per
-                    // trial as the one-at-a-time loop (the edge sum of a trial is now one wave's: rho agrees to rounding).
-                    const int wv = tid >> 6, lane = tid & 63;
-                    bool leave = false;
-                    while (!leave) {
-                        double lam_c = lambda, ni_c = ni;
-                        for (int t = 0; t < wv; ++t) { lam_c *= ni_c; ni_c *= 2; }
-                        double Hl[36];
-#pragma unroll
-                        for (int i = 0; i < 36; ++i) Hl[i] = H[i];
-#pragma unroll
-                        for (int a = 0; a < 6; ++a) Hl[a * 7] += lam_c;
-                        const bool ok2 = d_ldlt6(Hl, b, x);
-                        double dT[7], Tn[7];
-                        d_se3_exp(x, dT);
-                        d_se3_mul(dT, T, Tn);
-                        double Rtn[12];
-                        po_pose_table(Tn, Rtn);
-                        double tchi = 0;
-                        for (int k = 0; 64 * k < n; ++k) {
-                            if (!((s_act[k] >> lane) & 1ull)) continue;
-                            const int e = 64 * k + lane;
-                            const double Pq[3] = { s_edge[e], s_edge[PO_MAX_EDGES + e], s_edge[2 * PO_MAX_EDGES + e] };
-                            double ea, eb;
-                            po_error(cam, Rtn, Pq, s_edge[3 * PO_MAX_EDGES + e], s_edge[4 * PO_MAX_EDGES + e], ea, eb);
-                            double e2 = ea * ea + eb * eb, w_, rr = e2;
-                            if (robust) d_huber(e2, 1.0, rr, w_);
-                            tchi += rr;
-                        }
-                        double tempChi = wave_sum_f64(tchi);
-                        if (!ok2) tempChi = 1.7976931348623157e308;
-                        double scale = 0;
-#pragma unroll
-                        for (int a = 0; a < 6; ++a) scale += x[a] * (lam_c * x[a] + b[a]);
-                        scale += 1e-3;
-                        const double rho_c = (currentChi - tempChi) * d_rcp1(scale);
-                        double *cd = s_cand + (one * 4 + wv) * 12;
-                        if (lane == 0) {
-                            cd[0] = rho_c; cd[1] = tempChi; cd[2] = lam_c; cd[3] = ni_c;
-#pragma unroll
-                            for (int i = 0; i < 7; ++i) cd[4 + i] = Tn[i];
-                        }
-                        __syncthreads();
-                        const double *ca = s_cand + one * 4 * 12;
-                        one ^= 1;
-                        for (int w4 = 0; w4 < 4 && !leave; ++w4) {
-                            const double *c4 = ca + 12 * w4;
-                            rho = c4[0];
-                            const double tchi4 = c4[1];
-                            // (lambda, ni are this trial's: the replay has multiplied them like the burst did)
-#pragma unroll
-                            for (int i = 0; i < 7; ++i) Te[i] = c4[4 + i];
-                            have_eval = true;
-                            const bool acc_ = rho > 0 && isfinite(tchi4);
-                            if (trace && tid == 0) lm_trace_put(trace, blockIdx.x, 16 * r + it, lambda, currentChi, tchi4, rho, acc_);
-                            if (acc_) {
-                                double t = 2 * rho - 1;
-                                double alpha = 1. - t * t * t;
-                                alpha = fmin(alpha, 2. / 3.);
-                                double sf = fmax(1. / 3., alpha);
-                                lambda *= sf; ni = 2; currentChi = tchi4;
-#pragma unroll
-                                for (int i = 0; i < 7; ++i) T[i] = Te[i];
-                            } else {
-                                lambda *= ni; ni *= 2;
-                                if (!isfinite(lambda)) { leave = true; break; }
-                            }
-                            ++qmax;
-                            if (!(rho < 0 && qmax < 10)) leave = true;
-                        }
-                    }
-                } else
                 do {
                     double Tb[7];
 #pragma unroll
