@@ -262,7 +262,9 @@ k_gftt_eig3(const GfttJob *jobs, int njobs, const uint8_t *pyr, PyrGeom g, GfttW
 #define GF_MAX_CORNERS 1024
 #define GS_THREADS 256
 #define GS_BINS 2048
+#ifndef GS_CHUNK
 #define GS_CHUNK 2048
+#endif
 
 __device__ __forceinline__ void bitonic_desc(unsigned long long *a, int n2, int tid, int nthreads)
 {
