@@ -117,6 +117,29 @@ def compute_side(fam, cnt, fam_ms):
     return None
 
 
+def valu_step(cnt, elapsed_s):
+    """The whole step on the ruler that fits it (round 5): the step is VALU-issue work — k_lk alone is ~64 % of all VALU
+    wave-instructions, the local BA ~17 % — so the meaningful roofline of the JOB is instructions issued per second against the
+    chip's VALU issue peak.  Instructions = the timed region's units x the per-unit SQ_INSTS_VALU constants of the committed
+    PMC pass (profiles/pmc_valu_step.json, tools/pmc_valu_step.sh); peak = 1024 SIMDs / 1.75 ns (the 4-cycle instruction class
+    k_lk is made of; plain f32 / u32 adds issue faster, f64 slower: the fraction is against LK's class)."""
+    try:
+        c = json.load(open(os.path.join(ROOT, "profiles", "pmc_valu_step.json")))
+    except (OSError, ValueError):
+        return None
+    units = {"local_ba": cnt["ba_calls"], "lk": cnt["track_pts"] + cnt["right_pts"], "pose_only": cnt["frames"],
+             "pyramid": cnt["pyr_left"] + cnt["pyr_right"], "gftt": cnt["gftt_calls"], "triangulate": cnt["tri_pts"], "map": cnt["keyframes"]}
+    per = {f: units[f] * c[f]["valu_insts"] for f in units if f in c}
+    tot = sum(per.values())
+    if tot <= 0 or elapsed_s <= 0:
+        return None
+    peak = SIMDS / 1.75e-9 / 1e9
+    return {"valu_wave_insts_per_frame": round(tot / max(cnt["frames"], 1)), "achieved_ginst_s": round(tot / elapsed_s / 1e9, 1),
+            "peak_ginst_s": round(peak, 1), "frac": round(tot / elapsed_s / 1e9 / peak, 4),
+            "share": {f: round(v / tot, 3) for f, v in per.items()},
+            "source": "profiles/pmc_valu_step.json (committed PMC pass, per-unit SQ_INSTS_VALU) x the units of this run's first timed window, per GPU"}
+
+
 def effective_cpus():
     """CPUs this process may actually burn: min(affinity, cgroup v2 cpu.max quota)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
@@ -584,6 +607,7 @@ def main():
             # whole step: all algorithmic bytes of the timed region over its wall time
             "roofline_by_family": by_fam,
             "roofline_compute": {f: compute_side(f, cnt, fam_t[f][0]) for f in ("local_ba", "lk") if fam_t[f][1]},
+            "roofline_valu_step": valu_step(cnt, t_timed),
             "roofline_solo": solo,
             "value_spread": {"windows": [round(v, 1) for v in spread], "steps_each": K,
                              "min": round(min(spread), 1) if spread else None, "max": round(max(spread), 1) if spread else None,

@@ -566,9 +566,6 @@ __device__ __forceinline__ void ba_schur_task(int a, int b2_, int rg, int c0, in
 #pragma unroll
     for (int z = 0; z < 12; ++z) acc[z] = 0;
     accb[0] = accb[1] = 0;
-#ifdef BA_SCHUR_UNROLL
-#pragma unroll BA_SCHUR_UNROLL
-#endif
     for (int c = c0 + gl; c < c1; c += LANES) {
         const int it3 = (c - it0 < BA_PIT_CAP) ? Pit[c - it0] : pitem[c];
         const int by = it3 & 1023, bw = (it3 >> 10) & 1023, lq = it3 >> 20;
