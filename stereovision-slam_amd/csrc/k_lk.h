@@ -126,14 +126,16 @@ __device__ __forceinline__ int lk_sample_diff(const uint32_t *base32, int a, int
     return lk_dot2(t, w.top, lk_dot2(b, w.bot, acc0)) >> (LK_W_BITS - 5);
 }
 
-// The same with the tap's LDS BYTE ADDRESS given (array base + byte offset folded into one per-lane constant
-// by the caller): aligned dword address and byte selector both come from that one value.
+// J samples in the iteration loop come from the EXPANDED search region (round 5): one dword per pixel position holding the
+// horizontal tap pair (J[x] | J[x + 1] << 16), so that a bilinear sample is ONE ds_read2_b32 (the pair of this row and of the
+// row below, 32 dwords on) and two dot products — the byte region cost an address split, a selector and two v_perm per
+// sample, 10 of the iteration's 78 VALU instructions, on every iteration; the expansion costs 20 per staging.
+// addr: LDS byte address of the top-left tap's pair (per-lane constant + 4 x the window's offset in the region).
 typedef const __attribute__((address_space(3))) uint32_t *lk_lds_u32;
 __device__ __forceinline__ int lk_sample_diff_at(uint32_t addr, LkW w, int acc0)
 {
-    const uint32_t sel = LK_PAIR_SEL0 + (addr & 3u) * 0x00010001u;
-    lk_lds_u32 q = (lk_lds_u32)(uintptr_t)(addr & ~3u);
-    const uint32_t t = __builtin_amdgcn_perm(q[1], q[0], sel), b = __builtin_amdgcn_perm(q[LK_REG / 4 + 1], q[LK_REG / 4], sel);
+    lk_lds_u32 q = (lk_lds_u32)(uintptr_t)addr;
+    const uint32_t t = q[0], b = q[LK_REG];
     return lk_dot2(t, w.top, lk_dot2(b, w.bot, acc0)) >> (LK_W_BITS - 5);
 }
 
@@ -164,11 +166,25 @@ __device__ __forceinline__ LkJRegs lk_stage_J_issue(const uint8_t *J0, uint32_t 
     }
     return o;
 }
-// ... and written to LDS here, so that the latency of the loads hides behind whatever sits in between
+// ... and written to LDS here, so that the latency of the loads hides behind whatever sits in between.  The lane's dword
+// (bytes x .. x + 3 of a row) becomes the four tap pairs (x, x+1) .. (x+3, x+4); the fifth byte is the first of the next lane's
+// dword of the same row (row_shl:1 — the last lane of a row gets a foreign byte for the pair (31, 32), which no window reads:
+// a window starts at offset <= 20 and is 11 wide, its right taps end at 31).
 __device__ __forceinline__ void lk_stage_J_commit(uint32_t *sJ, const LkJRegs &o, int lane)
 {
+    typedef uint32_t lk_u4 __attribute__((ext_vector_type(4)));
+    const int r = lane >> 3, c4 = lane & 7;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) sJ[lane + 64 * k] = o.v[k];
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t cur = o.v[k];
+        const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cur, 0x101 /* row_shl:1 */, 0xf, 0xf, true);
+        lk_u4 pr;
+        pr.x = __builtin_amdgcn_perm(nxt, cur, 0x0c010c00u);
+        pr.y = __builtin_amdgcn_perm(nxt, cur, 0x0c020c01u);
+        pr.z = __builtin_amdgcn_perm(nxt, cur, 0x0c030c02u);
+        pr.w = __builtin_amdgcn_perm(nxt, cur, 0x0c040c03u);
+        *reinterpret_cast<lk_u4 *>(sJ + (r + 8 * k) * LK_REG + 4 * c4) = pr;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
@@ -193,36 +209,42 @@ __device__ __forceinline__ float lk_sum_to_f32(long long s, float scale)
     return (float)t * __uint_as_float(kb);
 }
 
-// Wave totals of two int32 lane values whose sums of absolute values fit int32: the first butterfly step
-// sends each lane's "other" value to its xor-1 neighbour, so the remaining three DPP steps carry both sums at
-// once (sum a in the lanes with bit0 ^ bit2 == 0, sum b in the others; that predicate is invariant under
-// xor 2, half-mirror and mirror and flips under xor 1).  5 + 8 VALU instead of 8 + 8 plus a 64-bit scalar tail.
-__device__ __forceinline__ void lk_wave_sum2_i32(int a, int b, bool second, int &sa, int &sb)
+// Wave totals of two (four) int32 lane values whose sums of absolute values fit int32 (round 5: gfx950's row swaps).
+// v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of its second, so
+// (a, b) -> ([a0 b0 a2 b2], [a1 b1 a3 b3]) and one add leaves the row pairs' sums of a in rows 0 / 2 and of b in rows 1 / 3;
+// v_permlane32_swap does the same with the 32-lane halves: a second add leaves, lane by lane, the column sums of a in row 0
+// and of b in row 1 (of c, d in rows 2, 3).  ONE 4-step DPP row reduction then finishes all of them at once and one
+// v_readlane per sum fetches it — 11 (14) VALU instructions instead of 14 (28) and no scalar additions; integer sums, exact
+// in any order.
+typedef unsigned lk_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int lk_row_reduce(int w)
 {
-    int v = (second ? b : a) + dpp_i32<SVS_DPP_XOR1>(second ? a : b);
-    v += dpp_i32<SVS_DPP_XOR2>(v);
-    v += dpp_i32<SVS_DPP_HALF_MIRROR>(v);
-    v += dpp_i32<SVS_DPP_MIRROR>(v);
-    sa = (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) +
-         (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
-    sb = (__builtin_amdgcn_readlane(v, 1) + __builtin_amdgcn_readlane(v, 17)) +
-         (__builtin_amdgcn_readlane(v, 33) + __builtin_amdgcn_readlane(v, 49));
+    w += dpp_i32<SVS_DPP_XOR1>(w);
+    w += dpp_i32<SVS_DPP_XOR2>(w);
+    w += dpp_i32<SVS_DPP_HALF_MIRROR>(w);
+    w += dpp_i32<SVS_DPP_MIRROR>(w);
+    return w;
 }
-
-// Four wave totals at once: after the xor-1 step a lane carries two of the four sums, after the xor-2 step
-// one (a: p = q = 0, b: q only, c: p only, d: both; p = bit0 ^ bit2 flips under xor 1 only, q = bit1 ^ bit2
-// under xor 2 only, both are invariant under half-mirror and mirror).  5 DPP adds instead of 16.
-__device__ __forceinline__ void lk_wave_sum4_i32(int a, int b, int c, int d, bool p, bool q, int &sa, int &sb, int &sc, int &sd)
+__device__ __forceinline__ void lk_wave_sum2_i32(int a, int b, int &sa, int &sb)
 {
-    const int v0 = (p ? c : a) + dpp_i32<SVS_DPP_XOR1>(p ? a : c);
-    const int v1 = (p ? d : b) + dpp_i32<SVS_DPP_XOR1>(p ? b : d);
-    int v = (q ? v1 : v0) + dpp_i32<SVS_DPP_XOR2>(q ? v0 : v1);
-    v += dpp_i32<SVS_DPP_HALF_MIRROR>(v);
-    v += dpp_i32<SVS_DPP_MIRROR>(v);
-    sa = (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) + (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
-    sb = (__builtin_amdgcn_readlane(v, 2) + __builtin_amdgcn_readlane(v, 18)) + (__builtin_amdgcn_readlane(v, 34) + __builtin_amdgcn_readlane(v, 50));
-    sc = (__builtin_amdgcn_readlane(v, 1) + __builtin_amdgcn_readlane(v, 17)) + (__builtin_amdgcn_readlane(v, 33) + __builtin_amdgcn_readlane(v, 49));
-    sd = (__builtin_amdgcn_readlane(v, 3) + __builtin_amdgcn_readlane(v, 19)) + (__builtin_amdgcn_readlane(v, 35) + __builtin_amdgcn_readlane(v, 51));
+    const lk_u2 r = __builtin_amdgcn_permlane16_swap((unsigned)a, (unsigned)b, false, false);
+    const int v = (int)(r.x + r.y);
+    const lk_u2 q = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    const int w = lk_row_reduce((int)(q.x + q.y));
+    sa = __builtin_amdgcn_readlane(w, 0);
+    sb = __builtin_amdgcn_readlane(w, 16);
+}
+__device__ __forceinline__ void lk_wave_sum4_i32(int a, int b, int c, int d, int &sa, int &sb, int &sc, int &sd)
+{
+    const lk_u2 r1 = __builtin_amdgcn_permlane16_swap((unsigned)a, (unsigned)b, false, false);
+    const lk_u2 r2 = __builtin_amdgcn_permlane16_swap((unsigned)c, (unsigned)d, false, false);
+    const int v1 = (int)(r1.x + r1.y), v2 = (int)(r2.x + r2.y);           // rows [a01 b01 a23 b23], [c01 d01 c23 d23]
+    const lk_u2 q = __builtin_amdgcn_permlane32_swap((unsigned)v1, (unsigned)v2, false, false);
+    const int w = lk_row_reduce((int)(q.x + q.y));                          // rows: a, b, c, d
+    sa = __builtin_amdgcn_readlane(w, 0);
+    sb = __builtin_amdgcn_readlane(w, 16);
+    sc = __builtin_amdgcn_readlane(w, 32);
+    sd = __builtin_amdgcn_readlane(w, 48);
 }
 
 #ifndef LK_OCC_TEST
@@ -239,7 +261,7 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
 {
     __shared__ uint32_t sI_all[LK_WAVES_PER_BLOCK][16 * LK_IROW / 4 + 2];     // 14 rows used, 16 staged
     __shared__ uint32_t sD_all[LK_WAVES_PER_BLOCK][144];
-    __shared__ uint32_t sJ_all[LK_WAVES_PER_BLOCK][LK_REG * LK_REG / 4 + 8];
+    __shared__ __attribute__((aligned(16))) uint32_t sJ_all[LK_WAVES_PER_BLOCK][LK_REG * LK_REG];     // expanded: one tap pair per position
 
 #if LK_OCC_TEST == 2
     __shared__ uint32_t sPad[8192];
@@ -275,14 +297,12 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
     const int oI0 = (wy0 + 1) * LK_IROW + wx0 + 1, oI1 = (wy1 + 1) * LK_IROW + wx1 + 1;
     const int oD0 = wy0 * 12 + wx0, oD1 = wy1 * 12 + wx1;
     const int oJ0 = wy0 * LK_REG + wx0, oJ1 = wy1 * LK_REG + wx1;
-    // LDS byte addresses of this lane's two window pixels at search-region offset 0
-    const uint32_t aJ0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)sJ + (uint32_t)oJ0,
-                   aJ1 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)sJ + (uint32_t)oJ1;
+    // LDS byte addresses of the tap pairs of this lane's two window pixels at search-region offset 0
+    const uint32_t aJ0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)sJ + 4u * (uint32_t)oJ0,
+                   aJ1 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)sJ + 4u * (uint32_t)oJ1;
     // Scharr work split: lanes 0..47 -> row lane/4, columns 3*(lane%4) .. +2
     const int sr = lane >> 2, sc = (lane & 3) * 3;
     const float FLT_SCALE = 1.f / (float)(1 << 20);
-    const bool second = ((lane ^ (lane >> 2)) & 1) != 0;       // lk_wave_sum2_i32 / lk_wave_sum4_i32 (p)
-    const bool second_q = (((lane >> 1) ^ (lane >> 2)) & 1) != 0;
     // f32 brackets of the f64 termination test dx^2 + dy^2 <= eps2: the f32 evaluation is within 2^-22
     // relative of the f64 one, so outside (e_lo, e_hi) it decides; inside, the f64 test runs
     const float e_lo = (float)(prm.eps2 * (1.0 - 2e-6)), e_hi = (float)(prm.eps2 * (1.0 + 2e-6));
@@ -390,7 +410,7 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
         // A sums (exact: 121 x 4080^2 < 2^31); the fourth lane of the butterfly is idle
         int sA11, sA12, sA22, sIdle;
         lk_wave_sum4_i32(__mul24(ix0, ix0) + __mul24(ix1, ix1), __mul24(ix0, iy0) + __mul24(ix1, iy1), __mul24(iy0, iy0) + __mul24(iy1, iy1), 0,
-                         second, second_q, sA11, sA12, sA22, sIdle);
+                         sA11, sA12, sA22, sIdle);
         const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         const float dd = A11 - A22;
@@ -431,7 +451,7 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
                 ox = inx - rx0; oy = iny - ry0;
             }
             const LkW jw = lk_weights(nx - (float)inx, ny - (float)iny);
-            const uint32_t jo = (uint32_t)(oy * LK_REG + ox);
+            const uint32_t jo = 4u * (uint32_t)(oy * LK_REG + ox);
             const int d0 = lk_sample_diff_at(aJ0 + jo, jw, acc00);
             const int d1 = lk_sample_diff_at(aJ1 + jo, jw, acc01);
             // |d| < 2^14, |Ix|,|Iy| < 2^13: 24-bit multiplies, 16-lane row sums fit int32
@@ -440,7 +460,7 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
             float b1, b2;
             if (narrow) {
                 int s1, s2;
-                lk_wave_sum2_i32(pb1, pb2, second, s1, s2);
+                lk_wave_sum2_i32(pb1, pb2, s1, s2);
                 b1 = (float)s1 * FLT_SCALE; b2 = (float)s2 * FLT_SCALE;
             } else {
                 b1 = lk_sum_to_f32(wave_sum_i32_wide(pb1), FLT_SCALE); b2 = lk_sum_to_f32(wave_sum_i32_wide(pb2), FLT_SCALE);
@@ -474,9 +494,10 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
                 ox = inx - rx0; oy = iny - ry0;
             }
             const LkW jw = lk_weights(fx - (float)inx, fy - (float)iny);
-            const int jo = oy * LK_REG + ox;
-            const int d0 = lk_sample_u8(sJ, jo + oJ0, LK_REG, jw) - iv0;
-            const int d1 = lk_sample_u8(sJ, jo + oJ1, LK_REG, jw) - iv1;
+            const uint32_t jo = 4u * (uint32_t)(oy * LK_REG + ox);
+            // (lk_sample_u8's rounding constant in the accumulator; the same taps from the expanded region)
+            const int d0 = lk_sample_diff_at(aJ0 + jo, jw, 1 << (LK_W_BITS - 5 - 1)) - iv0;
+            const int d1 = lk_sample_diff_at(aJ1 + jo, jw, 1 << (LK_W_BITS - 5 - 1)) - iv1;
             const int e = (d0 < 0 ? -d0 : d0) + (has1 ? (d1 < 0 ? -d1 : d1) : 0);
             const int serr = wave_sum_i32(e);
             errv = (float)serr * 1.f / (float)(32 * LK_WIN * LK_WIN);
