@@ -585,6 +585,7 @@ def main():
                        "preroll_steps": pre, "preroll_last_block_ba_keyframes_mean": round(preroll_kf, 2),
                        "streams_per_gpu": S, "host_threads_per_gpu": G, "bookkeeping_threads_per_group": args.host_threads, "frame": "%dx%d u8 stereo pair" % (W, H) + (" decimated on the fly from %dx%d frames in HBM" % (SW, SH) if args.full_res else ""),
                        "keyframes_in_timed_region": cnt["keyframes"],
+                       "pose_only_xtol": float(os.environ.get("SVSLAM_PO_XTOL", "1e-12")),   # svslam_set_pose_only_xtol (0 = g2o's schedule to the last trial)
                        "ba_problem_mean": {"keyframes": round(cnt["ba_kf"] / max(cnt["ba_calls"], 1), 1),
                                            "landmarks": round(cnt["ba_lm"] / max(cnt["ba_calls"], 1), 1),
                                            "edges": round(cnt["ba_edges"] / max(cnt["ba_calls"], 1), 1),

@@ -95,6 +95,19 @@ int svslam_set_source_size(svslam_ctx *ctx, int src_w, int src_h);
  * inside the same call.  Restriction: the solver scratch is one per context — svslam_local_ba_submit / _batch are refused while
  * a deferred local BA of the device map (svslam_dmap_params::ba_defer) is in flight on the context.                          */
 int svslam_set_low_latency(svslam_ctx *ctx, int on);
+/* Parameter tolerance of the pose-only LM (svslam_pose_only_batch, svslam_track_batch, svslam_rtrack_batch; default 1e-12,
+ * environment SVSLAM_PO_XTOL at svslam_create).  A round of EstimateCurrentPose (src/frontend.cpp:482-493: optimize(10)) ends
+ * when the first trial of an LM iteration, taken at a damping not above the round's initial one, asks for a step whose six
+ * components are all <= xtol (metres / radians): the round stands at a stationary point of its cost.  g2o has no such test;
+ * it runs the ten iterations, and where a round has converged earlier it spends the rest on trials that move the pose by
+ * rounding noise and are accepted or rejected by the sign of that noise.  The trials that are run are g2o's, bit for bit;
+ * what the rule leaves out moves the pose by about xtol.  At the default that is what another summation order moves, and
+ * every comparison with the oracle holds unchanged; 1e-9 ends the slowly (linearly) converging Huber rounds three
+ * iterations earlier (-20 % of the kernel for a tracked frame) at the price that two runs which differ in it part ways as
+ * early as runs of different kernel shapes do (LK rounds its initial guesses to f32): DESIGN 4.4 has the table.
+ * xtol = 0: g2o's schedule to the last trial.  0 <= xtol <= 1e-6.  Local BA is not touched: its ten iterations all move
+ * the window.                                                                                                           */
+int svslam_set_pose_only_xtol(svslam_ctx *ctx, double xtol);
 /* test hook: read one level back (tight rows of *w bytes) */
 int svslam_pyramid_read(svslam_ctx *ctx, int slot, int level, uint8_t *out,
                         int *w, int *h);

@@ -33,6 +33,7 @@ public:
 
     int set_source_size(int src_w, int src_h) { src_w_ = src_w; src_h_ = src_h; return 0; }
     int set_low_latency(int) { return 0; }      // a kernel shape of the HIP library; nothing to emulate
+    int set_pose_only_xtol(double) { return 0; } // a stopping rule of the HIP library; the twin runs g2o's schedule to the last trial
     int pyramid(int n, const int *slots, const void *const *imgs, const int *strides, int)
     {
         for (int i = 0; i < n; ++i) {

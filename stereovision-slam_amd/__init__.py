@@ -18,7 +18,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 
 ABI_SYMBOLS = [
     "svslam_create", "svslam_destroy", "svslam_last_error", "svslam_build_info",
-    "svslam_pyramid_batch", "svslam_pyramid_decimate_batch", "svslam_set_source_size", "svslam_set_low_latency", "svslam_pyramid_read",
+    "svslam_pyramid_batch", "svslam_pyramid_decimate_batch", "svslam_set_source_size", "svslam_set_low_latency", "svslam_set_pose_only_xtol", "svslam_pyramid_read",
     "svslam_pyramid_read_padded", "svslam_lk_batch", "svslam_gftt_batch", "svslam_gftt_eigmap", "svslam_triangulate_batch",
     "svslam_pose_only_batch", "svslam_local_ba_batch", "svslam_local_ba_submit", "svslam_local_ba_collect",
     "svslam_track_batch", "svslam_rtrack_batch", "svslam_rtrack_upload",
@@ -103,6 +103,7 @@ def load():
         L.svslam_last_error.argtypes = [C.c_void_p]
         L.svslam_destroy.argtypes = [C.c_void_p]
         L.svslam_destroy.restype = None
+        L.svslam_set_pose_only_xtol.argtypes = [C.c_void_p, C.c_double]
         L.svslam_dev_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         L.svslam_dev_free.argtypes = [C.c_void_p, C.c_void_p]
         L.svslam_dev_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
@@ -208,6 +209,10 @@ class Context:
     def low_latency(self, on=True):
         """latency shape of the serial kernels (svslam_set_low_latency): a few jobs per launch"""
         self._chk(self.L.svslam_set_low_latency(self.h, 1 if on else 0), "set_low_latency")
+
+    def pose_only_xtol(self, xtol):
+        """parameter tolerance of the pose-only LM (svslam_set_pose_only_xtol); 0 = g2o's schedule to the last trial"""
+        self._chk(self.L.svslam_set_pose_only_xtol(self.h, C.c_double(xtol)), "set_pose_only_xtol")
 
     def timing(self, on=True):
         self.L.svslam_timing_enable(self.h, 1 if on else 0)

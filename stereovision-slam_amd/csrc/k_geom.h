@@ -268,7 +268,7 @@ struct PoFuse { uint8_t *status; const uint8_t *has_mp; int w, h; RtJob *rt; RtS
 template <int WAVES, bool FUSED>
 __global__ void __launch_bounds__(64 * WAVES) PO_VGPR_ATTR
 k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *uv,
-            const uint8_t *edge_valid, uint8_t *outlier, double chi2_th, int rounds, int iters, double *trace, PoFuse fz)
+            const uint8_t *edge_valid, uint8_t *outlier, double chi2_th, int rounds, int iters, double *trace, PoFuse fz, double xtol)
 {
     constexpr int NT = 64 * WAVES, SLOTS = PO_MAX_EDGES / NT;
     __shared__ __attribute__((aligned(16))) double s_red[4 * WAVES * 32];
@@ -358,7 +358,8 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
         int nact = 0;
         nact = po_block_sum_i32<WAVES>(__builtin_popcount(vmask & ~omask), s_int, tid);
         if (nact > 0) {
-            double lambda = 0, ni = 2;
+            double lambda = 0, ni = 2, lambda0 = 0;
+            bool stationary = false;
             for (int it = 0; it < iters; ++it) {
                 // errors + chi2 + normal equations at T: acc[0..20] upper triangle of H, [21..26] b, [27] chi2
                 double acc[32];
@@ -421,7 +422,7 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
                     double md = 0;
 #pragma unroll
                     for (int a = 0; a < 6; ++a) md = fmax(md, fabs(H[a * 7]));
-                    lambda = 1e-5 * md; ni = 2;
+                    lambda = 1e-5 * md; ni = 2; lambda0 = lambda;
                 }
                 double rho = 0; int qmax = 0;
                 double x[6] = { 0, 0, 0, 0, 0, 0 };
@@ -437,6 +438,18 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
                     PO_TICK(5);
                     bool ok2 = d_ldlt6(Hl, b, x);
                     PO_TICKV(2, x[0] + x[5]);
+                    // Parameter tolerance (xtol > 0; svslam_set_pose_only_xtol): the FIRST trial of an iteration whose damping is
+                    // not above the round's initial one is (nearly) the Newton step; when no component of it reaches xtol
+                    // (metres / radians) the round stands at a stationary point of its cost and ends here, the step not taken.
+                    // g2o has no such test (optimization_algorithm_levenberg.cpp: it goes on for the iterations asked for,
+                    // src/frontend.cpp:487) — its remaining trials move the pose by rounding noise (|x| ~ 1e-13) and accept or
+                    // reject on the sign of that noise; what is skipped is bounded by ~2 xtol, far inside the LM tolerances.
+                    if (xtol > 0 && qmax == 0 && ok2 && lambda <= lambda0) {
+                        double mx = 0;
+#pragma unroll
+                        for (int a = 0; a < 6; ++a) mx = fmax(mx, fabs(x[a]));
+                        if (mx <= xtol) { stationary = true; break; }
+                    }
                     double dT[7], Tn[7];
                     d_se3_exp(x, dT);
                     d_se3_mul(dT, T, Tn);
@@ -485,7 +498,7 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
                     ++qmax;
                     PO_TICKV(7, lambda + rho);
                 } while (rho < 0 && qmax < 10);
-                if (qmax == 10 || rho == 0 || !isfinite(lambda)) break;
+                if (stationary || qmax == 10 || rho == 0 || !isfinite(lambda)) break;
             }
         }
         // classify (src/frontend.cpp:495-525)

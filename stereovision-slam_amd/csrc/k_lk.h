@@ -93,9 +93,13 @@ __device__ __forceinline__ LkW lk_weights(float a, float b)
     // first: A = 2^14 a (exact), 2^14 - A == fl(2^14 (1 - a)) == 2^14 fl(1 - a).  Round-half-even to an integer
     // in [0, 2^14] is one f32 add of 1.5 * 2^23: the integer sits in the low mantissa bits of the sum, and the
     // low 16 bits of the magic constant are zero, so the Q14 halves are packed straight from the float bits.
+    // Packed f32 arithmetic (v_pk_mul_f32 / v_pk_add_f32: two IEEE operations per instruction, each rounded exactly
+    // like its scalar form).
+    typedef float lk_f2 __attribute__((ext_vector_type(2)));
     const float S = (float)(1 << LK_W_BITS), M = 12582912.f;                  // M = 0x4B400000
     const float A = a * S, An = S - A, bn = 1.f - b;
-    const uint32_t b00 = __float_as_uint(An * bn + M), b01 = __float_as_uint(A * bn + M), b10 = __float_as_uint(An * b + M);
+    const lk_f2 p0 = (lk_f2){An, A} * (lk_f2){bn, bn} + (lk_f2){M, M};        // (An bn + M, A bn + M)
+    const uint32_t b00 = __float_as_uint(p0.x), b01 = __float_as_uint(p0.y), b10 = __float_as_uint(An * b + M);
     // w11 = 2^14 - w00 - w01 - w10 (may be -1, kept signed in its 16-bit half)
     const uint32_t w11 = ((1u << LK_W_BITS) + 3u * 0x4B400000u) - (b00 + b01 + b10);
     LkW w;
@@ -214,8 +218,8 @@ __device__ __forceinline__ float lk_sum_to_f32(long long s, float scale)
 // (a, b) -> ([a0 b0 a2 b2], [a1 b1 a3 b3]) and one add leaves the row pairs' sums of a in rows 0 / 2 and of b in rows 1 / 3;
 // v_permlane32_swap does the same with the 32-lane halves: a second add leaves, lane by lane, the column sums of a in row 0
 // and of b in row 1 (of c, d in rows 2, 3).  ONE 4-step DPP row reduction then finishes all of them at once and one
-// v_readlane per sum fetches it — 11 (14) VALU instructions instead of 14 (28) and no scalar additions; integer sums, exact
-// in any order.
+// v_readlane per sum fetches it — 14 VALU instructions instead of 28 for four sums; for two sums the second swap is
+// replaced by two more v_readlane and two scalar additions (10 instead of 14).  Integer sums, exact in any order.
 typedef unsigned lk_u2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int lk_row_reduce(int w)
 {
@@ -229,10 +233,11 @@ __device__ __forceinline__ void lk_wave_sum2_i32(int a, int b, int &sa, int &sb)
 {
     const lk_u2 r = __builtin_amdgcn_permlane16_swap((unsigned)a, (unsigned)b, false, false);
     const int v = (int)(r.x + r.y);
-    const lk_u2 q = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
-    const int w = lk_row_reduce((int)(q.x + q.y));
-    sa = __builtin_amdgcn_readlane(w, 0);
-    sb = __builtin_amdgcn_readlane(w, 16);
+    // rows [a01 b01 a23 b23]: the row reduction, then the two halves meet on the scalar unit (wrap-around is harmless: the
+    // totals fit) — 10 VALU instructions
+    const int w = lk_row_reduce(v);
+    sa = __builtin_amdgcn_readlane(w, 0) + __builtin_amdgcn_readlane(w, 32);
+    sb = __builtin_amdgcn_readlane(w, 16) + __builtin_amdgcn_readlane(w, 48);
 }
 __device__ __forceinline__ void lk_wave_sum4_i32(int a, int b, int c, int d, int &sa, int &sb, int &sc, int &sd)
 {
@@ -436,7 +441,11 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
         // sum Iy^2 <= 5.7e8 that is < 2^31 and the b sums fit int32 (always, short of adversarial patches)
         const bool narrow = sA11 <= 570000000 && sA22 <= 570000000;
         const int acc00 = (1 << (LK_W_BITS - 5 - 1)) - (iv0 << (LK_W_BITS - 5)), acc01 = (1 << (LK_W_BITS - 5 - 1)) - (iv1 << (LK_W_BITS - 5));
-        float pdx = 0.f, pdy = 0.f;
+        // (Ix0 | Ix1 << 16), (Iy0 | Iy1 << 16): b's per-lane terms are one i16 dot product each
+        const uint32_t ixx = __builtin_amdgcn_perm((uint32_t)ix1, (uint32_t)ix0, 0x05040100u), iyy = __builtin_amdgcn_perm((uint32_t)iy1, (uint32_t)iy0, 0x05040100u);
+        float pdx = 0.f, pdy = 0.f, dx = 0.f, dy = 0.f;
+        const float Ds = D * FLT_SCALE;
+        bool moved = false, osc = false;
         lk_stage_J_commit(sJ, jr, lane);
 
         for (int j = 0; j < prm.max_count; ++j) {
@@ -455,29 +464,36 @@ k_lk(const LkJob *jobs, const uint8_t *pyr, PyrGeom g, const float2 *prev_xy, fl
             const int d0 = lk_sample_diff_at(aJ0 + jo, jw, acc00);
             const int d1 = lk_sample_diff_at(aJ1 + jo, jw, acc01);
             // |d| < 2^14, |Ix|,|Iy| < 2^13: 24-bit multiplies, 16-lane row sums fit int32
-            const int pb1 = __mul24(d0, ix0) + __mul24(d1, ix1);
-            const int pb2 = __mul24(d0, iy0) + __mul24(d1, iy1);
+            const uint32_t dd01 = __builtin_amdgcn_perm((uint32_t)d1, (uint32_t)d0, 0x05040100u);
+            const int pb1 = lk_dot2(dd01, ixx, 0), pb2 = lk_dot2(dd01, iyy, 0);
             float b1, b2;
             if (narrow) {
                 int s1, s2;
                 lk_wave_sum2_i32(pb1, pb2, s1, s2);
-                b1 = (float)s1 * FLT_SCALE; b2 = (float)s2 * FLT_SCALE;
+                b1 = (float)s1; b2 = (float)s2;
             } else {
-                b1 = lk_sum_to_f32(wave_sum_i32_wide(pb1), FLT_SCALE); b2 = lk_sum_to_f32(wave_sum_i32_wide(pb2), FLT_SCALE);
+                b1 = lk_sum_to_f32(wave_sum_i32_wide(pb1), 1.f); b2 = lk_sum_to_f32(wave_sum_i32_wide(pb2), 1.f);
             }
-            const float dx = (A12 * b2 - A22 * b1) * D;
-            const float dy = (A12 * b1 - A11 * b2) * D;
+            // b's 2^-20 rides on 1 / det (Ds): a power of two commutes with every rounding of this expression (no
+            // operand comes near the subnormals: |b| >= 1 or 0, 2^-20 <= |A| < 2^10, 3e-6 < 1 / det < 8.4e6)
+            dx = (A12 * b2 - A22 * b1) * Ds;
+            dy = (A12 * b1 - A11 * b2) * Ds;
             nx += dx; ny += dy;
-            nextp.x = nx + 5.f; nextp.y = ny + 5.f;
+            moved = true;
             const float dd2 = dx * dx + dy * dy;
             if (dd2 < e_lo) break;
             if (dd2 <= e_hi && (double)dx * (double)dx + (double)dy * (double)dy <= prm.eps2) break;
             // (double)|v| < 0.01  <=>  |v| <= 0.01f  (0.01f is the largest float below 0.01)
             if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
-                nextp.x -= dx * 0.5f; nextp.y -= dy * 0.5f;
+                osc = true;
                 break;
             }
             pdx = dx; pdy = dy;
+        }
+        // the estimate leaves the loop in window-corner coordinates (the +5 is taken once, not per iteration)
+        if (moved) {
+            nextp.x = nx + 5.f; nextp.y = ny + 5.f;
+            if (osc) { nextp.x -= dx * 0.5f; nextp.y -= dy * 0.5f; }
         }
 
         if (st && level == 0) {

@@ -111,6 +111,7 @@ struct svslam_ctx {
     bool wait_poll = true;
     bool wait_block = false;    // SVSLAM_WAIT=block: the completion event sleeps in the driver (hipEventBlockingSync)
     bool low_latency = false;   // svslam_set_low_latency: 4-wave pose-only blocks
+    double po_xtol = 1e-12;     // svslam_set_pose_only_xtol: parameter tolerance of the pose-only LM (0 = g2o's schedule to the last trial)
     bool zero_copy = false;     // low latency: the small job / result structs of the tracking path are read and written by the
                                 // kernels straight in the pinned staging memory (no copy kernel, no boundary before / after it)
     bool timing_split = false;  // SVSLAM_TIMING_SPLIT: per-kernel events of the multi-kernel families (families 6..9)
@@ -213,11 +214,11 @@ void launch_pose_only(svslam_ctx *c, int njobs, PoseJob *jobs, const double *cam
     if (c->d_lm_trace) (void)hipMemsetAsync(c->d_lm_trace, 0, sizeof(double) * LM_TRACE_STRIDE * (size_t)njobs, c->stream);
     const PoFuse none = {};
     if (c->low_latency) {
-        if (fz) hipLaunchKernelGGL((k_pose_only<4, true>), dim3(njobs), dim3(256), 0, c->stream, jobs, cam, xyz, uv, valid, outlier, chi2_th, rounds, iters, c->d_lm_trace, *fz);
-        else hipLaunchKernelGGL((k_pose_only<4, false>), dim3(njobs), dim3(256), 0, c->stream, jobs, cam, xyz, uv, valid, outlier, chi2_th, rounds, iters, c->d_lm_trace, none);
+        if (fz) hipLaunchKernelGGL((k_pose_only<4, true>), dim3(njobs), dim3(256), 0, c->stream, jobs, cam, xyz, uv, valid, outlier, chi2_th, rounds, iters, c->d_lm_trace, *fz, c->po_xtol);
+        else hipLaunchKernelGGL((k_pose_only<4, false>), dim3(njobs), dim3(256), 0, c->stream, jobs, cam, xyz, uv, valid, outlier, chi2_th, rounds, iters, c->d_lm_trace, none, c->po_xtol);
     } else {
-        if (fz) hipLaunchKernelGGL((k_pose_only<1, true>), dim3(njobs), dim3(64), 0, c->stream, jobs, cam, xyz, uv, valid, outlier, chi2_th, rounds, iters, c->d_lm_trace, *fz);
-        else hipLaunchKernelGGL((k_pose_only<1, false>), dim3(njobs), dim3(64), 0, c->stream, jobs, cam, xyz, uv, valid, outlier, chi2_th, rounds, iters, c->d_lm_trace, none);
+        if (fz) hipLaunchKernelGGL((k_pose_only<1, true>), dim3(njobs), dim3(64), 0, c->stream, jobs, cam, xyz, uv, valid, outlier, chi2_th, rounds, iters, c->d_lm_trace, *fz, c->po_xtol);
+        else hipLaunchKernelGGL((k_pose_only<1, false>), dim3(njobs), dim3(64), 0, c->stream, jobs, cam, xyz, uv, valid, outlier, chi2_th, rounds, iters, c->d_lm_trace, none, c->po_xtol);
     }
 }
 void tm_collect(svslam_ctx *c)
@@ -549,6 +550,7 @@ int svslam_create(const svslam_limits *lim, svslam_ctx **out)
         c->wait_poll = !(wm && (std::strcmp(wm, "spin") == 0 || std::strcmp(wm, "block") == 0));
         c->wait_block = wm && std::strcmp(wm, "block") == 0;
         c->timing_split = std::getenv("SVSLAM_TIMING_SPLIT") != nullptr;
+        if (const char *xt = std::getenv("SVSLAM_PO_XTOL")) { const double v = atof(xt); if (v >= 0 && v <= 1e-6) c->po_xtol = v; }   // 0: g2o's schedule
         // the device build takes the edge indices packed into one word (landmark < 2^16, keyframe < 2^8)
         c->ba_host_build = std::getenv("SVSLAM_BA_HOST_BUILD") != nullptr || lim->max_lm >= 65536 || lim->max_kf >= 256;
     }
@@ -768,6 +770,13 @@ static void ll_release(svslam_ctx *c)
     if (c->ll.cnt) (void)hipFree(c->ll.cnt);
     ba_work_free(c->ll.bw);
     c->ll.shards = nullptr; c->ll.xch = nullptr; c->ll.cnt = nullptr; c->ll.w = 0; c->ll.max_problems = 0;
+}
+
+int svslam_set_pose_only_xtol(svslam_ctx *c, double xtol)
+{
+    if (!(xtol >= 0) || xtol > 1e-6) return fail(c, "svslam_set_pose_only_xtol: 0 <= xtol <= 1e-6 (got %g)", xtol);
+    c->po_xtol = xtol;
+    return 0;
 }
 
 int svslam_set_low_latency(svslam_ctx *c, int on)

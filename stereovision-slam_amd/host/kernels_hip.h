@@ -58,6 +58,9 @@ public:
         return svslam_set_low_latency(ctx_, on);
     }
 
+    // parameter tolerance of the pose-only LM (svslam_set_pose_only_xtol; pose-only runs on the frontend context only)
+    int set_pose_only_xtol(double xtol) { ba_failed_ = false; return svslam_set_pose_only_xtol(ctx_, xtol); }
+
     int pyramid(int n, const int *slots, const void *const *imgs, const int *strides, int is_device)
     { return svslam_pyramid_batch(ctx_, n, slots, imgs, strides, is_device); }
     int track(int n, svslam_track_job *jobs, const void *const *imgs, const int *strides, int is_device,

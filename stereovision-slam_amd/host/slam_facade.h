@@ -261,11 +261,17 @@ struct FrontendOptions {            // the hyper-parameters Frontend::Frontend()
     // batch shapes (least total work — what a host that runs hundreds of streams through one context wants).  The two
     // shapes sum in different orders: results agree to rounding, each is deterministic.
     int low_latency = 1;
+    // Parameter tolerance of the pose-only LM (svslam_set_pose_only_xtol, include/svslam.h): a round of EstimateCurrentPose ends at
+    // a stationary point instead of spending the rest of its ten iterations on trials that move the pose by rounding noise.
+    // `pose_xtol: 0` in the YAML (or this field) = g2o's schedule to the last trial (src/frontend.cpp:482-493 as written);
+    // 1e-9 trades the last digits of the pose for a fifth of the kernel's time.
+    double pose_xtol = 1e-12;
     static FrontendOptions FromConfig(const ConfigFile &c)
     {
         FrontendOptions o;
         o.device_map = (int)c.Num("device_map", o.device_map);
         o.low_latency = (int)c.Num("low_latency", o.low_latency);
+        o.pose_xtol = c.Num("pose_xtol", o.pose_xtol);
         o.num_features = (int)c.Num("num_features", o.num_features);
         o.num_features_init = (int)c.Num("num_features_init", o.num_features_init);
         o.num_features_tracking = (int)c.Num("num_features_tracking", o.num_features_tracking);
@@ -362,6 +368,7 @@ private:
         kernels_.reset(new K(lim));
         if (kernels_->set_source_size(w, h) != 0) throw SLAMException(std::string("source size: ") + kernels_->last_error());
         if (kernels_->set_low_latency(opt_.low_latency ? 1 : 0) != 0) throw SLAMException(std::string("low-latency shapes: ") + kernels_->last_error());
+        if (kernels_->set_pose_only_xtol(opt_.pose_xtol) != 0) throw SLAMException(std::string("pose_xtol: ") + kernels_->last_error());
         pipe_.reset(new Pipeline<K>(cfg, *kernels_, 1, 1));
         wire_backend(); wire_map();
     }
