@@ -14,7 +14,7 @@
  *   s = (float)(1/3060.)                        scale 1/(2^(3-1) * 3 * 255)
  *   Dx = (r0 + r2)*s + r1*(2s),  r_k = (float)p[y+k-1][x+1] - (float)p[y+k-1][x-1]
  *   Dy = c2 - c0,  c_k = (s*p[.][x-1] + (2s)*p[.][x]) + s*p[.][x+1]  on row y+k-1
- *   cov = (Dx*Dx, Dx*Dy, Dy*Dy);  box = (float)(exact f64 sum of the 3x3)
+ *   cov = (Dx*Dx, Dx*Dy, Dy*Dy);  box = (float)(f64 sum of the 3x3, three columns first, then the three rows)
  *   a = box_xx*0.5f, b = box_xy, c = box_yy*0.5f
  *   eig = (a + c) - sqrtf((a - c)*(a - c) + b*b)
  * Borders: BORDER_REFLECT_101 for Sobel (on the image) and for the box filter
@@ -67,14 +67,23 @@ void orc_min_eig_map(const uint8_t *img, int stride, int w, int h, float *eig)
         int ys[3] = { reflect101(y - 1, h), y, reflect101(y + 1, h) };
         for (int x = 0; x < w; ++x) {
             int xs[3] = { reflect101(x - 1, w), x, reflect101(x + 1, w) };
-            double sxx = 0, sxy = 0, syy = 0; /* exact in f64 */
+            /* f64 accumulators in box_filter's order: RowSum adds the three columns of a row, ColumnSum adds the rows
+             * (the first window of its running sum; a later window's "+ new row - old row" is the same number whenever
+             * the sum is exact, which it is but for ~1e-7 of the pixels — and there the f32 cast below hides it:
+             * 0 differences in 5.6e7 sums on the synthetic frames, round 5).  Until round 5 this was one row-major sum. */
+            double sxx = 0, sxy = 0, syy = 0;
             float fxx = 0.f, fxy = 0.f, fyy = 0.f;
-            for (int j = 0; j < 3; ++j)
-                for (int i = 0; i < 3; ++i) {
-                    size_t q = (size_t)ys[j] * w + xs[i];
-                    sxx += cxx[q]; sxy += cxy[q]; syy += cyy[q];
-                    fxx += cxx[q]; fxy += cxy[q]; fyy += cyy[q];
-                }
+            for (int j = 0; j < 3; ++j) {
+                const size_t q0 = (size_t)ys[j] * w + xs[0], q1 = (size_t)ys[j] * w + xs[1], q2 = (size_t)ys[j] * w + xs[2];
+                const double rxx = ((double)cxx[q0] + (double)cxx[q1]) + (double)cxx[q2];
+                const double rxy = ((double)cxy[q0] + (double)cxy[q1]) + (double)cxy[q2];
+                const double ryy = ((double)cyy[q0] + (double)cyy[q1]) + (double)cyy[q2];
+                if (j == 0) { sxx = rxx; sxy = rxy; syy = ryy; }
+                else { sxx += rxx; sxy += rxy; syy += ryy; }
+                fxx += cxx[q0]; fxy += cxy[q0]; fyy += cyy[q0];
+                fxx += cxx[q1]; fxy += cxy[q1]; fyy += cyy[q1];
+                fxx += cxx[q2]; fxy += cxy[q2]; fyy += cyy[q2];
+            }
             if (orc_whatif[5]) { sxx = fxx; sxy = fxy; syy = fyy; }
             float a = (float)sxx * 0.5f, b = (float)sxy, c = (float)syy * 0.5f;
             float t = a - c;

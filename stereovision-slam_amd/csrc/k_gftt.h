@@ -3,7 +3,7 @@
 // (OpenCV goodFeaturesToTrack: cornerMinEigenVal -> masked max -> threshold ->
 // 3x3 NMS -> sort -> greedy min-distance) at reference src/frontend.cpp:42-51.
 // Mirrors oracle/orc_gftt.c; the f32 operation order is the declared one
-// (-ffp-contract=off, IEEE sqrt), the 3x3 box sums are exact in f64, so the
+// (-ffp-contract=off, IEEE sqrt), the 3x3 box sums in f64 follow its order too (GeCov below), so the
 // corner list (coordinates, order, count) is bit-exact against the oracle.
 //
 // Two kernels per batch (grid.z / grid.x = job); the image is read ONCE and nothing
@@ -72,7 +72,12 @@ template <int CTRL> __device__ __forceinline__ float dpp_f32(float v)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
 struct GePix { float d, hs; };      // per pixel row: right - left, and (s*left + 2s*mid) + s*right (the two Sobel row passes)
-struct GeCov { double xxl, xxm, xxr, xyl, xym, xyr, yyl, yym, yyr; };   // covariance products, already f64 (exact)
+// covariance products of (left, this, right) summed in f64, in that order: box_filter's RowSum; the three rows are then added
+// top to bottom (its ColumnSum) — the order oracle/orc_gftt.c declares, so the f32 eigenvalue is the oracle's bit for bit.
+// (Round 5; before, both sides summed the nine products row-major: 24 f64 additions per pixel and a window of 27 doubles
+// instead of 12 and 9.  The sums are exact — and any order the same — for all but ~1e-7 of the pixels, where a dy that is
+// a rounding residue sits beside large products.)
+struct GeCov { double xx, xy, yy; };
 struct GeEig { float m, hm; };      // value, max over (left, value, right)
 template <int CTRL> __device__ __forceinline__ double dpp_f64x(double v)
 {
@@ -203,23 +208,13 @@ k_gftt_eig3(const GfttJob *jobs, int njobs, const uint8_t *pyr, PyrGeom g, GfttW
         if (col_zero || cy > h) { dx = 0.f; dy = 0.f; }
         // products in f32 (the reference's order), widened to f64 once; the 3x3 box sums below are f64
         const double xx = (double)(dx * dx), xy = (double)(dx * dy), yy = (double)(dy * dy);
-        Cnew.xxm = xx; Cnew.xym = xy; Cnew.yym = yy;
-        Cnew.xxl = dpp_f64x<SVS_DPP_WAVE_SHR1>(xx); Cnew.xxr = dpp_f64x<SVS_DPP_WAVE_SHL1>(xx);
-        Cnew.xyl = dpp_f64x<SVS_DPP_WAVE_SHR1>(xy); Cnew.xyr = dpp_f64x<SVS_DPP_WAVE_SHL1>(xy);
-        Cnew.yyl = dpp_f64x<SVS_DPP_WAVE_SHR1>(yy); Cnew.yyr = dpp_f64x<SVS_DPP_WAVE_SHL1>(yy);
+        Cnew.xx = (dpp_f64x<SVS_DPP_WAVE_SHR1>(xx) + xx) + dpp_f64x<SVS_DPP_WAVE_SHL1>(xx);
+        Cnew.xy = (dpp_f64x<SVS_DPP_WAVE_SHR1>(xy) + xy) + dpp_f64x<SVS_DPP_WAVE_SHL1>(xy);
+        Cnew.yy = (dpp_f64x<SVS_DPP_WAVE_SHR1>(yy) + yy) + dpp_f64x<SVS_DPP_WAVE_SHL1>(yy);
         if (i < 4) return;
-        // eigenvalue row oy = y0 - 5 + i from covariance rows (Ctop, Cmid, Cnew): row-major f64 sum
-        // (the reference starts from 0.0; 0.0 + x is x)
+        // eigenvalue row oy = y0 - 5 + i from covariance rows (Ctop, Cmid, Cnew): the exact f64 box sum
         const int oy = y0 - 5 + i;
-        double sxx = Ctop.xxl, sxy = Ctop.xyl, syy = Ctop.yyl;
-        sxx += Ctop.xxm; sxy += Ctop.xym; syy += Ctop.yym;
-        sxx += Ctop.xxr; sxy += Ctop.xyr; syy += Ctop.yyr;
-        sxx += Cmid.xxl; sxy += Cmid.xyl; syy += Cmid.yyl;
-        sxx += Cmid.xxm; sxy += Cmid.xym; syy += Cmid.yym;
-        sxx += Cmid.xxr; sxy += Cmid.xyr; syy += Cmid.yyr;
-        sxx += Cnew.xxl; sxy += Cnew.xyl; syy += Cnew.yyl;
-        sxx += Cnew.xxm; sxy += Cnew.xym; syy += Cnew.yym;
-        sxx += Cnew.xxr; sxy += Cnew.xyr; syy += Cnew.yyr;
+        const double sxx = (Ctop.xx + Cmid.xx) + Cnew.xx, sxy = (Ctop.xy + Cmid.xy) + Cnew.xy, syy = (Ctop.yy + Cmid.yy) + Cnew.yy;
         const float a = (float)sxx * 0.5f, b = (float)sxy, cc = (float)syy * 0.5f;
         const float t = a - cc;
         const float e = (a + cc) - sqrtf(t * t + b * b);
