@@ -69,7 +69,7 @@ __device__ __forceinline__ unsigned int gf_threshold_ordered(unsigned int mk, do
 #define SVS_DPP_WAVE_SHL1 0x130
 template <int CTRL> __device__ __forceinline__ float dpp_f32(float v)
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
 struct GePix { float d, hs; };      // per pixel row: right - left, and (s*left + 2s*mid) + s*right (the two Sobel row passes)
 // covariance products of (left, this, right) summed in f64, in that order: box_filter's RowSum; the three rows are then added
@@ -82,8 +82,8 @@ struct GeEig { float m, hm; };      // value, max over (left, value, right)
 template <int CTRL> __device__ __forceinline__ double dpp_f64x(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 
