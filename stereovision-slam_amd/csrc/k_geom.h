@@ -200,8 +200,11 @@ __device__ __forceinline__ void po_bfly(double *v, bool sel)
     }
 }
 
+#ifndef PO_BCAST_LDS        // A/B knob: 1 = the totals reach every lane through LDS broadcast reads, 0 = through v_readlane (SGPRs)
+#define PO_BCAST_LDS 1
+#endif
 template <int WAVES>
-__device__ __forceinline__ void po_block_sum32(double *v, double *buf, int tid)
+__device__ __forceinline__ void po_block_sum32(double *v, double *buf, double *bcast, int tid)
 {
     const int lane = tid & 63;
     const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
@@ -217,8 +220,25 @@ __device__ __forceinline__ void po_block_sum32(double *v, double *buf, int tid)
     double tot = 0;
 #pragma unroll
     for (int r = 0; r < 4 * WAVES; ++r) tot += buf[32 * r + (lane & 31)];
+    if (PO_BCAST_LDS && WAVES > 1) {
+    // the 28 totals to every lane: the wave parks them in its own 256 bytes of LDS and reads them back at wave-uniform
+    // addresses (14 broadcast ds_read_b128).  They then live in VGPRs: v_readlane would put them into SGPRs, of which the
+    // 6x6 algebra below wants more than there are (141 scalar spills = v_writelane / v_readlane pairs, and a v_mov for
+    // every second operand of an f64 instruction).  Same values either way.
+    double *mine = bcast + 32 * (tid >> 6);
+    if (lane < 32) mine[lane] = tot;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 14; ++i) {
+        const double2 q = reinterpret_cast<const double2 *>(mine)[i];
+        v[2 * i] = q.x; v[2 * i + 1] = q.y;
+    }
+    __builtin_amdgcn_wave_barrier();
+    } else {
 #pragma unroll
     for (int i = 0; i < 32; ++i) v[i] = readlane_f64(tot, i);
+    }
 }
 
 template <int WAVES>
@@ -257,7 +277,10 @@ __device__ __forceinline__ int po_block_sum_i32(int x, int *buf, int tid)
 #ifdef PO_NUM_VGPR          // A/B knob: cap of the kernel's unified registers (amdgpu_num_vgpr takes half of it on gfx90a+)
 #define PO_VGPR_ATTR __attribute__((amdgpu_num_vgpr((PO_NUM_VGPR) / 2)))
 #else
-#define PO_VGPR_ATTR
+// two waves per SIMD (<= 256 unified registers): the one-wave shape is a chain of dependent f64 instructions and runs a quarter
+// slower with the SIMD to itself (2048 jobs: 246 us at 243 registers, 277 us at 272 — what the kernel grew to when the
+// parameter tolerance was added, unnoticed for a day)
+#define PO_VGPR_ATTR __attribute__((amdgpu_waves_per_eu(WAVES == 1 ? 2 : 1)))
 #endif
 // FUSED (resident tracking): the kernel also does what stands before and after the optimisation in a tracked frame — the
 // survivor filter of TrackLastFrame (status && inside the image, src/frontend.cpp:361-371; an edge iff it also carries a map
@@ -272,6 +295,7 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
 {
     constexpr int NT = 64 * WAVES, SLOTS = PO_MAX_EDGES / NT;
     __shared__ __attribute__((aligned(16))) double s_red[4 * WAVES * 32];
+    __shared__ __attribute__((aligned(16))) double s_bcast[WAVES * 32];
     __shared__ double s_one[2][4 * WAVES];
     __shared__ int s_int[WAVES];
     PoseJob &jb = jobs[blockIdx.x];                    // (may be pinned host memory, svslam_hip.hip:dpz — every field is read once)
@@ -358,8 +382,7 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
         int nact = 0;
         nact = po_block_sum_i32<WAVES>(__builtin_popcount(vmask & ~omask), s_int, tid);
         if (nact > 0) {
-            double lambda = 0, ni = 2, lambda0 = 0;
-            bool stationary = false;
+            double lambda = 0, ni = 2;
             for (int it = 0; it < iters; ++it) {
                 // errors + chi2 + normal equations at T: acc[0..20] upper triangle of H, [21..26] b, [27] chi2
                 double acc[32];
@@ -405,7 +428,7 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
                     }
                 }
                 PO_TICKV(0, acc[0] + acc[27]);
-                po_block_sum32<WAVES>(acc, s_red, tid);
+                po_block_sum32<WAVES>(acc, s_red, s_bcast, tid);
                 PO_TICKV(1, acc[27] + acc[0]);
                 double currentChi = acc[27];
                 double H[36], b[6];
@@ -422,7 +445,7 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
                     double md = 0;
 #pragma unroll
                     for (int a = 0; a < 6; ++a) md = fmax(md, fabs(H[a * 7]));
-                    lambda = 1e-5 * md; ni = 2; lambda0 = lambda;
+                    lambda = 1e-5 * md; ni = 2;
                 }
                 double rho = 0; int qmax = 0;
                 double x[6] = { 0, 0, 0, 0, 0, 0 };
@@ -444,11 +467,13 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
                     // g2o has no such test (optimization_algorithm_levenberg.cpp: it goes on for the iterations asked for,
                     // src/frontend.cpp:487) — its remaining trials move the pose by rounding noise (|x| ~ 1e-13) and accept or
                     // reject on the sign of that noise; what is skipped is bounded by ~2 xtol, far inside the LM tolerances.
-                    if (xtol > 0 && qmax == 0 && ok2 && lambda <= lambda0) {
-                        double mx = 0;
+                    // (no state of its own: "not above the initial damping" is measured on the present H, and leaving the
+                    // trial loop with rho still 0 ends the round through g2o's own rho == 0 exit below)
+                    if (xtol > 0 && qmax == 0 && ok2) {
+                        double mx = 0, md = 0;
 #pragma unroll
-                        for (int a = 0; a < 6; ++a) mx = fmax(mx, fabs(x[a]));
-                        if (mx <= xtol) { stationary = true; break; }
+                        for (int a = 0; a < 6; ++a) { mx = fmax(mx, fabs(x[a])); md = fmax(md, fabs(H[a * 7])); }
+                        if (mx <= xtol && lambda <= 1e-5 * md) break;
                     }
                     double dT[7], Tn[7];
                     d_se3_exp(x, dT);
@@ -498,7 +523,7 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
                     ++qmax;
                     PO_TICKV(7, lambda + rho);
                 } while (rho < 0 && qmax < 10);
-                if (stationary || qmax == 10 || rho == 0 || !isfinite(lambda)) break;
+                if (qmax == 10 || rho == 0 || !isfinite(lambda)) break;
             }
         }
         // classify (src/frontend.cpp:495-525)
