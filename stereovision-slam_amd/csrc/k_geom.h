@@ -277,10 +277,12 @@ __device__ __forceinline__ int po_block_sum_i32(int x, int *buf, int tid)
 #ifdef PO_NUM_VGPR          // A/B knob: cap of the kernel's unified registers (amdgpu_num_vgpr takes half of it on gfx90a+)
 #define PO_VGPR_ATTR __attribute__((amdgpu_num_vgpr((PO_NUM_VGPR) / 2)))
 #else
-// two waves per SIMD (<= 256 unified registers): the one-wave shape is a chain of dependent f64 instructions and runs a quarter
-// slower with the SIMD to itself (2048 jobs: 246 us at 243 registers, 277 us at 272 — what the kernel grew to when the
-// parameter tolerance was added, unnoticed for a day)
-#define PO_VGPR_ATTR __attribute__((amdgpu_waves_per_eu(WAVES == 1 ? 2 : 1)))
+// (no cap: the kernel has to FIT two waves per SIMD — <= 256 unified registers — by itself.  The one-wave shape is a chain of
+// dependent f64 instructions and runs a third slower with the SIMD to itself: 2048 jobs 277 us at 272 registers, what the
+// kernel had grown to when the parameter tolerance was added, against 246 us at 243 before.  Forcing the limit
+// (amdgpu_waves_per_eu) made the compiler spill two registers to scratch, and the FUSED instantiation then disagreed with the
+// CPU twin in the pipeline tests — not pursued; the last trial's pose went to LDS instead: 228 registers, nothing spilled.)
+#define PO_VGPR_ATTR
 #endif
 // FUSED (resident tracking): the kernel also does what stands before and after the optimisation in a tracked frame — the
 // survivor filter of TrackLastFrame (status && inside the image, src/frontend.cpp:361-371; an edge iff it also carries a map
@@ -296,6 +298,7 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
     constexpr int NT = 64 * WAVES, SLOTS = PO_MAX_EDGES / NT;
     __shared__ __attribute__((aligned(16))) double s_red[4 * WAVES * 32];
     __shared__ __attribute__((aligned(16))) double s_bcast[WAVES * 32];
+    __shared__ __attribute__((aligned(16))) double s_te[WAVES][8];
     __shared__ double s_one[2][4 * WAVES];
     __shared__ int s_int[WAVES];
     PoseJob &jb = jobs[blockIdx.x];                    // (may be pinned host memory, svslam_hip.hip:dpz — every field is read once)
@@ -359,7 +362,9 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
             u_ = (double)m.x; v_ = (double)m.y;
         }
     };
-    double Te[7] = { 0, 0, 0, 1, 0, 0, 0 };        // pose of the last evaluated LM trial
+    // pose of the last evaluated LM trial: only the classification at the end of a round reads it, so it waits in LDS (the
+    // wave's own 64 bytes, written by lane 0), not in 14 registers through the whole trial loop
+    double *s_Te = s_te[tid >> 6];
     bool have_eval = false;
     bool robust = true;
     int cnt_outlier = 0, n_edges = 0, one = 0;
@@ -479,7 +484,11 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
                     d_se3_exp(x, dT);
                     d_se3_mul(dT, T, Tn);
 #pragma unroll
-                    for (int i = 0; i < 7; ++i) { T[i] = Tn[i]; Te[i] = Tn[i]; }
+                    for (int i = 0; i < 7; ++i) T[i] = Tn[i];
+                    if ((tid & 63) == 0) {
+#pragma unroll
+                        for (int i = 0; i < 7; ++i) s_Te[i] = Tn[i];
+                    }
                     have_eval = true;
                     PO_TICKV(3, T[0] + T[6]);
                     double tchi = 0;
@@ -528,7 +537,13 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
         }
         // classify (src/frontend.cpp:495-525)
         int co = 0;
-        double RtT[12], RtE[12];
+        double RtT[12], RtE[12], Te[7] = { 0, 0, 0, 1, 0, 0, 0 };
+        if (have_eval) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 7; ++i) Te[i] = s_Te[i];
+        }
         po_pose_table(T, RtT); po_pose_table(Te, RtE);
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
