@@ -200,6 +200,9 @@ __device__ __forceinline__ void po_bfly(double *v, bool sel)
     }
 }
 
+#ifndef PO_BCAST_W1
+#define PO_BCAST_W1 0
+#endif
 #ifndef PO_BCAST_LDS        // A/B knob: 1 = the totals reach every lane through LDS broadcast reads, 0 = through v_readlane (SGPRs)
 #define PO_BCAST_LDS 1
 #endif
@@ -220,7 +223,7 @@ __device__ __forceinline__ void po_block_sum32(double *v, double *buf, double *b
     double tot = 0;
 #pragma unroll
     for (int r = 0; r < 4 * WAVES; ++r) tot += buf[32 * r + (lane & 31)];
-    if (PO_BCAST_LDS && WAVES > 1) {
+    if (PO_BCAST_LDS && (WAVES > 1 || PO_BCAST_W1)) {
     // the 28 totals to every lane: the wave parks them in its own 256 bytes of LDS and reads them back at wave-uniform
     // addresses (14 broadcast ds_read_b128).  They then live in VGPRs: v_readlane would put them into SGPRs, of which the
     // 6x6 algebra below wants more than there are (141 scalar spills = v_writelane / v_readlane pairs, and a v_mov for
