@@ -14,9 +14,11 @@
 //      derivative image per level — 5.3 bytes/pixel of HBM traffic never needed),
 //   3. interpolates its two I/Ix/Iy samples (Q14 weights, v_dot2_i32_i16) into
 //      registers and wave-reduces A11,A12,A22 (int32, exact),
-//   4. stages a 32x32 J search region into LDS with aligned dword loads and
-//      iterates entirely out of LDS (re-staging only if the window leaves the
-//      region); b1,b2 are reduced as int32 DPP row sums + a 64-bit scalar tail.
+//   4. stages a 32x32 J search region into LDS with aligned dword loads — stored EXPANDED, one dword per position
+//      holding the tap pair (J[x] | J[x+1] << 16), so that a bilinear sample is one ds_read2_b32 (rows y, y+1) and two
+//      v_dot2_i32_i16 — and iterates entirely out of LDS (re-staging only if the window leaves the region); b1, b2 are
+//      one i16 dot product per lane each and are summed over the wave by v_permlane16_swap + ONE DPP row reduction
+//      (int32; a 64-bit scalar tail for adversarial patches).  Round 5: 71 -> 57 VALU instructions per iteration.
 // LDS discipline: every LDS access is a naturally aligned dword (pairs via
 // ds_read2_b32); bytes at arbitrary offsets are extracted with v_perm_b32 /
 // v_alignbyte_b32 using a per-lane selector.  A misaligned ds_read_u16/b32 is
