@@ -453,3 +453,39 @@ def test_pose_only_lm_trajectory_matches_independent_g2o_restatement(orc):
         traj = _np_g2o_lm_pose_only(P, uvd, cm.EXT_L, iters=k, delta=1.0)
         Rk, tk = traj[-1]
         assert np.allclose(cm.quat_R(T[:4]), Rk, atol=1e-9) and np.allclose(T[4:], tk, atol=1e-8), k
+
+
+def test_min_eigenvalue_map_is_independent_of_the_box_sum_order(orc, svs):
+    """The 3x3 box sum of the covariance products (cornerMinEigenVal -> boxFilter, f64 accumulators) is declared by the
+    oracle as box_filter's own order since round 5: three columns of a row, then the three rows (oracle/orc_gftt.c; the HIP
+    kernel sums the same way).  Until then it was declared as one row-major sum.  An independent numpy restatement of the
+    whole map with BOTH orders: the f64 sums may differ in a handful of pixels (they are not always exact: a dy that is a
+    rounding residue beside large products), the f32 eigenvalue map must be the oracle's bit for bit either way — so the
+    corner lists of rounds 1-4 and their golden fixtures stand."""
+    s1 = np.float32(1.0 / 3060.0); s2 = np.float32(2.0 * (1.0 / 3060.0))
+    differ64 = 0
+    for seed, frame in ((900, 0), (901, 7), (902, 3)):
+        img = svs.synth_pair(seed, frame)[seed & 1]
+        p = np.pad(img.astype(np.float32), 1, mode="reflect")
+        d = p[:, 2:] - p[:, :-2]
+        dx = ((d[:-2] + d[2:]) * s1 + d[1:-1] * s2).astype(np.float32)
+        c = ((s1 * p[:, :-2] + s2 * p[:, 1:-1]).astype(np.float32) + s1 * p[:, 2:]).astype(np.float32)
+        dy = (c[2:] - c[:-2]).astype(np.float32)
+        maps = []
+        for prod in ((dx * dx).astype(np.float32), (dx * dy).astype(np.float32), (dy * dy).astype(np.float32)):
+            q = np.pad(prod.astype(np.float64), 1, mode="reflect")
+            h, w = prod.shape
+            rowmajor = np.zeros((h, w))
+            for j in range(3):
+                for i in range(3):
+                    rowmajor = rowmajor + q[j:j + h, i:i + w]
+            hs = (q[:, :-2] + q[:, 1:-1]) + q[:, 2:]
+            separable = (hs[:-2] + hs[1:-1]) + hs[2:]
+            differ64 += int((rowmajor != separable).sum())
+            assert np.array_equal(rowmajor.astype(np.float32), separable.astype(np.float32))
+            maps.append(separable.astype(np.float32))
+        a, b, cc = maps[0] * np.float32(0.5), maps[1], maps[2] * np.float32(0.5)
+        t = (a - cc).astype(np.float32)
+        eig = ((a + cc).astype(np.float32) - np.sqrt((t * t).astype(np.float32) + (b * b).astype(np.float32)).astype(np.float32)).astype(np.float32)
+        assert np.array_equal(eig, orc.min_eig_map(img)), (seed, frame)
+    print("f64 box sums that depend on the order:", differ64, "of", 3 * 3 * img.size)
