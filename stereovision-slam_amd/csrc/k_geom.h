@@ -15,11 +15,22 @@
 struct TriJob { int pt_ofs, npts; double T_wc[7]; double zmax; };
 struct TriCams { double cam_l[4], ext_l[7], cam_r[4], ext_r[7]; };
 
+// (Round 5: the rotation without IEEE divisions / roots — one root, one reciprocal, one reciprocal root by estimate + Newton —
+// was built: 22 -> 19.5 us for one launch, results equal to rounding.  Not kept: it changes the last digit of a landmark, and a
+// pipeline run that differs in a last digit parts ways with the CPU twin as early as one at pose_xtol 1e-9 does (4.4), for
+// 0.2 % of the step.  The launch geometry below was the triangulation's real cost.)
+// No FMA contraction inside the SVD (round 5): the oracle's arithmetic operation for operation — IEEE products, sums, quotients
+// and roots round the same on both sides, so singular values and vectors are the oracle's bit for bit — and, what made it
+// urgent, its CONVERGENCE: with contracted dot products the off-diagonal term of a converged pair sat a hair above the
+// 2.3e-16 threshold in some lanes, the rotation it asked for changed nothing, and those lanes — hence their waves — ran all
+// 60 sweeps instead of 4-6: 210 us per wave, ~320 us per launch of 440 keyframes instead of ~30.
+#pragma clang fp contract(off)
 __device__ inline void d_svd4_jacobi(double *A, double *V, double *sv)
 {
     for (int i = 0; i < 16; ++i) V[i] = (i % 5 == 0) ? 1.0 : 0.0;
     for (int sweep = 0; sweep < 60; ++sweep) {
         int rotated = 0;
+        bool changed = false;
         for (int p = 0; p < 3; ++p)
             for (int q = p + 1; q < 4; ++q) {
                 double al = 0, be = 0, ga = 0;
@@ -35,14 +46,20 @@ __device__ inline void d_svd4_jacobi(double *A, double *V, double *sv)
                 double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
                 for (int i = 0; i < 4; ++i) {
                     double ap = A[i * 4 + p], aq = A[i * 4 + q];
-                    A[i * 4 + p] = c * ap - s * aq;
-                    A[i * 4 + q] = s * ap + c * aq;
+                    const double ap1 = c * ap - s * aq, aq1 = s * ap + c * aq;
+                    A[i * 4 + p] = ap1; A[i * 4 + q] = aq1;
                     double vp = V[i * 4 + p], vq = V[i * 4 + q];
-                    V[i * 4 + p] = c * vp - s * vq;
-                    V[i * 4 + q] = s * vp + c * vq;
+                    const double vp1 = c * vp - s * vq, vq1 = s * vp + c * vq;
+                    V[i * 4 + p] = vp1; V[i * 4 + q] = vq1;
+                    changed |= (ap1 != ap) | (aq1 != aq) | (vp1 != vp) | (vq1 != vq);
                 }
             }
-        if (!rotated) break;
+        // A sweep that left every entry of A and V as it was is a fixed point: the remaining sweeps would repeat it bit for
+        // bit, so leaving here changes no output.  It is what an EXACTLY singular system does (a stereo match whose row equals
+        // the left feature's to the last bit makes two rows of A equal: the zero column's gamma is rounding noise above a zero
+        // threshold, the rotation it asks for is the identity) — 1 match in ~10 000, but its wave ran all 60 sweeps, ~200 us,
+        // and was the launch: k_triangulate 213 us per launch of ~440 keyframes (round 5: found by printing from the kernel).
+        if (!rotated || !changed) break;
     }
     for (int j = 0; j < 4; ++j) {
         double s = 0;
@@ -59,12 +76,17 @@ __device__ inline void d_svd4_jacobi(double *A, double *V, double *sv)
     }
 }
 
+#pragma clang fp contract(fast)
+
 __global__ void __launch_bounds__(64)
 k_triangulate(const TriJob *jobs, TriCams cams, const float2 *uv_l, const float2 *uv_r,
               double *out_xyz, uint8_t *out_ok)
 {
-    const TriJob &jb = jobs[blockIdx.y];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // grid (jobs, 64-point blocks of the capacity): consecutive workgroup ids — which the dispatcher deals round-robin to the
+    // 8 XCDs — are different JOBS' blocks.  The other way round (blocks of a job consecutive) the capacity of 512 points = 8
+    // blocks per job put block b of every job on XCD b, and a keyframe's ~160 points (3 blocks) on 3 of the 8 XCDs (round 5).
+    const TriJob &jb = jobs[blockIdx.x];
+    const int i = blockIdx.y * blockDim.x + threadIdx.x;
     if (i >= jb.npts) return;
     const int pt = jb.pt_ofs + i;
     const float2 l = uv_l[pt], r = uv_r[pt];

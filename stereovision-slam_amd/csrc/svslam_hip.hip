@@ -1075,7 +1075,7 @@ int svslam_triangulate_batch(svslam_ctx *c, int njobs, const svslam_tri_job *job
     if (h2d(c, 0, in_end)) return -1;
     if (maxn > 0) {
         tm_begin(c, FAM_TRI, total_pts);
-        hipLaunchKernelGGL(k_triangulate, dim3(cdiv(maxn, 64), njobs), dim3(64), 0, c->stream, dp<TriJob>(c, ojobs),
+        hipLaunchKernelGGL(k_triangulate, dim3(njobs, cdiv(maxn, 64)), dim3(64), 0, c->stream, dp<TriJob>(c, ojobs),       // (job-major grid: k_geom.h)
                            cams, dp<float2>(c, ol), dp<float2>(c, orr), dp<double>(c, oxyz), dp<uint8_t>(c, ook));
         tm_end(c);
         HIPCHK(c, hipGetLastError());
@@ -1821,7 +1821,7 @@ static int dmap_keyframe_impl(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, c
     hipLaunchKernelGGL(k_dmap_stereo_finish, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, prm, dp<float2>(c, onext), dp<uint8_t>(c, ostat),
                        dp<TriJob>(c, otj), dp<float2>(c, oul), dp<float2>(c, our_), dp<int>(c, otidx));
     tm_begin(c, FAM_TRI, 0);
-    hipLaunchKernelGGL(k_triangulate, dim3(cdiv(NF, 64), njobs), dim3(64), 0, c->stream, dp<TriJob>(c, otj), tc, dp<float2>(c, oul), dp<float2>(c, our_),
+    hipLaunchKernelGGL(k_triangulate, dim3(njobs, cdiv(NF, 64)), dim3(64), 0, c->stream, dp<TriJob>(c, otj), tc, dp<float2>(c, oul), dp<float2>(c, our_),
                        dp<double>(c, oxyz), dp<uint8_t>(c, ook));
     tm_end(c);
     hipLaunchKernelGGL(k_dmap_commit, dim3(njobs), dim3(DM_THREADS), 0, c->stream, dj, m, dp<double>(c, oxyz), dp<uint8_t>(c, ook), dp<int>(c, otidx), dp<int>(c, oslot));

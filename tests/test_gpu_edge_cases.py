@@ -267,3 +267,36 @@ def test_local_ba_batch_properties_without_oracle(svs):
     # the noise-free problem ends at (numerically) zero reprojection error: f32 pixel rounding only
     assert res[len(base) - 1][2].max() < 1e-4 and np.median(res[len(base) - 1][2]) < 1e-7
     c.close()
+
+
+def test_triangulate_exactly_singular_matches(svs, orc):
+    """A stereo match whose row equals the left feature's to the last bit (LK left the y coordinate untouched: about one match
+    in 10 000 of the synthetic streams) makes two rows of the DLT matrix equal: the system is exactly singular and the Jacobi
+    sweeps of the oracle never report convergence (60 sweeps of identity rotations).  The kernel leaves at the first sweep that
+    changes nothing — the outputs must still be the oracle's: flags exact, positions of the accepted points to 1e-9, and with
+    the SVD compiled without FMA contraction (round 5) bit for bit.  Mixed with ordinary matches in one job, plus identical
+    left / right pixels (zero disparity)."""
+    rng = np.random.default_rng(77)
+    n = 192
+    fx, fy, cx, cy = cm.CAM
+    Z = rng.uniform(3, 60, n); X = rng.uniform(-8, 8, n); Y = rng.uniform(-2, 1.5, n)
+    l = np.stack([fx * X / Z + cx, fy * Y / Z + cy], 1)
+    r = np.stack([fx * (X - cm.BASELINE) / Z + cx, fy * Y / Z + cy], 1)
+    l += rng.normal(0, 0.3, l.shape); r += rng.normal(0, 0.3, r.shape)
+    l = l.astype(np.float32); r = r.astype(np.float32)
+    l[::3] = np.round(l[::3])                  # GFTT corners are integers
+    r[::3, 1] = l[::3, 1]                      # ... and these matches kept the row exactly
+    r[5] = l[5]                                # zero disparity
+    c = svs.Context(cm.W, cm.H, max_slots=1, max_jobs=2, max_pts=256, max_kf=0, max_lm=0, max_obs=0)
+    T = cm.random_pose(np.random.default_rng(2))
+    jobs = [(l, r, None, 0.0), (l, r, T, 40.0)]
+    res = c.triangulate(jobs, cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R)
+    for (xyz, ok), (ul, ur, Tj, zmax) in zip(res, jobs):
+        xyz_ref, ok_ref = orc.triangulate(cm.CAM, cm.EXT_L, cm.CAM, cm.EXT_R, ul, ur, Tj, zmax)
+        assert np.array_equal(ok, ok_ref)
+        m = ok_ref > 0
+        assert m.sum() > 100
+        assert np.allclose(xyz[m], xyz_ref[m], rtol=1e-9, atol=1e-9)
+        if Tj is None:
+            assert np.array_equal(xyz[m], xyz_ref[m])           # camera frame == world frame: nothing but the SVD and three quotients
+    c.close()
