@@ -303,10 +303,11 @@ __device__ __forceinline__ int po_block_sum_i32(int x, int *buf, int tid)
 #define PO_VGPR_ATTR __attribute__((amdgpu_num_vgpr((PO_NUM_VGPR) / 2)))
 #else
 // (no cap: the kernel has to FIT two waves per SIMD — <= 256 unified registers — by itself.  The one-wave shape is a chain of
-// dependent f64 instructions and runs a third slower with the SIMD to itself: 2048 jobs 277 us at 272 registers, what the
-// kernel had grown to when the parameter tolerance was added, against 246 us at 243 before.  Forcing the limit
-// (amdgpu_waves_per_eu) made the compiler spill two registers to scratch, and the FUSED instantiation then disagreed with the
-// CPU twin in the pipeline tests — not pursued; the last trial's pose went to LDS instead: 228 registers, nothing spilled.)
+// dependent f64 instructions and runs a quarter slower with the SIMD to itself: 2048 copies of tools/po_trace.py's job (60
+// trials) 277 us at 272 registers — what the kernel had grown to when the parameter tolerance was added — against 218 us at
+// 228.  Forcing the limit (amdgpu_waves_per_eu) made the compiler spill two registers to scratch, and the FUSED instantiation
+// then disagreed with the CPU twin in the pipeline tests — not pursued; the last trial's pose went to LDS instead: 228
+// registers, nothing spilled.)
 #define PO_VGPR_ATTR
 #endif
 // FUSED (resident tracking): the kernel also does what stands before and after the optimisation in a tracked frame — the
