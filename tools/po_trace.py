@@ -39,4 +39,22 @@ for nj in (1, 256, 1024, 2048, 4096):
     ms, n, _ = c.timing_get("pose_only")
     print("pose_only jobs=%d: %.1f us/launch" % (nj, 1e3 * ms / max(n, 1)))
     c.timing(True)
+# The figures above belong to ONE job and move with its trial count (a last digit of its inputs changes that count).  For a
+# figure that compares builds: 64 different tracking-shaped jobs (tests/lm_cases.py: po_tracking_case, numpy only), cycled to
+# the launch size, with the trials they ran.
+import lm_cases as lc
+many = [lc.po_tracking_case(s) for s in range(64)]
+c.lm_trace(True)
+c.pose_only(many, cm.CAM)
+ntr = [len(c.lm_trace(True, job=i)) for i in range(len(many))]
+c.lm_trace(False)
+print("64 tracking-shaped jobs: trials per job mean %.1f (min %d, max %d), edges per job mean %.0f" % (np.mean(ntr), min(ntr), max(ntr), np.mean([len(j[1]) for j in many])))
+c.timing(True)
+for nj in (2048, 4096):
+    jobs = [many[i % 64] for i in range(nj)]
+    for rep in range(3):
+        c.pose_only(jobs, cm.CAM)
+    ms, n, _ = c.timing_get("pose_only")
+    print("pose_only jobs=%d (64 different, cycled): %.1f us/launch" % (nj, 1e3 * ms / max(n, 1)))
+    c.timing(True)
 c.close()
