@@ -97,7 +97,8 @@ int svslam_set_source_size(svslam_ctx *ctx, int src_w, int src_h);
 int svslam_set_low_latency(svslam_ctx *ctx, int on);
 /* Parameter tolerance of the pose-only LM (svslam_pose_only_batch, svslam_track_batch, svslam_rtrack_batch; default 1e-12,
  * environment SVSLAM_PO_XTOL at svslam_create).  A round of EstimateCurrentPose (src/frontend.cpp:482-493: optimize(10)) ends
- * when the first trial of an LM iteration, taken at a damping not above the round's initial one, asks for a step whose six
+ * when the first trial of an LM iteration, taken at a damping not above g2o's initial one for the present system (1e-5 x the
+ * largest diagonal entry of H), asks for a step whose six
  * components are all <= xtol (metres / radians): the round stands at a stationary point of its cost.  g2o has no such test;
  * it runs the ten iterations, and where a round has converged earlier it spends the rest on trials that move the pose by
  * rounding noise and are accepted or rejected by the sign of that noise.  The trials that are run are g2o's, bit for bit;

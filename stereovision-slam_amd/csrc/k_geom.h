@@ -493,7 +493,7 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
                     bool ok2 = d_ldlt6(Hl, b, x);
                     PO_TICKV(2, x[0] + x[5]);
                     // Parameter tolerance (xtol > 0; svslam_set_pose_only_xtol): the FIRST trial of an iteration whose damping is
-                    // not above the round's initial one is (nearly) the Newton step; when no component of it reaches xtol
+                    // not above g2o's initial one for the present H (1e-5 max diag) is (nearly) the Newton step; when no component of it reaches xtol
                     // (metres / radians) the round stands at a stationary point of its cost and ends here, the step not taken.
                     // g2o has no such test (optimization_algorithm_levenberg.cpp: it goes on for the iterations asked for,
                     // src/frontend.cpp:487) — its remaining trials move the pose by rounding noise (|x| ~ 1e-13) and accept or
