@@ -5,7 +5,7 @@
 // operation; integer patches and the exact-integer normal-equation sums make
 // the result bit-exact against the oracle.
 //
-// Mapping: window 11x11 = 121 pixels -> 2 pixels per lane.  Per level the wave
+// Mapping: one wave per point, one wave per workgroup; window 11x11 = 121 pixels -> 2 pixels per lane.  Per level the wave
 //   1. stages the 14 x 20 I neighbourhood (aligned dword loads from the
 //      stored-border pyramid -> LDS, no index arithmetic),
 //   2. computes the Scharr derivatives of the 12x12 inner positions on the fly,
@@ -52,7 +52,13 @@ struct LkParams {
 #define LK_NPIX 121
 #define LK_W_BITS 14
 #define LK_REG 32
-#define LK_WAVES_PER_BLOCK 4
+// Waves (= points) per workgroup.  The waves of this kernel never meet, but a workgroup keeps its wave slots, registers and LDS
+// until its LAST wave is done, and the iteration counts have a heavy tail (a point that runs max_count iterations on every
+// level takes five times the mean): with 4 waves per workgroup three finished waves' resources waited for the fourth.
+// One wave per workgroup: 367 -> 325-335 us per 512 x 150 points temporal, 295 -> 275 stereo, the bench +2 % (round 5).
+#ifndef LK_WAVES_PER_BLOCK
+#define LK_WAVES_PER_BLOCK 1
+#endif
 #define LK_IROW 20            // bytes per staged I row (5 aligned dwords)
 
 typedef uint32_t lk_u32_ua __attribute__((aligned(1)));
