@@ -28,9 +28,13 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 W, H = 620, 188                     # KITTI-00 1241x376 after the reference's 1/2 decimation (F3)
+FW, FH = 1241, 376                  # the camera's frame (BASELINE.json's metric names this size): stored in HBM by default
 HBM_PEAK_GBS = 8000.0               # spec (MI355X_MICROARCH.md)
 HBM_PEAK_MEASURED_GBS = 6290.0      # float4 copy on MI355X (MI355X_MICROARCH.md chip table); SURVEY 8d's denominator
 LEVEL_PIX = (620 * 188, 310 * 94, 155 * 47, 78 * 24)
+
+
+SRC_PIX = 0     # pixels of a stored frame when the 1/2 decimation is fused into the pyramid (0: frames arrive decimated)
 
 
 def algorithmic_bytes(fam, cnt, launches):
@@ -39,13 +43,15 @@ def algorithmic_bytes(fam, cnt, launches):
         return (cnt["track_pts"] + cnt["right_pts"]) * (2384 + 21)
     if fam == "pose_only":   # 40 B per edge (xyz f64 + uv f32 + flags) + 56 B pose
         return cnt["pose_edges"] * 40 + launches * 56
-    if fam == "pyramid":     # image read once + levels 1..3 written once
-        return (cnt["pyr_left"] + cnt["pyr_right"]) * sum(LEVEL_PIX)
+    if fam == "pyramid":     # image read once + levels 1..3 written once; from a full-resolution frame: the
+        #                      rows of the 1241x376 frame that the 1/2 nearest decimation samples (every second one, 233 308 B)
+        #                      read once + all four levels written once (level 0 IS the decimation's output)
+        return (cnt["pyr_left"] + cnt["pyr_right"]) * (sum(LEVEL_PIX) + SRC_PIX)
     if fam == "gftt":        # image read once + rect list + corners out
         return cnt["gftt_calls"] * LEVEL_PIX[0] + cnt["gftt_rects"] * 8 + cnt["corners"] * 8
     if fam == "triangulate":
         return cnt["tri_pts"] * (16 + 24 + 1)
-    if fam == "local_ba":    # iters x (E x 40 B obs+ids + K x 56 B + M x 24 B)
+    if fam in ("local_ba", "ba_solve"):    # iters x (E x 40 B obs+ids + K x 56 B + M x 24 B); ba_solve: the solver kernel of the family alone
         it = max(cnt["ba_iters"], 1) / max(cnt["ba_calls"], 1)
         return it * (cnt["ba_edges"] * 40 + cnt["ba_kf"] * 56 + cnt["ba_lm"] * 24)
     return 0
@@ -65,6 +71,18 @@ def measured_traffic(fam, cnt, launches):
     if not units or not launches:
         return None
     return t["bytes"] * units / launches
+
+
+def pmc_stamp(name, build_info):
+    """which build a committed PMC summary under profiles/ was measured on (its "build_info" field, written by tools/pmc_*.sh
+    from svslam_build_info()) and whether that is the library this run loaded"""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+    except (OSError, ValueError):
+        return {"file": "profiles/" + name, "build_info": None, "matches_loaded_library": False}
+    b = d.get("build_info")
+    return {"file": "profiles/" + name, "build_info": b, "operating_point": d.get("operating_point"),
+            "matches_loaded_library": bool(b) and b == build_info}
 
 
 F64_VECTOR_PEAK_TFLOPS = 78.6       # MI355X f64 vector peak (half the f32 vector rate, MI355X_MICROARCH.md chip table)
@@ -172,11 +190,12 @@ def thread_cpu_seconds():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("SVS_BENCH_STREAMS", "0")),
                     help="independent stereo streams per GPU, advanced in lockstep (0 = the largest of 12288 / 8192 / "
-                         "6144 whose frame buffers fit the GPU's memory for this --warmup + --steps)")
+                         "6144 whose frame ring of warmup + steps frames fits the GPU's memory; when none does — full-size "
+                         "frames and many steps — 8192 streams with a shorter ring, the timed region then runs in blocks)")
     ap.add_argument("--groups", type=int, default=int(os.environ.get("SVS_BENCH_GROUPS", "0")),
                     help="host threads per GPU, each driving streams/groups streams through its own "
                          "svslam context (own HIP stream): one group's BA overlaps the others' tracking")
@@ -215,15 +234,19 @@ def main():
                     help="keep every stream's map (window, features, landmarks, observations) on the HOST as in rounds 1-2; "
                          "default: the map lives in HBM and the keyframe path is one chain of kernels (svslam_dmap_*) — "
                          "bit-identical results, a fraction of the host CPU")
-    ap.add_argument("--full-res-streams", type=int, default=-1,
-                    help="streams of the value_full_res leg: after the reported run the script runs itself once more with the "
-                         "frames stored at the camera's 1241x376 (BASELINE's metric names that size) and the 1/2 decimation "
-                         "fused into the pyramid, at most 20 + 5 steps so that the full-size frame ring fits (0 = skip; -1 = 8192 when "
-                         "--streams is left to the script, i.e. the headline operating point, else skip; one GPU only, never under torchrun's N > 1)")
-    ap.add_argument("--full-res", action="store_true",
-                    help="keep the frames in HBM at the camera's 1241x376 and fuse the reference's 1/2 "
-                         "decimation (Dataset::NextFrame) into the pyramid's level 0 (SURVEY 8 row f3); 4x the "
-                         "frame bytes, so fewer streams fit")
+    ap.add_argument("--pre-decimated", action="store_true",
+                    help="keep the frames in HBM already decimated to 620x188 (the reference's working resolution, what "
+                         "Frontend::AddFrame sees; rounds 1-5 reported this as `value`).  Default since round 6: frames stored at "
+                         "the camera's 1241x376 — the size BASELINE.json's metric names — and the reference's 1/2 decimation "
+                         "(Dataset::NextFrame, src/dataset.cpp:126-129) fused into the pyramid's level 0 (SURVEY 8 row f3)")
+    ap.add_argument("--full-res", action="store_true", help="(the default since round 6; accepted for older scripts)")
+    ap.add_argument("--predecimated-streams", "--full-res-streams", dest="secondary_streams", type=int, default=-1,
+                    help="streams of the value_predecimated leg: after the reported run the script runs itself once more with "
+                         "--pre-decimated (0 = skip; -1 = 12288 when --streams is left to the script, i.e. the headline "
+                         "operating point, else skip; one GPU only, never under torchrun's N > 1)")
+    ap.add_argument("--super-windows", type=int, default=6,
+                    help="when a window of --steps steps lasts < 1 s: one more timed region of this many x --steps steps back to "
+                         "back (value_super_window; 0 = skip)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: the launch contract only — rank discovery, stream partition, barriers, max-over-ranks timing, "
                          "the JSON line (dry_run: true) — with a rank-dependent sleep as the step; what tests/test_abi_and_host.py "
@@ -231,8 +254,9 @@ def main():
     args = ap.parse_args()
     if args.dry_run:
         return dry_run(args)
-    if args.full_res_streams < 0:         # (a small --streams run of a test or a latency script must not spawn an 8192-stream child)
-        args.full_res_streams = 8192 if args.streams <= 0 else 0
+    full_res = not args.pre_decimated
+    if args.secondary_streams < 0:        # (a small --streams run of a test or a latency script must not spawn a 12288-stream child)
+        args.secondary_streams = 12288 if (args.streams <= 0 and full_res) else 0
 
     import torch
     svs = importlib.import_module("stereovision-slam_amd")
@@ -249,27 +273,45 @@ def main():
     svs.load()                                      # fails loudly if the HIP library is missing
 
     S, Wm, K = args.streams, args.warmup, args.steps
-    # The synthetic frames live in HBM.  One buffer of FB = warmup + steps frames per stream is rendered
-    # block by block (pre-roll blocks first, then the block that holds the warm-up and the timed steps),
-    # always outside the timed region: keep it under ~190 GB.
-    SW, SH = (1241, 376) if args.full_res else (W, H)     # stored frame size
-    FB = Wm + K if args.ring_frames <= 0 else max(Wm + 1, min(Wm + K, args.ring_frames))
-    budget = 225e9                                   # of the MI355X's 288 GB; the pyramids and work buffers need ~1 MB per stream
+    # The synthetic frames live in HBM.  One ring of FB frames per stream is rendered block by block (pre-roll blocks first,
+    # then the block that holds the warm-up and the first timed steps), always outside the timed region.  FB = warmup + steps
+    # when that fits (one timed block), else as many frames as fit: the timed region then runs in blocks (see timed()).
+    SW, SH = (FW, FH) if full_res else (W, H)             # stored frame size
+    global SRC_PIX
+    # INTER_NEAREST at 1/2 (src/dataset.cpp:126-129) samples the even pixels of the even rows: the rows that hold samples are
+    # read (whole rows: the samples sit in every 64-byte line of them), the odd rows are never touched
+    SRC_ROWS = (SH + 1) // 2
+    SRC_PIX = SW * SRC_ROWS if full_res else 0
+    budget = 225e9                                   # of the MI355X's 288 GB; the pyramids, maps and work buffers need ~1 MB per stream
     if torch.cuda.is_available():
         budget = min(budget, 0.8 * torch.cuda.mem_get_info(local_rank)[0])
-    cap = int(budget // (2 * SW * SH * FB + (1 << 20)))
+    per_stream = 1 << 20
+
+    def cap_for(fb):
+        return int(budget // (2 * SW * SH * fb + per_stream))
+
+    def ring_for(streams):
+        return int((budget / max(streams, 1) - per_stream) // (2 * SW * SH))
+    FB = Wm + K if args.ring_frames <= 0 else max(Wm + 1, min(Wm + K, args.ring_frames))
     if S <= 0:
         # more streams per launch fill the chip better (measured: 6144 / 8192 / 12288 streams = 1.00 / 1.04 / 1.08),
-        # the frame ring of warmup + steps frames per stream decides what fits
-        S = next((c for c in (12288, 8192, 6144) if c <= cap), cap)
+        # the frame ring decides what fits
+        S = next((c for c in (12288, 8192, 6144) if c <= cap_for(FB)), 0)
+        if S == 0:
+            S = 8192
+            FB = max(Wm + 1, min(FB, ring_for(S)))
         # a rank that may use only a few cores (N ranks sharing one CPU quota) cannot feed that many streams:
         # ~27 us of host CPU per frame; keep its memory footprint in proportion
         # (only with the map on the host: the device-resident map costs the host < 1 core per 12 288 streams)
         lw = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
         if args.host_map:
             S = min(S, 1024 * max(1, effective_cpus() // max(1, lw)))
-    if S > cap:
-        S = max(512, cap // 512 * 512) if cap >= 512 else max(1, cap)
+    if S > cap_for(FB):
+        if args.ring_frames <= 0 and ring_for(S) >= Wm + 4:
+            FB = min(FB, ring_for(S))                # an explicit stream count keeps its streams and gets a shorter ring
+        else:
+            cap = cap_for(FB)
+            S = max(512, cap // 512 * 512) if cap >= 512 else max(1, cap)
     # host layout from the cores this rank may actually use (cgroup quota / ranks on the node):
     # about two threads per core (half of them are waiting on the GPU at any time), at most 12
     # groups x at most 4 bookkeeping threads
@@ -292,7 +334,7 @@ def main():
         args.host_threads = 1 if dev_map else max(1, min(4, (2 * cores + G - 1) // G))
     Sg = S // G
     cfg = pl.default_config(W, H, host_threads=max(1, args.host_threads), backend_on=args.backend_mode,
-                            src_width=SW if args.full_res else 0, src_height=SH if args.full_res else 0,
+                            src_width=SW if full_res else 0, src_height=SH if full_res else 0,
                             low_latency=1 if args.low_latency else 0,
                             device_map=0 if args.host_map else 1, backend_lag=max(1, args.backend_lag))
     pipes = [pl.Pipeline(cfg, nstreams=Sg, device=local_rank) for _ in range(G)]
@@ -303,7 +345,7 @@ def main():
         ctxs = ctxs + [svs.Context.borrow(p.backend_ctx(), W, H) for p in pipes]
 
     img = SW * SH
-    cam_r = tuple(2 * v for v in svs.KITTI00_HALF_CAM) if args.full_res else svs.KITTI00_HALF_CAM
+    cam_r = tuple(2 * v for v in svs.KITTI00_HALF_CAM) if full_res else svs.KITTI00_HALF_CAM
     d_left = ctx.dev_alloc(S * FB * img)
     d_right = ctx.dev_alloc(S * FB * img)
     seeds = list(rk.stream_seeds(S))
@@ -358,6 +400,81 @@ def main():
                 tot[k] = tot.get(k, 0) + v
         return tot
 
+    # ---- the frame ring: frames [ring["base"], ring["base"] + FB) of every stream are in HBM; ring["next"] is the frame the
+    #      next step of every stream reads.  advance() renders the ring again from that frame on (never inside a timed region).
+    ring = {"base": None, "next": 0}
+
+    def advance():
+        render_block(ring["next"])
+        ring["base"] = ring["next"]
+
+    def ring_left():
+        return 0 if ring["base"] is None else ring["base"] + FB - ring["next"]
+
+    import resource
+
+    # shader clock under load: one wave on a HIP stream of its own spins through (most of) a window and reports the engine
+    # clock it saw (clock64 against the constant 100 MHz counter) — what a window's kernels ran at
+    probe = None
+    if torch.cuda.is_available() and os.environ.get("SVS_BENCH_CLOCK_PROBE", "1") == "1":
+        try:
+            probe = svs.Context(W, H, max_slots=1, max_jobs=1, max_pts=64, max_corners=16, max_kf=0, max_lm=0, max_obs=0, device=local_rank)
+        except Exception:   # noqa: BLE001
+            probe = None
+
+    def with_clock(fn, expect_s):
+        """runs fn() with the clock probe spinning beside it for ~80 % of the expected duration; returns (fn(), MHz or None)"""
+        if probe is None or expect_s <= 0:
+            return fn(), None
+        box = {}
+
+        def spin():
+            try:
+                box["mhz"] = probe.clock_mhz(1, max(1.0, min(2000.0, 800.0 * expect_s)))
+            except Exception:   # noqa: BLE001
+                box["mhz"] = None
+        th_ = threading.Thread(target=spin)
+        th_.start()
+        out_ = fn()
+        th_.join()
+        return out_, (round(box["mhz"], 1) if box.get("mhz") else None)
+
+    def timed(nsteps, want=False, bufs=None, account=None):
+        """`nsteps` steps of every stream, timed.  One block when the ring holds them (re-rendered first if it only holds a part
+        and could hold all), else block by block: every block between barrier + synchronize on both sides, the next block's
+        frames rendered in between, outside the timing.  Returns the summed wall time of the blocks (this rank)."""
+        left, done, t_sum, nblocks = nsteps, 0, 0.0, 0
+        if ring_left() < left and (left <= FB or ring_left() <= 0):
+            advance()
+        while left > 0:
+            if ring_left() <= 0:
+                advance()
+            n = min(ring_left(), left)
+            first = ring["next"] - ring["base"]
+            barrier()
+            if account is not None:
+                ru0 = resource.getrusage(resource.RUSAGE_SELF)
+                tc0 = thread_cpu_seconds()
+            t0 = time.perf_counter()
+            run_all(first, n, want, out_bufs=None if bufs is None else [b_[done:done + n] for b_ in bufs])
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            if account is not None:
+                ru1 = resource.getrusage(resource.RUSAGE_SELF)
+                tc1 = thread_cpu_seconds()
+                account["cpu"] += (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
+                account["minflt"] += ru1.ru_minflt - ru0.ru_minflt
+                for k in tc1:
+                    account["threads"][k] = account["threads"].get(k, 0.0) + tc1[k] - tc0.get(k, 0.0)
+            barrier()
+            t_sum += t1 - t0
+            ring["next"] += n
+            left -= n
+            done += n
+            nblocks += 1
+        return t_sum, nblocks
+
     # ---- pre-roll (untimed): StereoInit of every stream, then frames until the sliding window of
     #      local BA is full everywhere, so that the timed region is the steady-state workload whatever
     #      --warmup / --steps are
@@ -370,17 +487,23 @@ def main():
             if n <= 0:
                 break
             cb = counters_sum()
-            render_block(pre)
+            advance()
             run_all(0, n, False)
+            ring["next"] += n
             pre += n
             ca = counters_sum()
             calls = ca["ba_calls"] - cb["ba_calls"]
             preroll_kf = (ca["ba_kf"] - cb["ba_kf"]) / max(calls, 1)
             if args.preroll < 0 and (preroll_kf >= window_full - 0.05 or pre >= 400):
                 break
-    # ---- warmup, untimed
-    render_block(pre)
-    run_all(0, Wm, False)
+    # ---- warmup, untimed (in the ring block the first timed steps come from)
+    advance()
+    run_all(0, min(Wm, FB - 1), False)
+    ring["next"] += min(Wm, FB - 1)
+    for _ in range(Wm - min(Wm, FB - 1)):          # (a ring shorter than the warm-up: the rest one frame at a time)
+        advance()
+        run_all(0, 1, False)
+        ring["next"] += 1
     c0 = counters_sum()
     for c in ctxs:
         c.timing(True)
@@ -389,83 +512,65 @@ def main():
     res_bufs = [np.zeros((K, Sg), pl.RESULT_DTYPE) for _ in range(G)]
     for b_ in res_bufs:
         b_.view(np.uint8).fill(0)
-    # the K timed steps: one block when the ring holds warmup + steps frames (the default), else block by block — each
-    # block between barrier + synchronize on both sides, the next block's frames rendered outside the timing
-    blocks, first_, left_ = [], Wm, K
-    while left_ > 0:
-        n_ = min(FB - first_, left_)
-        blocks.append((first_, n_))
-        left_ -= n_
-        first_ = 0
-    import resource
     rss0 = int(open("/proc/self/statm").read().split()[1]) * os.sysconf("SC_PAGE_SIZE")
-    t_timed = cpu_timed = 0.0
-    minflt_timed = 0
-    tc_acc = {}
-    done_ = 0
-    for bi, (first_, n_) in enumerate(blocks):
-        if bi > 0:
-            render_block(pre + FB + (bi - 1) * FB)
-        barrier()
-        ru0 = resource.getrusage(resource.RUSAGE_SELF)
-        tc0 = thread_cpu_seconds()
-        t0 = time.perf_counter()
-        run_all(first_, n_, True, out_bufs=[b_[done_:done_ + n_] for b_ in res_bufs])
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        ru1 = resource.getrusage(resource.RUSAGE_SELF)
-        tc1 = thread_cpu_seconds()
-        barrier()
-        t_timed += t1 - t0
-        cpu_timed += (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
-        minflt_timed += ru1.ru_minflt - ru0.ru_minflt
-        for k in tc1:
-            tc_acc[k] = tc_acc.get(k, 0.0) + tc1[k] - tc0.get(k, 0.0)
-        done_ += n_
+    first_timed_frame = ring["next"]
+    acct = {"cpu": 0.0, "minflt": 0, "threads": {}}
+    # ---- the K timed steps (the window the per-family HIP events, the result log and the checks belong to)
+    t_timed, nblocks = timed(K, True, res_bufs, acct)
+    clocks = []
+    blocks_hint = [0] * nblocks      # (the clock probe runs beside single-block windows only: a block boundary renders frames)
+    cpu_timed, minflt_timed, tc_acc = acct["cpu"], acct["minflt"], acct["threads"]
     res_g = res_bufs
     rss1 = int(open("/proc/self/statm").read().split()[1]) * os.sysconf("SC_PAGE_SIZE")
     cpu_by_thread = {k: round(v / max(t_timed, 1e-9), 2) for k, v in tc_acc.items() if v > 0.005 * t_timed}
     cpu_busy = cpu_timed / max(t_timed, 1e-9)
-    t0, t1 = 0.0, t_timed                                # (the code below uses t1 - t0)
     elapsed = rk.max_over_ranks(t_timed)
-    if len(blocks) > 1:                                  # the extra legs assume a ring of warmup + steps frames
-        args.spread_windows = 0
-        args.host_input_steps = 0
     c1 = counters_sum()
     cnt = {k: c1[k] - c0[k] for k in c1}
     fam_t = {}
-    for f in svs.FAMILIES:
+    for f in list(svs.FAMILIES) + list(svs.KERNEL_FAMILIES):
         parts = [c.timing_get(f) for c in ctxs]
         fam_t[f] = (sum(p[0] for p in parts), sum(p[1] for p in parts), sum(p[2] for p in parts))
     for c in ctxs:
         c.timing(False)
-    frame_pos = pre + FB + (len(blocks) - 1) * FB  # next frame of every stream (a multi-block run leaves part of the last ring unused)
 
     # ---- value_spread: further windows of K steps, same process, same operating point (the 0.6-s
-    #      window of the driver's 20 steps scatters by +-10 % from run to run; here is the scatter inside one run)
-    spread = []
+    #      window of the driver's 20 steps scatters by +-10 % from run to run; here is the scatter inside one run).
+    #      Every window also logs how many keyframes (= local-BA problems) fell into it: the windows differ in their work.
+    spread, spread_kf = [], []
     for _ in range(max(0, args.spread_windows)):
-        render_block(frame_pos)
-        barrier()
-        ts0 = time.perf_counter()
-        run_all(0, K, False)
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
-        ts1 = time.perf_counter()
-        barrier()
-        spread.append(S * K * world / rk.max_over_ranks(ts1 - ts0))
-        frame_pos += K
+        ck0 = counters_sum()["keyframes"]
+        (ts, _nb), mhz_ = with_clock(lambda: timed(K), t_timed if len(blocks_hint) == 1 else 0)
+        spread.append(S * K * world / rk.max_over_ranks(ts))
+        spread_kf.append(counters_sum()["keyframes"] - ck0)
+        clocks.append(mhz_)
+
+    # ---- value_super_window: when a window is shorter than a second, super_windows x K steps back to back
+    #      as ONE measurement (with a full-size frame ring it still runs in blocks of at most FB steps, each between barrier +
+    #      synchronize; the time is the sum of the blocks)
+    super_window = None
+    if args.super_windows > 0 and elapsed < 1.0:
+        ck0 = counters_sum()["keyframes"]
+        Ksw = args.super_windows * K
+        ts, nb_sw = timed(Ksw)
+        e_sw = rk.max_over_ranks(ts)
+        super_window = {"value": round(S * Ksw * world / e_sw, 2), "unit": "frames/s", "steps": Ksw, "seconds": round(e_sw, 4),
+                        "ms_per_step": round(1e3 * e_sw / Ksw, 4), "timed_blocks": nb_sw,
+                        "keyframes_per_step": round((counters_sum()["keyframes"] - ck0) / Ksw, 1),
+                        "how": "%d x --steps steps as one measurement directly after the value_spread windows, no HIP events; "
+                               "blocks of at most %d steps (the frame ring), each between barrier + synchronize, time = sum of the blocks" % (args.super_windows, FB)}
 
     # ---- value_host_input: the same step with the frames in pinned host memory (what a host-buffer boundary
     #      hands over): k_pyr_fused reads them across PCIe itself, nothing is staged or copied by the CPU
     host_input = None
-    Kh = max(0, min(args.host_input_steps, FB))
+    # (at most ~14 GB of pinned host memory per eye)
+    Kh = max(0, min(args.host_input_steps, FB, int(14e9 // max(S * img, 1))))
     if world > 1:
         Kh = 0          # a one-GPU figure (PCIe of one device; 2 x 14 GB of pinned host memory per rank): not taken at N > 1
     if Kh > 0:
         try:
-            svs.synth_render_streams_device(seeds, frame_pos, Kh, SW, SH, d_left, d_right, device=local_rank, cam=cam_r)
+            svs.synth_render_streams_device(seeds, ring["next"], Kh, SW, SH, d_left, d_right, device=local_rank, cam=cam_r)
+            ring["base"] = None                      # (the ring's layout is gone: the next leg renders it again)
             hl = torch.empty(S * Kh * img, dtype=torch.uint8, pin_memory=True)
             hr = torch.empty(S * Kh * img, dtype=torch.uint8, pin_memory=True)
             ctx.L.svslam_dev_download(ctx.h, _vp(hl.data_ptr()), _vp(d_left), S * Kh * img)
@@ -480,10 +585,11 @@ def main():
             eh = rk.max_over_ranks(th1 - th0)
             host_input = {"value": round(S * Kh * world / eh, 2), "unit": "frames/s", "steps": Kh,
                           "ms_per_step": round(1e3 * eh / Kh, 4),
-                          "pcie_gbs": round(2 * S * Kh * img / eh / 1e9, 2),
+                          "pcie_gbs": round(2 * S * Kh * (SRC_PIX if full_res else img) / eh / 1e9, 2),
+                          "pcie_bytes_per_frame": 2 * (SRC_PIX if full_res else img),
                           "how": "frames in pinned host memory (torch pin_memory), read by k_pyr_fused over PCIe; "
                                  "no CPU staging copy; same streams, same operating point, directly after the timed region"}
-            frame_pos += Kh
+            ring["next"] += Kh
             del hl, hr
         except Exception as e:   # noqa: BLE001
             host_input = {"error": repr(e)[:300]}
@@ -491,8 +597,8 @@ def main():
     # ---- roofline_solo: group 0 alone on the GPU, so each kernel of its chain runs by itself
     solo = {}
     Ks = max(0, min(args.solo_steps, FB))
-    if Ks > 0 and host_input is not None and "error" not in host_input or Ks > 0 and Kh == 0:
-        render_block(frame_pos)
+    if Ks > 0 and (host_input is None or "error" not in host_input):
+        advance()
         cs0 = pipes[0].counters()
         ctxs[0].timing(True)
         if sep_backend:
@@ -502,7 +608,7 @@ def main():
             torch.cuda.synchronize()
         cs1 = pipes[0].counters()
         cnt_s = {k: cs1[k] - cs0[k] for k in cs1}
-        for f in svs.FAMILIES:
+        for f in list(svs.FAMILIES) + list(svs.KERNEL_FAMILIES):
             parts = [ctxs[0].timing_get(f)] + ([ctxs[G].timing_get(f)] if sep_backend else [])
             fms, fl = sum(p[0] for p in parts), sum(p[1] for p in parts)
             fb_ = algorithmic_bytes(f, cnt_s, fl)
@@ -529,7 +635,7 @@ def main():
                                          np.array_equal(res["n_inliers"][:, 0], res["n_inliers"][:, twin_of_0])))
     ate = []
     for s_ in range(0, S, max(1, S // 16))[:16]:
-        gt = np.array([svs.synth_gt(seeds[s_], pre + Wm + f) for f in range(K)])
+        gt = np.array([svs.synth_gt(seeds[s_], first_timed_frame + f) for f in range(K)])
         ate.append(pl.ate_rmse(res["pose"][:, s_], gt))
     rank_rows = rank_table(rk, sdist, local_rank, pinned, seeds)
     total_frames = S * K * world
@@ -543,22 +649,30 @@ def main():
     ranks_seen = int(round(rk.sum_over_ranks(1.0)))      # an all-reduce of ones over the job's communicator (1 without a process group)
 
     if rank == 0:
-        dom = max(fam_t, key=lambda f: fam_t[f][0])
+        # The dominant KERNEL: the interval with the largest summed HIP-event time among those that enclose one kernel (ba_solve =
+        # k_local_ba_t alone; pyramid, lk, pose_only, triangulate are one kernel each; gftt is two short ones and counted as one).
+        # "local_ba" (gather + build + solver + scatter) is a family of four kernels: priced in roofline_by_family, not here.
+        single = [f for f in fam_t if f != "local_ba"]
+        dom = max(single, key=lambda f: fam_t[f][0])
         ms, launches, _ = fam_t[dom]
         abytes = algorithmic_bytes(dom, cnt, launches)
         avg_s = (ms / 1e3) / max(launches, 1)
         achieved = (abytes / max(launches, 1)) / max(avg_s, 1e-12) / 1e9
+        dom_traffic_fam = "local_ba" if dom == "ba_solve" else dom
         by_fam = {}
         for f, (fms, fl, _) in fam_t.items():
             fb = algorithmic_bytes(f, cnt, fl)
             if fl and fms > 0:
                 by_fam[f] = {"achieved": round(fb / (fms / 1e3) / 1e9, 2), "frac": round(fb / (fms / 1e3) / 1e9 / HBM_PEAK_GBS, 6),
-                             "avg_launch_us": round(1e3 * fms / fl, 2), "launches": fl}
-        all_bytes = sum(algorithmic_bytes(f, cnt, fam_t[f][1]) for f in fam_t)
+                             "avg_launch_us": round(1e3 * fms / fl, 2), "launches": fl, "kernels": svs.FAMILY_KERNELS.get(f),
+                             "algorithmic_bytes_per_launch": round(fb / fl, 1)}
+        all_bytes = sum(algorithmic_bytes(f, cnt, fam_t[f][1]) for f in svs.FAMILIES)
+        build_info = svs.load().svslam_build_info().decode()
+        ctx_xtol = ctx.pose_only_xtol_effective()
         out = {
             "metric": "stereo frames/sec (track + local BA), KITTI-00-shaped synthetic stereo 1241x376 "
                       "(620x188 after the reference's 1/2 decimation)",
-            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "ranks_seen": ranks_seen,
+            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "ranks_seen": ranks_seen, "library": build_info,
             "rank_exchange": "RCCL (torch.distributed nccl): barrier + max-reduction of the elapsed time, no data-path collective"
                              if rk.dist is not None and os.environ.get("SVS_DIST_BACKEND", "nccl") == "nccl" else
                              ("gloo (dry run)" if rk.dist is not None else "none (a single process outside torch.distributed.run)"),
@@ -578,14 +692,16 @@ def main():
                                    "keyframes)" % ("completes before the next frame" if args.backend_mode == 1 else
                                                    "runs beside the next frames like the reference's backend thread, "
                                                    "lands %d frame(s) late, all of it inside the timed region" % max(1, args.backend_lag)),
+                       "frame_ring": "%d frames per stream in HBM (%.1f GB)" % (FB, 2.0 * S * FB * img / 1e9),
                        **({"timed_blocks": "%d blocks of <= %d steps, each between barrier + synchronize; the next block's frames are "
-                                           "rendered into the HBM ring in between, outside the timing" % (len(blocks), FB)} if len(blocks) > 1 else {}),
+                                           "rendered into the HBM ring in between, outside the timing" % (nblocks, FB)} if nblocks > 1 else {}),
                        "map": "host (Frontend/Map/Backend bookkeeping on the CPU)" if cfg.device_map == 0 else
                               "device-resident (svslam_dmap_*: window, features, landmarks, observation counts in HBM; the host keeps ids and poses of the window)",
                        "preroll_steps": pre, "preroll_last_block_ba_keyframes_mean": round(preroll_kf, 2),
-                       "streams_per_gpu": S, "host_threads_per_gpu": G, "bookkeeping_threads_per_group": args.host_threads, "frame": "%dx%d u8 stereo pair" % (W, H) + (" decimated on the fly from %dx%d frames in HBM" % (SW, SH) if args.full_res else ""),
+                       "streams_per_gpu": S, "host_threads_per_gpu": G, "bookkeeping_threads_per_group": args.host_threads, "frame": ("%dx%d u8 stereo pair in HBM, the reference's 1/2 decimation to %dx%d fused into the pyramid kernel" % (SW, SH, W, H)) if full_res else
+                                ("%dx%d u8 stereo pair in HBM (already decimated: the reference's working resolution)" % (W, H)),
                        "keyframes_in_timed_region": cnt["keyframes"],
-                       "pose_only_xtol": float(os.environ.get("SVSLAM_PO_XTOL", "1e-12")),   # svslam_set_pose_only_xtol (0 = g2o's schedule to the last trial)
+                       "pose_only_xtol": ctx_xtol,   # read back from the context (svslam_get_pose_only_xtol; 0 = g2o's schedule to the last trial)
                        "ba_problem_mean": {"keyframes": round(cnt["ba_kf"] / max(cnt["ba_calls"], 1), 1),
                                            "landmarks": round(cnt["ba_lm"] / max(cnt["ba_calls"], 1), 1),
                                            "edges": round(cnt["ba_edges"] / max(cnt["ba_calls"], 1), 1),
@@ -596,13 +712,20 @@ def main():
                                   "ate_rmse_m_mean_of_%d_streams" % len(ate): round(float(np.mean(ate)), 4),
                                   "ate_rmse_m_max": round(float(np.max(ate)), 4)},
                        "parallelism": "%d independent streams/GPU x %d GPU(s), no collective" % (S, world)},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "+".join(svs.FAMILY_KERNELS.get(dom, [dom])), "interval": dom,
+                         "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "peak_measured": HBM_PEAK_MEASURED_GBS, "frac_of_peak_measured": round(achieved / HBM_PEAK_MEASURED_GBS, 6),
-                         "traffic": measured_traffic(dom, cnt, launches),
-                         "traffic_source": "committed PMC pass (profiles/pmc_traffic.json, tools/pmc_traffic.sh), not measured by this run",
+                         "traffic": measured_traffic(dom_traffic_fam, cnt, launches),
+                         "traffic_source": "committed PMC passes (profiles/pmc_traffic.json, tools/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in "
+                                           "separate runs, FETCH_SIZE x 2 on gfx950), not measured by this run"
+                                           + ("; the figure is the whole local_ba family's (gather + build + solver + scatter)" if dom == "ba_solve" else ""),
+                         "traffic_stamp": pmc_stamp("pmc_traffic.json", build_info),
                          "avg_launch_us": round(avg_s * 1e6, 2), "launches": launches,
-                         "algorithmic_bytes_per_launch": round(abytes / max(launches, 1), 1)},
+                         "algorithmic_bytes_per_launch": round(abytes / max(launches, 1), 1),
+                         "how": "HIP events on the launching stream around this kernel only, summed over the first timed window's launches "
+                                "(kernels of the other host threads' streams run beside it); the rocprofv3 --kernel-trace --stats row of the "
+                                "same command is profiles/r6_bench_default_kernel_stats.csv"},
             # every kernel family priced the same way (launches of different groups overlap, so each
             # family's duration is its own HIP-event time, not a share of the wall clock), and the
             # whole step: all algorithmic bytes of the timed region over its wall time
@@ -610,7 +733,12 @@ def main():
             "roofline_compute": {f: compute_side(f, cnt, fam_t[f][0]) for f in ("local_ba", "lk") if fam_t[f][1]},
             "roofline_valu_step": valu_step(cnt, t_timed),
             "roofline_solo": solo,
-            "value_spread": {"windows": [round(v, 1) for v in spread], "steps_each": K,
+            "pmc_stamps": {f: pmc_stamp(f, build_info) for f in ("pmc_traffic.json", "pmc_valu.json", "pmc_valu_step.json")},
+            "value_super_window": super_window,
+            "value_spread": {"windows": [round(v, 1) for v in spread], "keyframes": spread_kf, "keyframes_first_window": cnt["keyframes"], "steps_each": K,
+                             "shader_clock_mhz": clocks,
+                             "hip_events": "only the first window records the per-family HIP events (pyramid, lk, gftt, triangulate, pose_only, local_ba, "
+                                           "ba_solve) and writes the per-frame result log; the spread windows and the super-window record none",
                              "min": round(min(spread), 1) if spread else None, "max": round(max(spread), 1) if spread else None,
                              "mean": round(float(np.mean(spread)), 1) if spread else None,
                              "rel_std": round(float(np.std(spread) / np.mean(spread)), 4) if spread else None,
@@ -641,21 +769,22 @@ def main():
                                 effective_cpus())
             out["cpu_baseline"] = base["one_thread"]
             out["cpu_baseline_all_cores"] = base["all_cores"]
-    run_full_res = rank == 0 and world == 1 and args.full_res_streams > 0 and not args.full_res
-    if run_full_res:
+    run_secondary = rank == 0 and world == 1 and args.secondary_streams > 0 and full_res
+    if run_secondary:
         ctx.dev_free(d_left); ctx.dev_free(d_right)     # (before the contexts go: the leg below needs the memory)
     for p in pipes:
         p.close()
+    if probe is not None:
+        probe.close()
     if rank == 0:
-        # ---- value_full_res: BASELINE.json's metric names 1241x376 frames; the reported run keeps the frames in HBM already
-        #      decimated (the reference's working resolution).  This leg stores them at full size and fuses the decimation
-        #      (src/dataset.cpp:126-129) into the pyramid's level 0: the same hot path plus the 4x larger frame read.
-        if run_full_res:
+        # ---- value_predecimated: rounds 1-5 reported the run whose frames are stored in HBM already decimated (620x188: what the
+        #      reference's Frontend::AddFrame sees) as `value`; since round 6 `value` is the 1241x376 configuration
+        #      BASELINE.json's metric names and the pre-decimated run is this named secondary (more streams fit: 12288).
+        if run_secondary:
             import subprocess
-            # (at most 20 + 5 steps: a full-size frame ring of 8192 streams then fits the GPU's memory)
-            cmd = [sys.executable, os.path.abspath(__file__), "--full-res", "--streams", str(args.full_res_streams), "--steps", str(min(K, 20)),
-                   "--warmup", str(min(Wm, 5)), "--no-cpu-baseline", "--spread-windows", "0", "--host-input-steps", "0", "--solo-steps", "0",
-                   "--full-res-streams", "0"]
+            cmd = [sys.executable, os.path.abspath(__file__), "--pre-decimated", "--streams", str(args.secondary_streams), "--steps", str(K),
+                   "--warmup", str(Wm), "--no-cpu-baseline", "--spread-windows", "2", "--super-windows", "0", "--host-input-steps", "0", "--solo-steps", "0",
+                   "--predecimated-streams", "0"]
             # the child is a single process of its own: it must not join the parent's rendezvous
             env = {k: v for k, v in os.environ.items()
                    if not (k.startswith("TORCHELASTIC_") or k.startswith("MASTER_") or k.startswith("TORCH_NCCL") or
@@ -666,14 +795,15 @@ def main():
                 if r.returncode != 0 or not r.stdout.strip():
                     raise RuntimeError("child rc %d: %s" % (r.returncode, (r.stderr or "").strip()[-200:]))
                 d = json.loads(r.stdout.strip().splitlines()[-1])
-                out["value_full_res"] = {"value": d["value"], "unit": "frames/s", "streams": d["config"]["streams_per_gpu"], "steps": d["steps"],
-                                         "ms_per_step": d["ms_per_step"], "frame": d["config"]["frame"],
-                                         "checks": d["config"]["checks"],
-                                         "how": "the same script run once more after the reported measurement: frames kept in HBM at "
-                                                "1241x376, 1/2 decimation fused into the pyramid kernel (SURVEY 8 row f3); fewer streams "
-                                                "and at most 20 + 5 steps because a frame is 4x the bytes"}
+                out["value_predecimated"] = {"value": d["value"], "unit": "frames/s", "streams": d["config"]["streams_per_gpu"], "steps": d["steps"],
+                                             "ms_per_step": d["ms_per_step"], "frame": d["config"]["frame"], "value_windows": d["value_windows"],
+                                             "roofline": d["roofline"], "kernel_ms": d["kernel_ms"],
+                                             "checks": d["config"]["checks"],
+                                             "how": "the same script run once more after the reported measurement with --pre-decimated: frames "
+                                                    "kept in HBM at 620x188 (a quarter of the frame bytes, so 12288 streams fit); what rounds "
+                                                    "1-5 reported as `value`"}
             except Exception as e:   # noqa: BLE001
-                out["value_full_res"] = {"error": repr(e)[:300]}
+                out["value_predecimated"] = {"error": repr(e)[:300]}
         print(json.dumps(out), flush=True)
     rk.close()
 
@@ -705,15 +835,37 @@ def dry_run(args):
     S, K, Wm = (args.streams if args.streams > 0 else 16), args.steps, args.warmup
     seeds = list(rk.stream_seeds(S))
     step_s = 1e-3 * (1 + rk.rank % 3)
-    for _ in range(Wm):
-        time.sleep(step_s)
+    # the host layout of a real rank: G group threads, each waiting for "its GPU work" the way the library waits for a HIP
+    # stream (sleep-polling, csrc/svslam_hip.hip wait_stream), + this thread.  What the dry run checks about it:
+    # N ranks x (G + 1) threads on one node do not oversubscribe the CPUs a rank may use — the threads sleep, they do not spin.
+    import resource
+    import threading
+    G = args.groups if args.groups > 0 else 4
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(rk.world)))
+    cpus_per_rank = effective_cpus() / max(1, local_world)
+
+    def steps(n):
+        def group():
+            for _ in range(n):
+                t_end = time.perf_counter() + step_s
+                while time.perf_counter() < t_end:          # poll every ~150 us like wait_stream's nap
+                    time.sleep(min(150e-6, max(0.0, t_end - time.perf_counter())))
+        th = [threading.Thread(target=group) for _ in range(G)]
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+    steps(Wm)
     rk.barrier()
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
-    for _ in range(K):
-        time.sleep(step_s)
+    steps(K)
     t1 = time.perf_counter()
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
     rk.barrier()
     elapsed = rk.max_over_ranks(t1 - t0)
+    busy = ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / max(t1 - t0, 1e-9)
+    busy_max = rk.max_over_ranks(busy)
     ranks_seen = int(round(rk.sum_over_ranks(1.0)))
     rows = rank_table(rk, sdist, rk.local_rank, set(), seeds)
     if rk.rank == 0:
@@ -724,6 +876,13 @@ def dry_run(args):
             "rank_exchange": "gloo (dry run)" if rk.dist is not None else "none (a single process outside torch.distributed.run)",
             "ranks": rows, "steps": K, "warmup": Wm, "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "none (dry run: no kernel ran)", "data": "none (dry run)",
+            "host": {"threads_per_rank": G + 1, "ranks_on_node": local_world, "cpus_allowed": effective_cpus(),
+                     "cpus_per_rank": round(cpus_per_rank, 2), "cpu_cores_busy_per_rank_max": round(busy_max, 3),
+                     # measured on the GPU box at the headline operating point (bench.py host_ms_per_step.cpus_busy, profiles/r6_bench_default.json)
+                     "product_cpu_cores_busy_per_rank": 0.6,
+                     "oversubscribed": bool(busy_max > cpus_per_rank or 0.6 > cpus_per_rank),
+                     "how": "every rank runs %d group threads that wait the way the library waits for a HIP stream (sleep-polling) + the main "
+                            "thread; busy = CPU seconds / wall seconds of the timed steps, max over ranks" % G},
             "config": {"workload": "dry run of the launch contract: a rank-dependent sleep per step, no GPU work",
                        "streams_per_gpu": S, "parallelism": "%d independent streams/GPU x %d rank(s), no collective" % (S, rk.world)}}),
               flush=True)

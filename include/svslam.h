@@ -109,6 +109,9 @@ int svslam_set_low_latency(svslam_ctx *ctx, int on);
  * xtol = 0: g2o's schedule to the last trial.  0 <= xtol <= 1e-6.  Local BA is not touched: its ten iterations all move
  * the window.                                                                                                           */
 int svslam_set_pose_only_xtol(svslam_ctx *ctx, double xtol);
+/* the tolerance the context actually uses (the default, svslam_set_pose_only_xtol or the SVSLAM_PO_XTOL environment variable
+ * read by svslam_create — which fails on a value outside [0, 1e-6] instead of ignoring it); -1 for a null context */
+double svslam_get_pose_only_xtol(const svslam_ctx *ctx);
 /* test hook: read one level back (tight rows of *w bytes) */
 int svslam_pyramid_read(svslam_ctx *ctx, int slot, int level, uint8_t *out,
                         int *w, int *h);

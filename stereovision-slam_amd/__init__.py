@@ -18,7 +18,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 
 ABI_SYMBOLS = [
     "svslam_create", "svslam_destroy", "svslam_last_error", "svslam_build_info",
-    "svslam_pyramid_batch", "svslam_pyramid_decimate_batch", "svslam_set_source_size", "svslam_set_low_latency", "svslam_set_pose_only_xtol", "svslam_pyramid_read",
+    "svslam_pyramid_batch", "svslam_pyramid_decimate_batch", "svslam_set_source_size", "svslam_set_low_latency", "svslam_set_pose_only_xtol", "svslam_get_pose_only_xtol", "svslam_pyramid_read",
     "svslam_pyramid_read_padded", "svslam_lk_batch", "svslam_gftt_batch", "svslam_gftt_eigmap", "svslam_triangulate_batch",
     "svslam_pose_only_batch", "svslam_local_ba_batch", "svslam_local_ba_submit", "svslam_local_ba_collect",
     "svslam_track_batch", "svslam_rtrack_batch", "svslam_rtrack_upload",
@@ -31,6 +31,13 @@ ABI_SYMBOLS = [
 
 FAMILIES = {"pyramid": 0, "lk": 1, "gftt": 2, "triangulate": 3, "pose_only": 4, "local_ba": 5}
 DEBUG_FAMILIES = {"dbg0": 6, "dbg1": 7, "dbg2": 8, "dbg3": 9}     # per-kernel split (SVSLAM_TIMING_SPLIT=1), development
+# intervals nested inside a family: the local-BA solver kernel alone (k_local_ba_t<0, 1, EID>, or the low-latency solver's kernels)
+# inside "local_ba" (= map gather + structure build + solver + scatter)
+KERNEL_FAMILIES = {"ba_solve": 10}
+# the HIP kernel(s) behind each timing family at the batch operating point (what a rocprofv3 --kernel-trace --stats row is named)
+FAMILY_KERNELS = {"pyramid": ["k_pyr_fused"], "lk": ["k_lk"], "gftt": ["k_gftt_eig3", "k_gftt_select2"], "triangulate": ["k_triangulate"],
+                  "pose_only": ["k_pose_only"], "local_ba": ["k_dmap_ba_gather", "k_ba_build", "k_local_ba_t", "k_dmap_ba_scatter"],
+                  "ba_solve": ["k_local_ba_t"]}
 
 
 class Limits(C.Structure):
@@ -104,6 +111,8 @@ def load():
         L.svslam_destroy.argtypes = [C.c_void_p]
         L.svslam_destroy.restype = None
         L.svslam_set_pose_only_xtol.argtypes = [C.c_void_p, C.c_double]
+        L.svslam_get_pose_only_xtol.argtypes = [C.c_void_p]
+        L.svslam_get_pose_only_xtol.restype = C.c_double
         L.svslam_dev_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         L.svslam_dev_free.argtypes = [C.c_void_p, C.c_void_p]
         L.svslam_dev_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
@@ -191,6 +200,12 @@ class Context:
         self._chk(self.L.svslam_sync(self.h), "sync")
 
     # ---- timing ----------------------------------------------------------
+    def clock_mhz(self, blocks=1, ms=1.0):
+        """effective shader clock seen by a wave that spins for `ms` of the constant 100 MHz counter (svslam_debug_clock_mhz)"""
+        mhz = C.c_double(0)
+        self._chk(self.L.svslam_debug_clock_mhz(self.h, blocks, C.c_double(ms), C.byref(mhz)), "debug_clock_mhz")
+        return mhz.value
+
     def host_counters(self):
         """test hook (svslam_debug_host_ns): 8 host-side counters since the last call; [6] = local-BA problems the
         low-latency solver took"""
@@ -214,13 +229,17 @@ class Context:
         """parameter tolerance of the pose-only LM (svslam_set_pose_only_xtol); 0 = g2o's schedule to the last trial"""
         self._chk(self.L.svslam_set_pose_only_xtol(self.h, C.c_double(xtol)), "set_pose_only_xtol")
 
+    def pose_only_xtol_effective(self):
+        """the tolerance the context uses (svslam_get_pose_only_xtol)"""
+        return float(self.L.svslam_get_pose_only_xtol(self.h))
+
     def timing(self, on=True):
         self.L.svslam_timing_enable(self.h, 1 if on else 0)
         self.L.svslam_timing_reset(self.h)
 
     def timing_get(self, family):
         ms, n, u = C.c_double(), C.c_longlong(), C.c_longlong()
-        fam = FAMILIES[family] if family in FAMILIES else DEBUG_FAMILIES[family]
+        fam = FAMILIES[family] if family in FAMILIES else (KERNEL_FAMILIES[family] if family in KERNEL_FAMILIES else DEBUG_FAMILIES[family])
         self._chk(self.L.svslam_timing_get(self.h, fam, C.byref(ms), C.byref(n), C.byref(u)), "timing")
         return ms.value, n.value, u.value
 

@@ -51,12 +51,25 @@ def _run(cmd, verbose):
     subprocess.check_call(cmd)
 
 
+def source_hash():
+    """sha256 (first 12 hex digits) over the sources and flags libsvslam_hip.so is compiled from: svslam_build_info() carries
+    it, the PMC summaries under profiles/ are stamped with it and bench.py says whether the stamp is the loaded library's"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(_sources(CSRC, (".hip", ".h")) + [os.path.join(ROOT, "include", "svslam.h")]):
+        h.update(os.path.relpath(f, ROOT).encode())
+        h.update(open(f, "rb").read())
+    h.update(" ".join(HIP_FLAGS).encode())
+    return h.hexdigest()[:12]
+
+
 def build_hip(force=False, verbose=False):
     os.makedirs(LIB, exist_ok=True)
     out = os.path.join(LIB, "libsvslam_hip.so")
     srcs = _sources(CSRC, (".hip", ".h")) + [os.path.join(ROOT, "include", "svslam.h")]
     if force or _newer(out, srcs):
-        _run([HIPCC] + HIP_FLAGS + [os.path.join(CSRC, "svslam_hip.hip"), os.path.join(CSRC, "synth.hip"),
+        _run([HIPCC] + HIP_FLAGS + ['-DSVS_SRC_HASH="%s"' % source_hash(),
+                                     os.path.join(CSRC, "svslam_hip.hip"), os.path.join(CSRC, "synth.hip"),
                                      "-o", out], verbose)
     return out
 

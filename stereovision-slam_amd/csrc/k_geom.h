@@ -408,6 +408,10 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
             if (r == 2) { robust = false; same_as_prev = false; }
             continue;
         }
+        // no trial of THIS round has been evaluated yet: a round that ends before its first trial (the parameter tolerance at
+        // it == 0) classifies its active edges at the errors g2o's computeActiveErrors() took at the start estimate T0, not at
+        // the previous round's last trial pose
+        have_eval = false;
 #pragma unroll
         for (int i = 0; i < 7; ++i) T[i] = T0[i];
         int nact = 0;
@@ -569,6 +573,9 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int i = 0; i < 7; ++i) Te[i] = s_Te[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) Te[i] = T[i];          // (T is the round's start estimate then)
         }
         po_pose_table(T, RtT); po_pose_table(Te, RtE);
 #pragma unroll
@@ -579,7 +586,7 @@ k_pose_only(PoseJob *jobs, const double *cam4, const double *xyz, const float2 *
             edge(s, Pq, mu_, mv_);
             // an outlier of this round: its error at the round's result; an active edge: at the last evaluated trial
             if (was) po_error(cam, RtT, Pq, mu_, mv_, ea, eb);
-            else if (have_eval) po_error(cam, RtE, Pq, mu_, mv_, ea, eb);
+            else po_error(cam, RtE, Pq, mu_, mv_, ea, eb);
             double chi2 = ea * ea + eb * eb;
             const bool now = chi2 > chi2_th;
             co += (now ? 1 : 0) + (now != was ? 1 << 16 : 0);           // outliers | flags changed << 16 (<= 512 edges)

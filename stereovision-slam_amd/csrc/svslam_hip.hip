@@ -48,7 +48,9 @@ typedef enum { ncclDouble = 8 } ncclDataType_t;
 
 namespace {
 
-enum { FAM_PYR = 0, FAM_LK, FAM_GFTT, FAM_TRI, FAM_POSE, FAM_BA, FAM_DBG0, FAM_DBG1, FAM_DBG2, FAM_DBG3, FAM_COUNT };
+enum { FAM_PYR = 0, FAM_LK, FAM_GFTT, FAM_TRI, FAM_POSE, FAM_BA, FAM_DBG0, FAM_DBG1, FAM_DBG2, FAM_DBG3,
+       FAM_BA_SOLVE,   // the local-BA solver kernel(s) alone, nested inside FAM_BA (gather + build + solve + scatter)
+       FAM_COUNT };
 
 struct Timing {
     double ms[FAM_COUNT] = { 0 };
@@ -147,6 +149,7 @@ struct svslam_ctx {
     Timing tm;
     hipEvent_t ev[2 * 8];
     int nev = 0;
+    int ev_open[4]; int ev_depth = 0;   // event pairs begun and not yet ended (an interval may nest inside another)
     int ev_fam[8];
     long long ev_units[8];
 };
@@ -194,18 +197,24 @@ void make_geom(PyrGeom &g, int w, int h)
     g.slot_bytes = off;
 }
 
+// HIP-event intervals of a call, on the stream the kernels are launched on.  Intervals may nest (the solver kernel inside the
+// local-BA family): tm_end closes the innermost open one.  At most 8 intervals per call; beyond that they are not recorded.
 void tm_begin(svslam_ctx *c, int fam, long long units)
 {
-    if (!c->timing || c->nev >= 8) return;
-    c->ev_fam[c->nev] = fam;
-    c->ev_units[c->nev] = units;
-    (void)hipEventRecord(c->ev[2 * c->nev], c->stream);
+    if (!c->timing) return;
+    if (c->nev >= 8 || c->ev_depth >= 4) { if (c->ev_depth < 4) c->ev_open[c->ev_depth] = -1; c->ev_depth++; return; }
+    const int slot = c->nev++;
+    c->ev_open[c->ev_depth++] = slot;
+    c->ev_fam[slot] = fam;
+    c->ev_units[slot] = units;
+    (void)hipEventRecord(c->ev[2 * slot], c->stream);
 }
 void tm_end(svslam_ctx *c)
 {
-    if (!c->timing || c->nev >= 8) return;
-    (void)hipEventRecord(c->ev[2 * c->nev + 1], c->stream);
-    c->nev++;
+    if (!c->timing || c->ev_depth <= 0) return;
+    const int d = --c->ev_depth;
+    const int slot = d < 4 ? c->ev_open[d] : -1;
+    if (slot >= 0) (void)hipEventRecord(c->ev[2 * slot + 1], c->stream);
 }
 // pose-only LM: one wave per job by default, four when the context is in low-latency mode
 void launch_pose_only(svslam_ctx *c, int njobs, PoseJob *jobs, const double *cam, const double *xyz, const float2 *uv,
@@ -232,7 +241,7 @@ void tm_collect(svslam_ctx *c)
             c->tm.units[c->ev_fam[i]] += c->ev_units[i];
         }
     }
-    c->nev = 0;
+    c->nev = 0; c->ev_depth = 0;
 }
 
 // both extrinsics are pure translations: quaternion exactly (0, 0, 0, 1)
@@ -274,8 +283,10 @@ int ba_ll_tile_cap(const svslam_ctx *c)
 }
 void launch_ba_solver(svslam_ctx *c, int njobs, bool ll, BaDev *jobs, const BaCams *cams, double *poses, double *pts, const unsigned int *packed,
                       const float2 *uv, const int *srt, BaRec *recs, int *aux, double *chi, int *flag, int max_nlm, int max_nobs,
-                      double delta, int iters, bool split_timing)
+                      double delta, int iters, bool split_timing, bool time_solver = true)
 {
+    // (time_solver: FAM_BA_SOLVE interval around the solver kernel(s); off where the solve runs on a stream the call does not wait for)
+    const bool tms = time_solver && !split_timing;
     const int tile_cap = ll ? ba_ll_tile_cap(c) : ba_tile_cap(c->lim.max_kf);
     const int ec = bb_edge_cache_fits(max_nlm, max_nobs) ? 1 : 0;
     if (!ll) {
@@ -283,12 +294,14 @@ void launch_ba_solver(svslam_ctx *c, int njobs, bool ll, BaDev *jobs, const BaCa
                            tile_cap, max_nlm, flag, 0, ec, 0);
         if (split_timing) { tm_end(c); tm_begin(c, FAM_DBG3, njobs); }
         const SbaArgs sa{ 0, 0, 0.0, nullptr, c->d_lm_trace, 0, nullptr, nullptr, nullptr, 0 };
+        if (tms) tm_begin(c, FAM_BA_SOLVE, njobs);
         if (c->ba_eid)
             hipLaunchKernelGGL((k_local_ba_t<0, 1, true>), dim3(njobs), dim3(BA_THREADS), ba_lds_bytes(c->lim.max_kf), c->stream, jobs, cams, poses, pts, recs, aux,
                                c->bw, delta, iters, chi, c->d_ba_prof, tile_cap, sa);
         else
             hipLaunchKernelGGL((k_local_ba_t<0, 1, false>), dim3(njobs), dim3(BA_THREADS), ba_lds_bytes(c->lim.max_kf), c->stream, jobs, cams, poses, pts, recs, aux,
                                c->bw, delta, iters, chi, c->d_ba_prof, tile_cap, sa);
+        if (tms) tm_end(c);
         return;
     }
     const int W = c->ll.w;
@@ -300,6 +313,7 @@ void launch_ba_solver(svslam_ctx *c, int njobs, bool ll, BaDev *jobs, const BaCa
     if (split_timing) { tm_end(c); tm_begin(c, FAM_DBG3, njobs); }
     if (c->ll.test_drop > 0) { --c->ll.test_drop; hipLaunchKernelGGL(k_ll_test_drop, dim3(1), dim3(1), 0, c->stream, c->ll.shards); }
     // problems whose shards all fit LDS: the resident kernel; the others: the streaming one (each kernel skips the other's)
+    if (tms) tm_begin(c, FAM_BA_SOLVE, njobs);
     if (c->ll.caps.B > 0) {
         if (W == 4) launch_ba_ll_resident<4>(c, njobs * W, c->ll.shards, cams, poses, pts, recs, aux, delta, iters, chi, jobs);
         else if (W == 8) launch_ba_ll_resident<8>(c, njobs * W, c->ll.shards, cams, poses, pts, recs, aux, delta, iters, chi, jobs);
@@ -308,7 +322,7 @@ void launch_ba_solver(svslam_ctx *c, int njobs, bool ll, BaDev *jobs, const BaCa
     if (W == 4) launch_ba_ll_t<4>(c, njobs * W, c->ll.shards, cams, poses, pts, recs, aux, delta, iters, chi, tile_cap, jobs);
     else if (W == 16) launch_ba_ll_t<16>(c, njobs * W, c->ll.shards, cams, poses, pts, recs, aux, delta, iters, chi, tile_cap, jobs);
     else if (W == 8) launch_ba_ll_t<8>(c, njobs * W, c->ll.shards, cams, poses, pts, recs, aux, delta, iters, chi, tile_cap, jobs);
-    else return;
+    if (tms) tm_end(c);
 }
 
 inline long long now_ns()
@@ -520,7 +534,10 @@ extern "C" {
 
 const char *svslam_build_info(void)
 {
-    return "libsvslam_hip gfx950 (hipcc " __VERSION__ "), -ffp-contract=off";
+#ifndef SVS_SRC_HASH
+#define SVS_SRC_HASH "unstamped"
+#endif
+    return "libsvslam_hip gfx950 (hipcc " __VERSION__ "), -ffp-contract=off, src " SVS_SRC_HASH;
 }
 
 const char *svslam_last_error(const svslam_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
@@ -550,7 +567,12 @@ int svslam_create(const svslam_limits *lim, svslam_ctx **out)
         c->wait_poll = !(wm && (std::strcmp(wm, "spin") == 0 || std::strcmp(wm, "block") == 0));
         c->wait_block = wm && std::strcmp(wm, "block") == 0;
         c->timing_split = std::getenv("SVSLAM_TIMING_SPLIT") != nullptr;
-        if (const char *xt = std::getenv("SVSLAM_PO_XTOL")) { const double v = atof(xt); if (v >= 0 && v <= 1e-6) c->po_xtol = v; }   // 0: g2o's schedule
+        if (const char *xt = std::getenv("SVSLAM_PO_XTOL")) {      // 0: g2o's schedule; a value the setter would refuse fails the create
+            char *end = nullptr;
+            const double v = strtod(xt, &end);
+            if (end == xt || !(v >= 0) || v > 1e-6) return fail(c, "svslam_create: SVSLAM_PO_XTOL=%s is outside [0, 1e-6]", xt);
+            c->po_xtol = v;
+        }
         // the device build takes the edge indices packed into one word (landmark < 2^16, keyframe < 2^8)
         c->ba_host_build = std::getenv("SVSLAM_BA_HOST_BUILD") != nullptr || lim->max_lm >= 65536 || lim->max_kf >= 256;
     }
@@ -772,6 +794,8 @@ static void ll_release(svslam_ctx *c)
     c->ll.shards = nullptr; c->ll.xch = nullptr; c->ll.cnt = nullptr; c->ll.w = 0; c->ll.max_problems = 0;
 }
 
+double svslam_get_pose_only_xtol(const svslam_ctx *c) { return c ? c->po_xtol : -1.0; }
+
 int svslam_set_pose_only_xtol(svslam_ctx *c, double xtol)
 {
     if (!(xtol >= 0) || xtol > 1e-6) return fail(c, "svslam_set_pose_only_xtol: 0 <= xtol <= 1e-6 (got %g)", xtol);
@@ -812,10 +836,14 @@ int svslam_set_low_latency(svslam_ctx *c, int on)
             if (const char *ec = std::getenv("SVSLAM_LL_CUS")) { const int v = atoi(ec); if (v > 0) cus = std::min(cus, v); }
             int maxp = 0, per_cu = 0;
             for (; w >= 4; w /= 2) {
+                // every kernel a launch at this shard count may use: both extrinsic instantiations of the resident solver have their
+                // own register count (the reference's rig launches <W, true>), the streaming solver has one
                 const void *fr = w == 4 ? reinterpret_cast<const void *>(k_ba_ll<4, false>) : w == 8 ? reinterpret_cast<const void *>(k_ba_ll<8, false>) : reinterpret_cast<const void *>(k_ba_ll<16, false>);
+                const void *fe = w == 4 ? reinterpret_cast<const void *>(k_ba_ll<4, true>) : w == 8 ? reinterpret_cast<const void *>(k_ba_ll<8, true>) : reinterpret_cast<const void *>(k_ba_ll<16, true>);
                 const void *fs = w == 4 ? reinterpret_cast<const void *>(k_local_ba_t<2, 4>) : w == 8 ? reinterpret_cast<const void *>(k_local_ba_t<2, 8>) : reinterpret_cast<const void *>(k_local_ba_t<2, 16>);
                 int blocks = ll_resident_blocks(fs, ba_lds_bytes_ll(c->lim.max_kf), cus);
-                if (caps.B > 0) blocks = std::min(blocks, ll_resident_blocks(fr, ba_ll_lds_bytes(c->lim.max_kf, caps), cus));
+                if (caps.B > 0)
+                    for (const void *f : { fr, fe }) blocks = std::min(blocks, ll_resident_blocks(f, ba_ll_lds_bytes(c->lim.max_kf, caps), cus));
                 per_cu = cus > 0 ? blocks / cus : 0;
                 maxp = std::min(SVSLAM_LL_MAX_PROBLEMS, blocks / w);
                 if (maxp >= 1) break;
@@ -1315,29 +1343,41 @@ int svslam_local_ba_collect(svslam_ctx *c, int njobs, svslam_ba_job *jobs, int t
     if (const int fl = hp<int>(c, c->ba_pending.oflag)[0])
         return fail(c, "local_ba: the device structure build overflowed a capacity (code %d)", fl);
     const BaDev *dj = hp<BaDev>(c, c->ba_pending.ojobs);
-    bool gave_up = false;
-    for (int i = 0; i < njobs; ++i) gave_up = gave_up || dj[i].iters_done < 0;
-    if (gave_up) {
-        // a shard of the low-latency solver never became resident; the problems' inputs are untouched in the device arena
-        // (a problem that gives up writes nothing back): the whole batch once more with one workgroup per problem
+    std::vector<int> bad;
+    for (int i = 0; i < njobs; ++i) if (dj[i].iters_done < 0) bad.push_back(i);
+    std::vector<BaDev> res(dj, dj + njobs);        // descriptors as the first solve returned them
+    if (!bad.empty()) {
+        // a shard of the low-latency solver never became resident.  A problem that gives up writes nothing back, so ITS inputs are
+        // untouched in the device arena; the problems that finished have their results there already (poses and positions are
+        // updated in place) and must not be solved a second time (20 LM iterations instead of the reference's 10).
+        // Only the problems that gave up go to the batch solver — one workgroup per problem, no barrier — as a compacted list:
+        // every descriptor carries its own offsets into the arena.
         if (!c->ba_pending.ll_used || (int)c->ll.saved.size() != njobs) return fail(c, "local_ba: a problem reports iters_done < 0 outside the low-latency solver");
         const auto &bp = c->ba_pending;
-        memcpy(hp<void>(c, bp.ojobs), c->ll.saved.data(), sizeof(BaDev) * (size_t)njobs);
+        const int nb = (int)bad.size();
+        BaDev *hj = hp<BaDev>(c, bp.ojobs);
+        int max_nlm = 1, max_nobs = 1;
+        for (int k = 0; k < nb; ++k) {
+            hj[k] = c->ll.saved[(size_t)bad[(size_t)k]];
+            max_nlm = std::max(max_nlm, hj[k].nlm); max_nobs = std::max(max_nobs, hj[k].nobs);
+        }
         hp<int>(c, bp.oflag)[0] = 0;
-        if (h2d(c, bp.ojobs, bp.ojobs + sizeof(BaDev) * (size_t)njobs)) return -1;
+        if (h2d(c, bp.ojobs, bp.ojobs + sizeof(BaDev) * (size_t)nb)) return -1;
         if (h2d(c, bp.oflag, bp.oflag + sizeof(int) * 4)) return -1;
-        launch_ba_solver(c, njobs, false, dp<BaDev>(c, bp.ojobs), dp<BaCams>(c, bp.ocams), dp<double>(c, bp.oposes), dp<double>(c, bp.opts),
+        launch_ba_solver(c, nb, false, dp<BaDev>(c, bp.ojobs), dp<BaCams>(c, bp.ocams), dp<double>(c, bp.oposes), dp<double>(c, bp.opts),
                          dp<unsigned int>(c, bp.opk), dp<float2>(c, bp.ouv), dp<int>(c, bp.osrt), dp<BaRec>(c, bp.orecs), dp<int>(c, bp.oaux),
-                         dp<double>(c, bp.ochi), dp<int>(c, bp.oflag), bp.max_nlm, bp.max_nobs, bp.delta, bp.iters, false);
+                         dp<double>(c, bp.ochi), dp<int>(c, bp.oflag), max_nlm, max_nobs, bp.delta, bp.iters, false);
         HIPCHK(c, hipGetLastError());
         if (d2h_sync(c, bp.ojobs, bp.out_end)) return -1;
         if (const int fl = hp<int>(c, bp.oflag)[0]) return fail(c, "local_ba: the device structure build overflowed a capacity (code %d)", fl);
-        c->ll.fallbacks += njobs;
+        for (int k = 0; k < nb; ++k) res[(size_t)bad[(size_t)k]] = dj[k];
+        c->ll.fallbacks += nb;
     }
     for (int i = 0; i < njobs; ++i) {
-        if (dj[i].iters_done < 0) return fail(c, "local_ba: job %d reports iters_done < 0 from the batch solver", i);
-        jobs[i].iters_done = dj[i].iters_done;
-        jobs[i].reserved = (int)(((unsigned)std::min(dj[i].ntrial, 255) << 24) | ((unsigned)dj[i].ncontrib & 0x00ffffffu));   // accounting (svslam.h)
+        const BaDev &d = res[(size_t)i];
+        if (d.iters_done < 0) return fail(c, "local_ba: job %d reports iters_done < 0 from the batch solver", i);
+        jobs[i].iters_done = d.iters_done;
+        jobs[i].reserved = (int)(((unsigned)std::min(d.ntrial, 255) << 24) | ((unsigned)d.ncontrib & 0x00ffffffu));   // accounting (svslam.h)
     }
     if (total_kf > 0) memcpy(poses, hp<void>(c, c->ba_pending.oposes), sizeof(double) * 7 * total_kf);
     if (total_lm > 0) memcpy(pts, hp<void>(c, c->ba_pending.opts), sizeof(double) * 3 * total_lm);
@@ -1853,7 +1893,7 @@ static int dmap_keyframe_impl(svslam_ctx *c, int njobs, svslam_dmap_job *jobs, c
         }
         launch_ba_solver(c, njobs, use_ll, b_bd, b_cams, b_poses, b_pts, reinterpret_cast<unsigned int *>(bp_(opk)),
                          reinterpret_cast<float2 *>(bp_(ouv)), b_ref /* order: identity, not read */, reinterpret_cast<BaRec *>(bp_(orecs)),
-                         reinterpret_cast<int *>(bp_(oaux)), b_chi, reinterpret_cast<int *>(bp_(oflag)), NL, MO, p->chi2_th, p->ba_iters, false);
+                         reinterpret_cast<int *>(bp_(oaux)), b_chi, reinterpret_cast<int *>(bp_(oflag)), NL, MO, p->chi2_th, p->ba_iters, false, !defer);
         if (defer) {
             (void)hipEventRecord(c->dmba.t1, c->stream);
             const hipError_t rec_rc = hipEventRecord(c->dmba.solved, c->stream);

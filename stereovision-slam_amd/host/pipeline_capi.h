@@ -70,6 +70,13 @@ int svs_pipe_run_device(void *p, const void *left_base, const void *right_base, 
 int svs_pipe_counters_get(void *p, svs_pipe_counters *out);
 /* keyframes.txt + landmarks.pcd of one stream, in the reference's formats (src/visual_odometry.cpp:198-310) */
 int svs_pipe_save_outputs(void *p, int stream, const char *dir, const char *dataset_dir, int left_cam_index);
+/* Inspection hook (host map only): the map of one stream as it stands after the last step, flat.
+ *   ints: n_active_keyframes, (keyframe id)*, n_active_landmarks, per landmark { id, observed_times, n_obs,
+ *         (keyframe id, 0 left / 1 right, index of the feature in that keyframe's list)* }  — ids ascending, observations in list order
+ *   dbl:  7 per active keyframe (pose, T_cw), then 3 per active landmark (position)
+ * Returns the number of ints the snapshot has (nothing is written when cap_i or cap_d is too small: call again), -1 for a bad
+ * stream, -2 when the map lives on the device (svslam_dmap_read is the reader there), -3 when a BA in flight cannot be completed. */
+long long svs_pipe_map_snapshot(void *p, int stream, long long *ints, long long cap_i, double *dbl, long long cap_d);
 /* underlying svslam_ctx (product build) or NULL (CPU twin) */
 void *svs_pipe_kernel_ctx(void *p);
 /* context the backend's local BA runs on: a second one when backend_on == 2, else the same */

@@ -157,6 +157,35 @@ int svs_pipe_save_outputs(void *p, int stream, const char *dir, const char *data
     return h->pipe->SaveOutputs(stream, dir, dataset_dir, left_cam_index) ? 0 : -2;
 }
 
+long long svs_pipe_map_snapshot(void *p, int stream, long long *ints, long long cap_i, double *dbl, long long cap_d)
+{
+    PipeHandle *h = static_cast<PipeHandle *>(p);
+    if (stream < 0 || stream >= h->pipe->nstreams()) return -1;
+    if (!h->pipe->map_on_host()) return -2;
+    if (svs_pipe_flush(p)) return -3;
+    const svs::Map &m = h->pipe->stream(stream).map;
+    long long ni = 2 + (long long)m.active_keyframes_.size(), nd = 7 * (long long)m.active_keyframes_.size() + 3 * (long long)m.active_landmarks_.size();
+    for (const svs::MapPoint *mp : m.active_landmarks_) ni += 3 + 3 * (long long)mp->observations.size();
+    if (ni > cap_i || nd > cap_d || !ints || !dbl) return ni;
+    long long *o = ints;
+    double *d = dbl;
+    *o++ = (long long)m.active_keyframes_.size();
+    for (const svs::Frame *kf : m.active_keyframes_) {
+        *o++ = kf->keyframe_id;
+        std::memcpy(d, kf->pose.v, sizeof(double) * 7); d += 7;
+    }
+    *o++ = (long long)m.active_landmarks_.size();
+    for (const svs::MapPoint *mp : m.active_landmarks_) {
+        *o++ = mp->id; *o++ = mp->observed_times; *o++ = (long long)mp->observations.size();
+        for (size_t i = 0; i < mp->observations.size(); ++i) {
+            const svs::ObsRef &r = mp->observations[i];
+            *o++ = r.frame->keyframe_id; *o++ = r.is_left ? 0 : 1; *o++ = r.idx;
+        }
+        std::memcpy(d, mp->pos, sizeof(double) * 3); d += 3;
+    }
+    return ni;
+}
+
 int svs_pipe_counters_get(void *p, svs_pipe_counters *out)
 {
     const svs::Counters &c = static_cast<PipeHandle *>(p)->pipe->counters();

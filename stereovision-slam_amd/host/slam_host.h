@@ -421,6 +421,7 @@ public:
     int nstreams() const { return (int)streams_.size(); }
     const Counters &counters() const { return cnt_; }
     Stream &stream(int s) { return *streams_[s]; }
+    bool map_on_host() const { return !(cfg_.device_map && cfg_.resident_track); }   // (svs_pipe_map_snapshot)
 
     // Frontend::AddFrame for every stream (src/frontend.cpp:690-721), in lockstep.
     // left/right: one image pointer per stream (host or device memory).
@@ -440,7 +441,7 @@ public:
             st.is_new_kf = false; st.init_ok = false;
             std::swap(st.slot_prev, st.slot_cur);   // last frame's pyramid becomes "prev"
             if (st.status == FrontendStatus::INITING) IS.push_back(s);
-            else if (st.status == FrontendStatus::LOST) { /* Reset(): not implemented upstream */ }
+            else if (st.status == FrontendStatus::LOST) { st.dev_feat = 0; /* Reset(): not implemented upstream (:723-731); the frame gets no features */ }
             else TS.push_back(s);
         }
         cnt_.frames += S;

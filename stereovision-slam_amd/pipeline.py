@@ -94,6 +94,8 @@ def _bind(L):
     L.svs_pipe_counters_get.argtypes = [C.c_void_p, C.POINTER(Counters)]
     L.svs_pipe_save_outputs.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int]
     L.svs_pipe_flush.argtypes = [C.c_void_p]
+    L.svs_pipe_map_snapshot.restype = C.c_longlong
+    L.svs_pipe_map_snapshot.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong]
     L.svs_pipe_tune_allocator.restype = None
     L.svs_pipe_backend_ctx.restype = C.c_void_p
     L.svs_pipe_backend_ctx.argtypes = [C.c_void_p]
@@ -182,6 +184,28 @@ class Pipeline:
         rc = self.L.svs_pipe_save_outputs(self.h, stream, out_dir.encode(), dataset_dir.encode(), left_cam_index)
         if rc != 0:
             raise RuntimeError("svs_pipe_save_outputs failed (%d)" % rc)
+
+    def map_snapshot(self, stream=0):
+        """the host map of one stream after the last step (svs_pipe_map_snapshot): active keyframe ids and poses, active landmarks
+        with position, observation counter and observation list [(keyframe id, 0 left / 1 right, feature index)]"""
+        ni = self.L.svs_pipe_map_snapshot(self.h, stream, None, 0, None, 0)
+        if ni < 0:
+            raise RuntimeError("svs_pipe_map_snapshot: %d (-2: the map of this pipeline lives on the device)" % ni)
+        ints = np.zeros(ni, np.int64)
+        dbl = np.zeros(7 * ni, np.float64)
+        if self.L.svs_pipe_map_snapshot(self.h, stream, ints.ctypes.data_as(C.c_void_p), ni, dbl.ctypes.data_as(C.c_void_p), dbl.size) != ni:
+            raise RuntimeError("svs_pipe_map_snapshot changed size between two calls")
+        o = d = 0
+        nk = int(ints[o]); o += 1
+        kf = [int(v) for v in ints[o:o + nk]]; o += nk
+        poses = {k: dbl[d + 7 * i:d + 7 * i + 7].copy() for i, k in enumerate(kf)}; d += 7 * nk
+        nl = int(ints[o]); o += 1
+        lms = []
+        for _ in range(nl):
+            mid, times, no = (int(v) for v in ints[o:o + 3]); o += 3
+            obs = tuple((int(ints[o + 3 * i]), int(ints[o + 3 * i + 1]), int(ints[o + 3 * i + 2])) for i in range(no)); o += 3 * no
+            lms.append((mid, times, obs, tuple(float(v) for v in dbl[d:d + 3]))); d += 3
+        return {"active_keyframes": kf, "landmarks": lms, "keyframe_poses": poses}
 
     def kernel_ctx(self):
         return self.L.svs_pipe_kernel_ctx(self.h)

@@ -305,6 +305,13 @@ def test_bench_launch_contract_dry_run_over_gloo(world):
     assert seeds == set(range(0x5EED0000, 0x5EED0000 + S * world))     # disjoint and complete: global stream ids 0 .. S * world - 1
     assert 3.0 <= d["ms_per_step"] < 12.0                     # the 3-ms ranks set the time (max over ranks), not the 1-ms ones
     assert d["value"] == pytest.approx(S * K * world / (d["ms_per_step"] * 1e-3 * K), rel=1e-3)
+    # 8 ranks x (4 group threads + 1) on this node: the waiting threads sleep, so a rank needs less than the CPUs it may use
+    # (cpus_allowed / ranks — one CPU per rank in the 8-CPU build container)
+    h = d["host"]
+    assert h["threads_per_rank"] == 5 and h["ranks_on_node"] == world
+    assert h["cpus_per_rank"] == pytest.approx(h["cpus_allowed"] / world, abs=0.01)
+    assert h["cpu_cores_busy_per_rank_max"] <= h["cpus_per_rank"] and h["product_cpu_cores_busy_per_rank"] <= h["cpus_per_rank"], h
+    assert h["oversubscribed"] is False
 
 
 def test_numa_pinning_helpers_degrade_gracefully():

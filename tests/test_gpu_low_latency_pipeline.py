@@ -187,3 +187,40 @@ def test_a_shard_that_never_arrives_costs_a_repeat_not_the_call(svs, monkeypatch
     assert outs[0][3] == batch[3]
     for a, b in zip(outs[1][:2], batch[:2]):    # and the low-latency solver agrees with it to rounding
         assert np.allclose(np.asarray(a), np.asarray(b), atol=1e-6)
+
+
+def test_only_the_problem_that_gave_up_is_repeated(svs, monkeypatch):
+    """two problems in one low-latency call of the flat ABI, shard 0 of problem 0 never runs.  Problem 0 comes back
+    with the batch solver's bits, problem 1 — which finished, and whose results are already in the device arena the repeat
+    reads its inputs from — keeps the low-latency solver's bits (it is NOT optimised a second time), one fallback is counted."""
+    import common
+    rng = np.random.default_rng(11)
+    jobs = []
+    for nkf, nlm in ((8, 400), (7, 300)):
+        pr = common.make_ba_problem(rng, nkf=nkf, nlm=nlm)
+        o = np.lexsort((pr["okf"], pr["olm"]))
+        jobs.append((pr["poses0"], pr["pts0"], pr["okf"][o], pr["olm"][o], pr["ori"][o], pr["ouv"][o]))
+    mk = lambda: svs.Context(W, H, max_slots=1, max_jobs=2, max_kf=11, max_lm=2048, max_obs=16384)
+    args = (common.CAM, common.EXT_L, common.CAM, common.EXT_R, 5.991, 10)
+    outs = {}
+    for drop in (1, 0):
+        if drop:
+            monkeypatch.setenv("SVSLAM_LL_TEST_DROP_SHARD", "1")
+        ctx = mk()
+        ctx.low_latency(True)
+        if drop:
+            monkeypatch.delenv("SVSLAM_LL_TEST_DROP_SHARD")
+        ctx.host_counters()
+        outs[drop] = ctx.local_ba(jobs, *args)
+        hc = ctx.host_counters()
+        assert (hc[6], hc[7]) == ((2, 1) if drop else (2, 0)), hc
+        ctx.close()
+    ctx = mk()
+    batch = ctx.local_ba(jobs, *args)
+    ctx.close()
+    for a, b in zip(outs[1][0][:3], batch[0][:3]):      # problem 0: the batch solver's result, bit for bit
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+    assert outs[1][0][3] == batch[0][3]
+    for a, b in zip(outs[1][1][:3], outs[0][1][:3]):    # problem 1: untouched by the repeat
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+    assert outs[1][1][3] == outs[0][1][3] == 10

@@ -3,7 +3,8 @@ export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out/pmc_lk; rm -rf $O; mkdir -p $O
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_SCA" \
            "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_LDS" \
-           "SQ_WAVE_CYCLES SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_WAVES"; do
+           "SQ_WAVE_CYCLES SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_WAVES" \
+           "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   timeout 180 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/p$i -- env LKBENCH_MC=30 python tools/kbench.py lk > $O/p$i.log 2>&1
   f=$(find $O/p$i -name "*counter_collection.csv" | head -1)

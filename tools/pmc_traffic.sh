@@ -2,13 +2,15 @@
 # HBM-side traffic per kernel from two PMC passes (FETCH_SIZE, WRITE_SIZE separately: they do not fit one
 # pass) over a bench run; aggregated per kernel name -> gpurun_out/pmc_traffic_raw.json.
 # PMC_BENCH_ARGS chooses the operating point: default the small one of round 2 (256 streams, 1 group); round 3 also
-# runs the headline one: PMC_BENCH_ARGS="--steps 20 --warmup 5" (12288 streams x 12 groups)
+# runs the headline one: PMC_BENCH_ARGS="--steps 20 --warmup 5" (round 6: 8192 streams x 4 groups, 1241x376 frames in HBM).
+# Also writes gpurun_out/pmc_traffic.json in the layout bench.py reads from profiles/pmc_traffic.json, stamped with
+# svslam_build_info() of the library that was measured (bench.py compares the stamp with the library it loads).
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 for ctr in FETCH_SIZE WRITE_SIZE; do
   O=gpurun_out/pmc_$ctr; rm -rf "$O"; mkdir -p "$O"
-  timeout ${PMC_TIMEOUT:-400} rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$O" -- python bench.py ${PMC_BENCH_ARGS:---streams 256 --groups 1 --host-threads 4 --steps 30 --warmup 5 --preroll 100} --no-cpu-baseline --spread-windows 0 --host-input-steps 0 --solo-steps 0 > gpurun_out/pmc_${ctr}_bench.json 2> gpurun_out/pmc_${ctr}.err < /dev/null
+  timeout ${PMC_TIMEOUT:-400} rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$O" -- python bench.py ${PMC_BENCH_ARGS:---streams 256 --groups 1 --host-threads 4 --steps 30 --warmup 5 --preroll 100} --no-cpu-baseline --spread-windows 0 --super-windows 0 --host-input-steps 0 --solo-steps 0 --predecimated-streams 0 > gpurun_out/pmc_${ctr}_bench.json 2> gpurun_out/pmc_${ctr}.err < /dev/null
 done
 python - <<'PY'
 import csv, glob, json, collections, re
@@ -51,6 +53,18 @@ try:
 except Exception as e:
     out["per_unit"] = "unavailable: %r" % (e,)
 json.dump(out, open("gpurun_out/pmc_traffic_raw.json", "w"), indent=1)
+if isinstance(out.get("per_unit"), dict):
+    line = json.loads(open("gpurun_out/pmc_FETCH_SIZE_bench.json").read().strip().splitlines()[-1])
+    pub = {"_comment": "HBM-side traffic per unit of work from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs, "
+                       "--kernel-trace only) over one bench.py run, summed per kernel over the whole process and divided by the unit counts "
+                       "of the whole process the bench line reports (units_whole_process).  KB -> bytes x 1024.  fetch_bytes = 2 x the raw "
+                       "counter: on gfx950 FETCH_SIZE reports half of the bytes read for every access width (tools/pmc_calib.sh, "
+                       "profiles/r2_pmc_calibration.txt; WRITE_SIZE 1.000 x).  Under a PMC pass rocprofv3 serialises the kernels: every launch "
+                       "is measured alone on the chip at the bench's own batch shapes.  Written by tools/pmc_traffic.sh.",
+           "build_info": line.get("library"),
+           "operating_point": {k: line["config"].get(k) for k in ("streams_per_gpu", "host_threads_per_gpu", "frame", "frame_ring")}}
+    pub.update(out["per_unit"])
+    json.dump(pub, open("gpurun_out/pmc_traffic.json", "w"), indent=1)
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     print(ctr, {k: v["KB_per_launch"] for k, v in out[ctr].items()})
 print("per unit", out["per_unit"])
