@@ -274,3 +274,37 @@ def test_pipeline_config2_hip_frontend_with_cpu_backend(svs):
         gt = np.array([svs.synth_gt(sd, f) for f in range(N)])
         assert abs(pl.ate_rmse(eh[:, k], gt) - pl.ate_rmse(ec[:, k], gt)) < 1e-2
     hyb.close(); cpu.close()
+
+
+@pytest.mark.parametrize("device_map", [0, 1])
+def test_hip_pipeline_meets_the_second_reading_of_the_glue(svs, device_map):
+    """tests/golden/glue_second_reading.npz holds what tests/ref_glue.py — the plain-Python restatement of the reference's
+    Frontend / Map / MapPoint / Backend glue, written from /root/reference alone — reports and holds after
+    every frame of two seeded streams.  The HIP pipeline must meet it: the first frames exactly (status, keyframe flag, feature and
+    inlier counts, ids; with the map on the host also the active window, the landmark count, the observation total and the
+    checksum of every observation list), poses to LM tolerance; later frames up to the flipped outlier bits of
+    test_pipeline_matches_cpu_twin."""
+    import glue_scenarios as gs
+    pl = importlib.import_module("stereovision-slam_amd.pipeline")
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "glue_second_reading.npz"))
+    N = g["status"].shape[1]
+    keys = ("status", "is_keyframe", "n_features", "n_inliers", "frame_id", "keyframe_id")
+    for si, seed in enumerate(int(v) for v in g["seeds"]):
+        pipe = pl.Pipeline(pl.default_config(device_map=device_map), nstreams=1)
+        mism = 0
+        for f, (left, right) in enumerate(gs.frames(seed, "plain", N)):
+            r = pipe.step([left], [right])[0]
+            for k in keys:
+                same = int(r[k]) == int(g[k][si, f])
+                assert same or f >= 10, (hex(seed), f, k, int(r[k]), int(g[k][si, f]))
+                mism += 0 if same else 1
+            tol_t, tol_q = (5e-4, 5e-5) if f < 10 else (5e-2, 5e-3)
+            assert np.allclose(r["pose"][4:], g["pose"][si, f, 4:], atol=tol_t) and np.allclose(r["pose"][:4], g["pose"][si, f, :4], atol=tol_q), (hex(seed), f)
+            assert int(r["status"]) == int(g["status"][si, f])
+            if device_map == 0 and f < 10:
+                kf, nlm, nobs, crc = gs.map_digest(pipe.map_snapshot(0))
+                assert kf == [int(v) for v in g["window"][si, f] if v >= 0], (hex(seed), f, kf)
+                assert (nlm, nobs, crc) == (int(g["n_landmarks"][si, f]), int(g["n_observations"][si, f]), int(g["map_crc32"][si, f])), (hex(seed), f)
+        print("second-reading fixture, seed %d, device_map %d: %d of %d metadata values differ after frame 10" % (seed, device_map, mism, N * len(keys)))
+        assert mism <= 0.1 * N * len(keys)
+        pipe.close()
