@@ -419,6 +419,11 @@ int svslam_debug_ll_shards(svslam_ctx *ctx, int nproblems, int *out8, int *shard
  * problems one call may hand to it, CUs counted, co-resident solver workgroups per CU                                      */
 int svslam_debug_ll_limits(svslam_ctx *ctx, int *out4);
 int svslam_debug_clock_mhz(svslam_ctx *ctx, int blocks, double ms, double *mhz);
+/* test hook: `ncus` workgroups that each take one CU's whole LDS and spin for `ms` milliseconds, enqueued on the context's stream
+ * (asynchronous; svslam_sync waits): those CUs cannot take a workgroup that needs LDS meanwhile — the situation in which the
+ * low-latency local BA of ANOTHER context finds only some of its shards resident, gives up after SVSLAM_LL_TIMEOUT_US (2 ms)
+ * and is repeated by the batch solver                                                                                        */
+int svslam_debug_hold_cus(svslam_ctx *ctx, int ncus, double ms);
 
 /* ---- device memory helpers for HBM-resident inputs (bench, pipelining) --- */
 int svslam_dev_alloc(svslam_ctx *ctx, size_t bytes, void **out);

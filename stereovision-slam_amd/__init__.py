@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "svslam_device_count", "svslam_dmap_keyframe_batch", "svslam_dmap_ba_collect", "svslam_dmap_read", "svslam_dmap_evicted", "svslam_sba_comm_unique_id", "svslam_sba_comm_init", "svslam_sba_comm_destroy", "svslam_sba_solve",
     "svslam_dev_alloc", "svslam_dev_free", "svslam_dev_upload", "svslam_dev_download", "svslam_sync",
     "svslam_timing_enable", "svslam_timing_reset", "svslam_timing_get", "svslam_ba_profile",
-    "svslam_set_host_threads", "svslam_debug_host_ns", "svslam_debug_ll_shards", "svslam_debug_ll_limits", "svslam_debug_clock_mhz", "svslam_lm_trace",
+    "svslam_set_host_threads", "svslam_debug_host_ns", "svslam_debug_ll_shards", "svslam_debug_ll_limits", "svslam_debug_clock_mhz", "svslam_debug_hold_cus", "svslam_lm_trace",
 ]
 
 FAMILIES = {"pyramid": 0, "lk": 1, "gftt": 2, "triangulate": 3, "pose_only": 4, "local_ba": 5}
@@ -200,6 +200,16 @@ class Context:
         self._chk(self.L.svslam_sync(self.h), "sync")
 
     # ---- timing ----------------------------------------------------------
+    def ll_limits(self):
+        """test hook (svslam_debug_ll_limits): [shards per problem, problems per call, CUs counted, solver workgroups per CU]"""
+        o = (C.c_int * 4)()
+        self._chk(self.L.svslam_debug_ll_limits(self.h, o), "debug_ll_limits")
+        return [int(v) for v in o]
+
+    def hold_cus(self, ncus, ms):
+        """test hook (svslam_debug_hold_cus): ncus workgroups take a CU's LDS each and spin for ms; asynchronous"""
+        self._chk(self.L.svslam_debug_hold_cus(self.h, int(ncus), C.c_double(ms)), "debug_hold_cus")
+
     def clock_mhz(self, blocks=1, ms=1.0):
         """effective shader clock seen by a wave that spins for `ms` of the constant 100 MHz counter (svslam_debug_clock_mhz)"""
         mhz = C.c_double(0)

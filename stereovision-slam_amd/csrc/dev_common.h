@@ -3,8 +3,18 @@
 // integer/f32 paths (pyramids, LK, GFTT) are bit-exact against the declared
 // operation order of the oracle, so no FMA contraction is allowed.
 #pragma once
+// The f64 LM code opts into FMA contraction through this macro.  -DSVS_NO_CONTRACT (parity debugging, tests/ate_bias.py)
+// builds it without: no contraction, and the explicit __builtin_fma calls become a multiplication and an addition.
+#ifdef SVS_NO_CONTRACT
+#define SVS_CONTRACT_FAST _Pragma("clang fp contract(off)")
+#else
+#define SVS_CONTRACT_FAST _Pragma("clang fp contract(fast)")
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#ifdef SVS_NO_CONTRACT
+#define __builtin_fma(a, b, c) ((a) * (b) + (c))      // (after the runtime's headers: only this library's kernels)
+#endif
 
 #define SVS_WAVE 64
 #define SVS_BORDER 16          // stored REFLECT_101 border of every pyramid level
@@ -160,7 +170,7 @@ __device__ __forceinline__ void d_project_exact(const double *T, const double *K
 // The f64 geometry below is compared to the oracle at a stated tolerance, not bit for bit,
 // so FMA contraction is allowed for it (halves the f64 op count); the integer / f32 code
 // above and in k_pyramid/k_lk/k_gftt stays strictly un-contracted.
-#pragma clang fp contract(fast)
+SVS_CONTRACT_FAST
 // ---- SE(3), Sophus layout qx qy qz qw tx ty tz (mirrors oracle/orc_geom.c) ----
 __device__ __forceinline__ void d_quat_rot(const double *q, const double *v, double *o)
 {

@@ -34,7 +34,7 @@
 #include <cstring>
 
 // f64 LM algebra, compared with the oracle at stated tolerances: FMA contraction allowed
-#pragma clang fp contract(fast)
+SVS_CONTRACT_FAST
 
 #ifndef BA_THREADS
 #define BA_THREADS 512
@@ -882,7 +882,8 @@ __device__ __forceinline__ int ba_chol_solve(double *S, const int ld, const int 
 //   scalars: 0 chi2, 1 landmark diagonal max, 2 cholesky ok, 3 scale (landmarks), 4 scale (poses), 5 chi2 of the trial
 struct SbaArgs { int phase, first; double lambda; double *io; double *trace; int add_lambda;      // trace: svslam_lm_trace test hook (MODE 0 / 2);
                                                                    // add_lambda: phase 3 adds lambda I to the reduced system itself (svslam_sba_solve)
-                 double *xch; unsigned int *cnt; BaDev *parents; size_t xch_stride; };   // MODE 2 (low latency): exchange area, arrival counters, the problems
+                 double *xch; unsigned int *cnt; BaDev *parents; size_t xch_stride;     // MODE 2 (low latency): exchange area, arrival counters, the problems
+                 long long ll_timeout; };   // MODE 2: a shard that waits longer than this at one exchange (ticks of the 100 MHz wall clock) gives the problem up
 #define SBA_IO_DOUBLES(np) ((size_t)(np) * (np) + 3 * (size_t)(np) + 8)
 
 // Low-latency BA (MODE 2): ONE problem over LLW workgroups.  The phase cut is the shared-map one (MODE 1) — a shard holds all K
@@ -900,7 +901,9 @@ struct SbaArgs { int phase, first; double lambda; double *io; double *trace; int
 // loads (`sc1`: served past the CU's L1), so no release / acquire fence is needed.  A buffer written before sync X is next
 // written after the following sync Y, which nobody passes before everyone has read: A and B protect each other's buffers.
 // All shards of a problem must be resident (the host keeps problems x LLW far below the CU count); a shard that waits longer
-// than ~1 s sets the problem's abort word, every shard then returns with iters_done = -1.
+// than SbaArgs::ll_timeout at ONE exchange (round 6: a wall-clock limit, 2 ms by default — an exchange takes microseconds when
+// the shards are resident; rounds 4-5 counted ~2 M polls, about a second) sets the problem's abort word, every shard then
+// returns with iters_done = -1 and the host repeats the problem with the batch solver.
 #define LL_SLAB(np) ((size_t)(np) * (np) + 2 * (size_t)(np))      // lower triangle of S in an np x np frame | bs | bp
 #define LL_X0(np) ((size_t)(np) + 2)                              // diag(Hpp) | landmark diagonal max | chi2
 #define LL_XB 4                                                   // chi2 of the trial | rho denominator (landmarks)
@@ -1063,10 +1066,11 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
             const unsigned target = ll_n * ll_ep;
             unsigned spins = 0;
             int good = 1;
+            const long long t_wait0 = wall_clock64();
             while (__hip_atomic_load(ll_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
                 __builtin_amdgcn_s_sleep(2);
-                if ((++spins & 1023u) == 0 &&
-                    (spins > (1u << 21) || __hip_atomic_load(ll_cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                if ((++spins & 63u) == 0 &&
+                    (wall_clock64() - t_wait0 > sba.ll_timeout || __hip_atomic_load(ll_cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
                     __hip_atomic_store(ll_cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     good = 0;
                     break;
@@ -1647,12 +1651,13 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                     unsigned long long x = 0;
                     unsigned spins = 0;
                     int good = 1;
+                    const long long t_wait0 = wall_clock64();
                     for (;;) {
                         if (mineg) x = __hip_atomic_load(gran + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (__all(!mineg || (unsigned)(x >> 32) == ll_epb)) break;
                         __builtin_amdgcn_s_sleep(1);
-                        if ((++spins & 1023u) == 0 &&
-                            (spins > (1u << 21) || __hip_atomic_load(ll_cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                        if ((++spins & 63u) == 0 &&
+                            (wall_clock64() - t_wait0 > sba.ll_timeout || __hip_atomic_load(ll_cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
                             __hip_atomic_store(ll_cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             good = 0;
                             break;

@@ -18,7 +18,7 @@
 #pragma once
 #include "k_ba.h"
 
-#pragma clang fp contract(fast)
+SVS_CONTRACT_FAST
 
 struct LlCaps { int B, L, E; };      // blocks, landmarks, edges of a shard that the resident layout holds
 
@@ -118,10 +118,11 @@ k_ba_ll(BaDev *shards, const BaCams *camsp, double *poses_all, double *pts_all, 
             const unsigned target = ll_n * ll_ep;
             unsigned spins = 0;
             int good = 1;
+            const long long t_wait0 = wall_clock64();
             while (__hip_atomic_load(ll_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
                 __builtin_amdgcn_s_sleep(1);
-                if ((++spins & 1023u) == 0 &&
-                    (spins > (1u << 21) || __hip_atomic_load(ll_cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                if ((++spins & 63u) == 0 &&
+                    (wall_clock64() - t_wait0 > sba.ll_timeout || __hip_atomic_load(ll_cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
                     __hip_atomic_store(ll_cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     good = 0;
                     break;
@@ -461,12 +462,13 @@ k_ba_ll(BaDev *shards, const BaCams *camsp, double *poses_all, double *pts_all, 
                     unsigned long long x = 0;
                     unsigned spins = 0;
                     int good = 1;
+                    const long long t_wait0 = wall_clock64();
                     for (;;) {
                         if (mineg) x = __hip_atomic_load(gran + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (__all(!mineg || (unsigned)(x >> 32) == ll_epb)) break;
                         __builtin_amdgcn_s_sleep(1);
-                        if ((++spins & 1023u) == 0 &&
-                            (spins > (1u << 21) || __hip_atomic_load(ll_cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                        if ((++spins & 63u) == 0 &&
+                            (wall_clock64() - t_wait0 > sba.ll_timeout || __hip_atomic_load(ll_cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
                             __hip_atomic_store(ll_cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             good = 0;
                             break;

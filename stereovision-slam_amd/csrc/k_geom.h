@@ -9,7 +9,7 @@
 #include "dev_common.h"
 #include "k_rt.h"
 // f64 LM kernels: tolerance-level parity, FMA contraction allowed (see dev_common.h)
-#pragma clang fp contract(fast)
+SVS_CONTRACT_FAST
 
 // ------------------------------------------------------------------ triangulation
 struct TriJob { int pt_ofs, npts; double T_wc[7]; double zmax; };
@@ -76,7 +76,7 @@ __device__ inline void d_svd4_jacobi(double *A, double *V, double *sv)
     }
 }
 
-#pragma clang fp contract(fast)
+SVS_CONTRACT_FAST
 
 __global__ void __launch_bounds__(64)
 k_triangulate(const TriJob *jobs, TriCams cams, const float2 *uv_l, const float2 *uv_r,

@@ -15,6 +15,7 @@
 #include <sys/prctl.h>
 #include <new>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include <dlfcn.h>
@@ -106,6 +107,9 @@ struct svslam_ctx {
              // problems take the batch solver.  A shard that still never arrives (the CUs were taken by something else) makes
              // the problem give up after ~1 s; the call then solves it again with the batch solver (fallbacks counts those).
              int max_problems = 0, cus = 0, blocks_per_cu = 0; bool force_batch = false; int test_drop = 0; long long fallbacks = 0;
+             // round 6: the give-up is a wall-clock limit per exchange (SVSLAM_LL_TIMEOUT_US, default 2000 us; 100 MHz ticks here);
+             // coop: the two solver kernels go through hipLaunchCooperativeKernel (SVSLAM_LL_COOP=1; DESIGN 4.3 has the A/B)
+             long long timeout_ticks = 200000; bool coop = false; long long coop_refused = 0;
              std::vector<BaDev> saved; } ll;
     double *d_lm_trace = nullptr;            // svslam_lm_trace test hook: [max_jobs][LM_TRACE_STRIDE]
     // host-side wall time (ns): 0 h2d enqueue, 1 d2h enqueue, 2 stream wait, 3 launches, 4 staging memcpy/prep
@@ -253,23 +257,40 @@ static bool ba_ext_identity(const double *ext_l, const double *ext_r)
 }
 // The local-BA solver of a batch whose structure the device builds: the batch kernel (one workgroup per problem), or — in
 // low-latency mode, for a few problems with landmark-major edges — every problem dealt over ll.w workgroups.
+// A solver kernel of the low-latency path: an ordinary launch, or — ll.coop — a cooperative one: the runtime then checks that the
+// whole grid can be resident at once (and refuses the launch otherwise: counted, the ordinary launch + the in-kernel give-up
+// take over) and runs cooperative launches of different streams one after the other, so two half-resident problems of two
+// contexts cannot wait for each other's CUs.
+template <class... P, class... A> void ll_launch(svslam_ctx *c, void (*kern)(P...), int nshards, size_t lds, A... a)
+{
+    if (c->ll.coop) {
+        std::tuple<P...> args(a...);
+        void *ptrs[sizeof...(P)];
+        size_t i = 0;
+        std::apply([&](auto &...x) { ((ptrs[i++] = (void *)&x), ...); }, args);
+        if (hipLaunchCooperativeKernel(reinterpret_cast<const void *>(kern), dim3(nshards), dim3(BA_THREADS), ptrs, (unsigned)lds, c->stream) == hipSuccess) return;
+        (void)hipGetLastError();
+        c->ll.coop_refused++;
+    }
+    hipLaunchKernelGGL(kern, dim3(nshards), dim3(BA_THREADS), lds, c->stream, a...);
+}
 template <int W> void launch_ba_ll_t(svslam_ctx *c, int nshards, BaDev *shards, const BaCams *cams, double *poses, double *pts, const BaRec *recs,
                                       const int *aux, double delta, int iters, double *chi, int tile_cap, BaDev *parents)
 {
-    hipLaunchKernelGGL((k_local_ba_t<2, W>), dim3(nshards), dim3(BA_THREADS), ba_lds_bytes_ll(c->lim.max_kf), c->stream, shards, cams, poses, pts,
-                       recs, aux, c->ll.bw, delta, iters, chi, c->d_ba_prof, tile_cap,
-                       SbaArgs{ 0, 0, 0.0, nullptr, c->d_lm_trace, 0, c->ll.xch, c->ll.cnt, parents, c->ll.xch_stride });
+    ll_launch(c, k_local_ba_t<2, W>, nshards, ba_lds_bytes_ll(c->lim.max_kf), shards, cams, poses, pts, recs, aux, c->ll.bw, delta, iters, chi,
+              c->d_ba_prof, tile_cap,
+              SbaArgs{ 0, 0, 0.0, nullptr, c->d_lm_trace, 0, c->ll.xch, c->ll.cnt, parents, c->ll.xch_stride, c->ll.timeout_ticks });
 }
 template <int W> void launch_ba_ll_resident(svslam_ctx *c, int nshards, BaDev *shards, const BaCams *cams, double *poses, double *pts, const BaRec *recs,
                                             const int *aux, double delta, int iters, double *chi, BaDev *parents)
 {
-    const SbaArgs sa{ 0, 0, 0.0, nullptr, c->d_lm_trace, 0, c->ll.xch, c->ll.cnt, parents, c->ll.xch_stride };
+    const SbaArgs sa{ 0, 0, 0.0, nullptr, c->d_lm_trace, 0, c->ll.xch, c->ll.cnt, parents, c->ll.xch_stride, c->ll.timeout_ticks };
     if (c->ba_eid)
-        hipLaunchKernelGGL((k_ba_ll<W, true>), dim3(nshards), dim3(BA_THREADS), ba_ll_lds_bytes(c->lim.max_kf, c->ll.caps), c->stream, shards, cams, poses, pts,
-                           recs, aux, delta, iters, chi, c->d_ba_prof, c->ll.caps, sa);
+        ll_launch(c, k_ba_ll<W, true>, nshards, ba_ll_lds_bytes(c->lim.max_kf, c->ll.caps), shards, cams, poses, pts, recs, aux, delta, iters, chi,
+                  c->d_ba_prof, c->ll.caps, sa);
     else
-        hipLaunchKernelGGL((k_ba_ll<W, false>), dim3(nshards), dim3(BA_THREADS), ba_ll_lds_bytes(c->lim.max_kf, c->ll.caps), c->stream, shards, cams, poses, pts,
-                           recs, aux, delta, iters, chi, c->d_ba_prof, c->ll.caps, sa);
+        ll_launch(c, k_ba_ll<W, false>, nshards, ba_ll_lds_bytes(c->lim.max_kf, c->ll.caps), shards, cams, poses, pts, recs, aux, delta, iters, chi,
+                  c->d_ba_prof, c->ll.caps, sa);
 }
 // test hook (SVSLAM_LL_TEST_DROP_SHARD = n: the next n low-latency launches): shard 0 of problem 0 never runs, its peers give up at
 // their first exchange and the call falls back to the batch solver — the path a GPU without room for every shard takes
@@ -293,7 +314,7 @@ void launch_ba_solver(svslam_ctx *c, int njobs, bool ll, BaDev *jobs, const BaCa
         hipLaunchKernelGGL(k_ba_build, dim3(njobs), dim3(BB_THREADS), bb_lds_bytes(max_nlm, max_nobs), c->stream, jobs, packed, uv, srt, recs, aux,
                            tile_cap, max_nlm, flag, 0, ec, 0);
         if (split_timing) { tm_end(c); tm_begin(c, FAM_DBG3, njobs); }
-        const SbaArgs sa{ 0, 0, 0.0, nullptr, c->d_lm_trace, 0, nullptr, nullptr, nullptr, 0 };
+        const SbaArgs sa{ 0, 0, 0.0, nullptr, c->d_lm_trace, 0, nullptr, nullptr, nullptr, 0, 0 };
         if (tms) tm_begin(c, FAM_BA_SOLVE, njobs);
         if (c->ba_eid)
             hipLaunchKernelGGL((k_local_ba_t<0, 1, true>), dim3(njobs), dim3(BA_THREADS), ba_lds_bytes(c->lim.max_kf), c->stream, jobs, cams, poses, pts, recs, aux,
@@ -866,6 +887,8 @@ int svslam_set_low_latency(svslam_ctx *c, int on)
             c->ll.w = w;
             c->ll.max_problems = maxp;
             if (const char *et = std::getenv("SVSLAM_LL_TEST_DROP_SHARD")) c->ll.test_drop = atoi(et);   // test hook, see launch_ba_solver
+            if (const char *eu = std::getenv("SVSLAM_LL_TIMEOUT_US")) { const long long us = atoll(eu); if (us >= 50 && us <= 5000000) c->ll.timeout_ticks = us * 100; }
+            if (const char *ecp = std::getenv("SVSLAM_LL_COOP")) c->ll.coop = atoi(ecp) != 0;
         }
     }
     return 0;
@@ -1311,7 +1334,7 @@ int svslam_local_ba_submit(svslam_ctx *c, int njobs, const svslam_ba_job *jobs, 
         hipLaunchKernelGGL((k_local_ba_t<0, 1, false>), dim3(njobs), dim3(BA_THREADS), ba_lds_bytes(c->lim.max_kf), c->stream,
                            dp<BaDev>(c, ojobs), dp<BaCams>(c, ocams), dp<double>(c, oposes), dp<double>(c, opts),
                            dp<BaRec>(c, orecs), dp<int>(c, oaux), c->bw, huber_delta, iters, dp<double>(c, ochi), c->d_ba_prof,
-                           tile_cap, SbaArgs{ 0, 0, 0.0, nullptr, c->d_lm_trace, 0, nullptr, nullptr, nullptr, 0 });
+                           tile_cap, SbaArgs{ 0, 0, 0.0, nullptr, c->d_lm_trace, 0, nullptr, nullptr, nullptr, 0, 0 });
     tm_end(c);
     HIPCHK(c, hipGetLastError());
     c->ba_pending.oflag = oflag;
@@ -2131,6 +2154,26 @@ __global__ void k_clock_probe(long long *out, long long wall_ticks)
     long long c1 = clock64();
     if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = w - w0; out[1] = c1 - c0; }
 }
+// test hook: `ncus` workgroups that each take a CU's whole LDS and spin for `ms` — the CUs they sit on cannot take a workgroup
+// that needs LDS until they leave (what another process' kernels do to a partitioned or shared GPU).  Asynchronous: enqueued on
+// the context's stream, returns at once; svslam_sync waits for it.
+__global__ void k_hold_cu(long long wall_ticks)
+{
+    extern __shared__ unsigned char hold_lds[];
+    if (threadIdx.x == 0) hold_lds[0] = 1;
+    const long long w0 = wall_clock64();
+    while (wall_clock64() - w0 < wall_ticks) __builtin_amdgcn_s_sleep(8);
+}
+int svslam_debug_hold_cus(svslam_ctx *c, int ncus, double ms)
+{
+    if (ncus <= 0) return 0;
+    const int lds = 160 * 1024;
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_hold_cu), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(k_hold_cu, dim3(ncus), dim3(64), lds, c->stream, (long long)(ms * 1e5));
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
 int svslam_debug_clock_mhz(svslam_ctx *c, int blocks, double ms, double *mhz)
 {
     long long *d = nullptr, h[2] = { 0, 0 };

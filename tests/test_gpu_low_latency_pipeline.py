@@ -224,3 +224,43 @@ def test_only_the_problem_that_gave_up_is_repeated(svs, monkeypatch):
     for a, b in zip(outs[1][1][:3], outs[0][1][:3]):    # problem 1: untouched by the repeat
         assert np.array_equal(np.asarray(a), np.asarray(b))
     assert outs[1][1][3] == outs[0][1][3] == 10
+
+
+def test_cus_held_by_another_kernel_cost_milliseconds_not_a_second(svs):
+    """all but six CUs are held by another context's kernel (svslam_debug_hold_cus: one workgroup per CU with
+    the CU's whole LDS), so only some of the 16 shards of a low-latency problem become resident.  The shards that run give the
+    problem up after SVSLAM_LL_TIMEOUT_US at their first exchange (2 ms of wall clock; rounds 4-5: ~1 s of polls) and the call
+    repeats it with the batch solver on a free CU: the batch solver's bits, within milliseconds."""
+    import time
+    import common
+    rng = np.random.default_rng(5)
+    pr = common.make_ba_problem(rng, nkf=8, nlm=400)
+    o = np.lexsort((pr["okf"], pr["olm"]))
+    job = (pr["poses0"], pr["pts0"], pr["okf"][o], pr["olm"][o], pr["ori"][o], pr["ouv"][o])
+    args = (common.CAM, common.EXT_L, common.CAM, common.EXT_R, 5.991, 10)
+    mk = lambda: svs.Context(W, H, max_slots=1, max_jobs=2, max_kf=11, max_lm=2048, max_obs=16384)
+    ctx = mk(); batch = ctx.local_ba([job], *args)[0]; ctx.close()
+    ll = mk(); ll.low_latency(True)
+    cus = ll.ll_limits()[2]
+    ll.local_ba([job], *args)                      # warm: allocations, code objects
+    ll.host_counters()
+    t0 = time.perf_counter(); free_run = ll.local_ba([job], *args)[0]; t_free = time.perf_counter() - t0
+    assert ll.host_counters()[6:8] == [1, 0]
+    holder = mk()
+    times = []
+    for _ in range(3):
+        holder.hold_cus(cus - 6, 30.0)
+        time.sleep(0.004)                          # the holders are resident by now
+        t0 = time.perf_counter()
+        out = ll.local_ba([job], *args)[0]
+        times.append(time.perf_counter() - t0)
+        hc = ll.host_counters()
+        assert hc[6:8] == [1, 1], hc               # taken by the low-latency solver, given up, repeated
+        for a, b in zip(out[:3], batch[:3]):
+            assert np.array_equal(np.asarray(a), np.asarray(b))
+        holder.sync()
+    print("low-latency BA with %d of %d CUs held: %s ms per call (free GPU: %.2f ms)" % (cus - 6, cus, ["%.2f" % (1e3 * t) for t in times], 1e3 * t_free))
+    assert min(times) < 5e-3, times
+    for a, b in zip(free_run[:2], batch[:2]):
+        assert np.allclose(np.asarray(a), np.asarray(b), atol=1e-6)
+    holder.close(); ll.close()
