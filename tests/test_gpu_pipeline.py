@@ -241,6 +241,15 @@ def test_bench_contract_small_run():
     # sliding window of local BA was full
     assert d["config"]["preroll_steps"] >= 60 and d["config"]["ba_problem_mean"]["keyframes"] >= 9.5
     assert r["peak_measured"] == 6290.0
+    # round 6: the reported run is the configuration BASELINE.json's metric names — 1241x376 frames in HBM, the 1/2 decimation fused
+    # — and its roofline object prices ONE kernel, named, with the stamp of the PMC summary its traffic figure comes from
+    assert d["config"]["frame"].startswith("1241x376") and "frame_ring" in d["config"]
+    assert r["interval"] in ("ba_solve", "pyramid", "lk", "pose_only", "gftt", "triangulate") and r["kernel"].startswith("k_")
+    assert set(d["kernel_ms"]) >= {"pyramid", "lk", "gftt", "triangulate", "pose_only", "local_ba", "ba_solve"}
+    assert d["kernel_ms"]["ba_solve"] <= d["kernel_ms"]["local_ba"]
+    assert " src " in d["library"] and set(d["pmc_stamps"]) == {"pmc_traffic.json", "pmc_valu.json", "pmc_valu_step.json"}
+    assert isinstance(r["traffic_stamp"]["matches_loaded_library"], bool)
+    assert d["value_super_window"]["steps"] == 36 and d["value_super_window"]["value"] > 0
     a = d["cpu_baseline_all_cores"]
     assert a["kind"] == "port" and a["cores"] >= 1 and a["value"] >= 0.8 * c["value"]
 
@@ -292,16 +301,16 @@ def test_hip_pipeline_meets_the_second_reading_of_the_glue(svs, device_map):
     for si, seed in enumerate(int(v) for v in g["seeds"]):
         pipe = pl.Pipeline(pl.default_config(device_map=device_map), nstreams=1)
         mism = 0
+        est = np.zeros((N, 7))
         for f, (left, right) in enumerate(gs.frames(seed, "plain", N)):
             r = pipe.step([left], [right])[0]
             for k in keys:
                 same = int(r[k]) == int(g[k][si, f])
                 assert same or f >= 10, (hex(seed), f, k, int(r[k]), int(g[k][si, f]))
                 mism += 0 if same else 1
-            # (after a flipped outlier bit the two runs are different, equally valid runs: the absolute pose then drifts along the
-            #  gauge the unpinned local BA leaves free — centimetres to a decimetre over these 50 m; test_pipeline_matches_cpu_twin)
-            tol_t, tol_q = (5e-4, 5e-5) if f < 10 else (0.3, 2e-2)
-            assert np.allclose(r["pose"][4:], g["pose"][si, f, 4:], atol=tol_t) and np.allclose(r["pose"][:4], g["pose"][si, f, :4], atol=tol_q), (hex(seed), f)
+            est[f] = r["pose"]
+            if f < 10:
+                assert np.allclose(r["pose"][4:], g["pose"][si, f, 4:], atol=5e-4) and np.allclose(r["pose"][:4], g["pose"][si, f, :4], atol=5e-5), (hex(seed), f)
             assert int(r["status"]) == int(g["status"][si, f])
             if device_map == 0 and f < 10:
                 kf, nlm, nobs, crc = gs.map_digest(pipe.map_snapshot(0))
@@ -309,4 +318,9 @@ def test_hip_pipeline_meets_the_second_reading_of_the_glue(svs, device_map):
                 assert (nlm, nobs, crc) == (int(g["n_landmarks"][si, f]), int(g["n_observations"][si, f]), int(g["map_crc32"][si, f])), (hex(seed), f)
         print("second-reading fixture, seed %d, device_map %d: %d of %d metadata values differ after frame 10" % (seed, device_map, mism, N * len(keys)))
         assert mism <= 0.1 * N * len(keys)
+        # after a flipped outlier bit the two runs are different, equally valid runs (the absolute pose then drifts along the gauge
+        # the unpinned local BA leaves free — decimetres over these 50 m): they agree at the level of the trajectory error itself
+        gt = np.array([svs.synth_gt(seed, f) for f in range(N)])
+        a_hip, a_fix = pl.ate_rmse(est, gt), pl.ate_rmse(g["pose"][si], gt)
+        assert a_hip < 0.15 and abs(a_hip - a_fix) < 2e-2, (a_hip, a_fix)
         pipe.close()
