@@ -420,9 +420,10 @@ int svslam_debug_ll_shards(svslam_ctx *ctx, int nproblems, int *out8, int *shard
 int svslam_debug_ll_limits(svslam_ctx *ctx, int *out4);
 int svslam_debug_clock_mhz(svslam_ctx *ctx, int blocks, double ms, double *mhz);
 /* test hook: `ncus` workgroups that each take one CU's whole LDS and spin for `ms` milliseconds, enqueued on the context's stream
- * (asynchronous; svslam_sync waits): those CUs cannot take a workgroup that needs LDS meanwhile — the situation in which the
- * low-latency local BA of ANOTHER context finds only some of its shards resident, gives up after SVSLAM_LL_TIMEOUT_US (2 ms)
- * and is repeated by the batch solver                                                                                        */
+ * (asynchronous; svslam_sync waits): those CUs cannot take a workgroup that needs LDS meanwhile.  What it shows
+ * (tests/test_gpu_low_latency_pipeline.py): a launch of ANOTHER context whose workgroups do not all find a CU cannot
+ * retire before the holders leave, whichever solver it uses — the give-up of the low-latency BA (SVSLAM_LL_TIMEOUT_US) bounds the
+ * wait of partly resident problems on EACH OTHER, not the wait for foreign kernels                                             */
 int svslam_debug_hold_cus(svslam_ctx *ctx, int ncus, double ms);
 
 /* ---- device memory helpers for HBM-resident inputs (bench, pipelining) --- */

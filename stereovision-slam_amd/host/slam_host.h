@@ -255,10 +255,11 @@ public:
             if (dis < min_dis) { min_dis = dis; min_kf = kf; }
         }
         const double min_dis_th = 0.2;
-        // The reference indexes keyframes_ with the ids it found, default id 0 if nothing qualified
-        // (all distances 0, or NaN after a diverged pose): `.at(0)` on a frame that usually left the
-        // window long ago, which erases nothing and lets the window grow.  Here the window always
-        // shrinks: fall back to the oldest active keyframe that is not the current one.
+        // The reference indexes active_keyframes_ with the ids it found, default id 0 if no distance qualified (NaN after a
+        // diverged pose: neither comparison holds; all distances exactly 0 still set min_kf_id): `.at(0)` removes keyframe 0
+        // while it is in the window and throws std::out_of_range once it has left — the reference run ends there
+        // (src/map.cpp:127-134; tests/ref_glue.py, the second reading, keeps that behaviour as a KeyError).  Declared
+        // deviation: here the window always shrinks — the oldest active keyframe that is not the current one goes.
         Frame *rm = (min_dis < min_dis_th) ? min_kf : max_kf;
         if (!rm)
             for (Frame *kf : active) if (kf != current) { rm = kf; break; }
