@@ -4,6 +4,7 @@
 #   rocprof     the default command under rocprofv3 --kernel-trace --stats
 #   variants    stream count / ring sweeps of the full-resolution configuration, backend mode 2, host map
 #   kbench      kernel benches (batch BA, low-latency BA, LK, GFTT, pose-only)
+#   coop        cooperative launch of the low-latency BA solver, A/B
 #   latency     few-stream latency table (pre-decimated frames like rounds 4-5, and 1241x376 frames)
 #   pmc_valu    PMC passes over k_local_ba (256 problems) and k_lk (512 x 150) -> pmc_valu.json
 #   pmc_step    SQ_INSTS_VALU per unit for every family at the headline configuration -> pmc_valu_step.json
@@ -47,6 +48,15 @@ python bench.py $fr --streams $s --groups 1 --host-threads 1 --steps 300 --warmu
 import sys,json; d=json.loads(sys.stdin.read()); h=d['host_ms_per_step']; k=d['kernel_ms']; sp=d.get('value_spread') or {}
 print('S=$s $fr $v --low-latency: fps %.0f (ms/step %.3f) with the per-family HIP events of the measurement; without them %.0f (three further windows %s)  in_abi %.3f  kernel ms/step: ' % (d['value_windows']['first'], d['value_windows']['first_ms_per_step'], sp.get('mean', 0), sp.get('windows'), h['in_abi_calls']) + ', '.join('%s %.3f' % (a, b/d['steps']) for a,b in k.items()), ' kf', d['config']['keyframes_in_timed_region'], 'ate', d['config']['checks'])"
 done; done; done ) > $O/latency_small_S.txt 2>&1
+fi
+if has coop; then
+# low-latency BA through hipLaunchCooperativeKernel (SVSLAM_LL_COOP=1) against the ordinary launch: a lone camera's frame rate and the solver alone
+( for c in 0 1 0 1; do
+SVSLAM_LL_COOP=$c python bench.py --pre-decimated --streams 1 --groups 1 --host-threads 1 --steps 300 --warmup 20 $QUIET --spread-windows 3 --super-windows 0 --low-latency --backend-mode 1 2>/dev/null | tail -1 | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); sp=d.get('value_spread') or {}; k=d['kernel_ms']
+print('SVSLAM_LL_COOP=$c S=1 mode 1: %.0f frames/s with HIP events, %.0f without (%s); local_ba %.3f ms/step, ba_solve %.3f' % (d['value_windows']['first'], sp.get('mean', 0), sp.get('windows'), k['local_ba']/d['steps'], k['ba_solve']/d['steps']))"
+done
+for c in 0 1; do echo "== SVSLAM_LL_COOP=$c kbench ball"; SVSLAM_LL_COOP=$c timeout 300 python tools/kbench.py ball 2>&1 | tail -6; done ) > $O/coop_ab.txt 2>&1
 fi
 if has pmc_valu; then
 timeout 900 bash tools/pmc_ba.sh > $O/pmc_ba.log 2>&1 < /dev/null; cp gpurun_out/pmc_ba/summary.txt $O/pmc_local_ba_256problems.txt 2>/dev/null
