@@ -752,6 +752,11 @@ def main():
             # process divides its per-kernel totals by (tools/pmc_traffic.sh)
             "units_whole_process": {k: c1[k] for k in ("frames", "keyframes", "ba_calls", "gftt_calls", "pyr_left", "pyr_right",
                                                        "track_pts", "right_pts", "tri_pts", "pose_edges") if k in c1},
+            # the same counts for the first timed window alone, with the launches of every family in it: a PMC pass over a run whose
+            # LAST launches are this window (no further legs) prices the steady state, not the pre-roll's growing windows (tools/pmc_reduce.py)
+            "units_timed_window": {**{k: cnt[k] for k in ("frames", "keyframes", "ba_calls", "gftt_calls", "pyr_left", "pyr_right",
+                                                          "track_pts", "right_pts", "tri_pts", "pose_edges") if k in cnt},
+                                   "launches": {f: fam_t[f][1] for f in fam_t}},
             "host_ms_per_step": {"in_step": round(cnt["ns_step"] / 1e6 / K / G, 3),
                                  "in_abi_calls": round(cnt["ns_kernel_calls"] / 1e6 / K / G, 3),
                                  "h2d_enqueue": round(hostns[0] / 1e6 / K / G, 3), "d2h_enqueue": round(hostns[1] / 1e6 / K / G, 3),
