@@ -66,7 +66,7 @@ def measured_traffic(fam, cnt, launches):
         return None
     if not t or not t.get("bytes"):
         return None
-    units = {"local_ba": cnt["ba_calls"], "lk": cnt["track_pts"] + cnt["right_pts"], "pose_only": cnt["frames"],
+    units = {"local_ba": cnt["ba_calls"], "ba_solve": cnt["ba_calls"], "lk": cnt["track_pts"] + cnt["right_pts"], "pose_only": cnt["frames"],
              "gftt": cnt["gftt_calls"], "pyramid": cnt["pyr_left"] + cnt["pyr_right"], "triangulate": cnt["tri_pts"]}.get(fam)
     if not units or not launches:
         return None
@@ -658,7 +658,7 @@ def main():
         abytes = algorithmic_bytes(dom, cnt, launches)
         avg_s = (ms / 1e3) / max(launches, 1)
         achieved = (abytes / max(launches, 1)) / max(avg_s, 1e-12) / 1e9
-        dom_traffic_fam = "local_ba" if dom == "ba_solve" else dom
+        dom_traffic_fam = dom if measured_traffic(dom, cnt, launches) is not None else ("local_ba" if dom == "ba_solve" else dom)
         by_fam = {}
         for f, (fms, fl, _) in fam_t.items():
             fb = algorithmic_bytes(f, cnt, fl)
@@ -718,8 +718,8 @@ def main():
                          "peak_measured": HBM_PEAK_MEASURED_GBS, "frac_of_peak_measured": round(achieved / HBM_PEAK_MEASURED_GBS, 6),
                          "traffic": measured_traffic(dom_traffic_fam, cnt, launches),
                          "traffic_source": "committed PMC passes (profiles/pmc_traffic.json, tools/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in "
-                                           "separate runs, FETCH_SIZE x 2 on gfx950), not measured by this run"
-                                           + ("; the figure is the whole local_ba family's (gather + build + solver + scatter)" if dom == "ba_solve" else ""),
+                                           "separate runs over the launches of a timed window, FETCH_SIZE x 2 on gfx950), not measured by this run"
+                                           + ("; the figure is the whole local_ba family's (gather + build + solver + scatter)" if dom_traffic_fam != dom else ""),
                          "traffic_stamp": pmc_stamp("pmc_traffic.json", build_info),
                          "avg_launch_us": round(avg_s * 1e6, 2), "launches": launches,
                          "algorithmic_bytes_per_launch": round(abytes / max(launches, 1), 1),
