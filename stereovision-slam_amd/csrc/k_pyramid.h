@@ -226,10 +226,15 @@ k_pyr_down_fast(const PyrJob *jobs, uint8_t *pyr, PyrGeom g, int l)
 // Strips overlap only in what they READ.  Host side (pyr_fused_plan): strip height in coarsest-level
 // rows, LDS offsets and pitches.
 #ifndef PF_THREADS
-#define PF_THREADS 1024      // A/B knob (512: 2 workgroups per CU, easier to place beside other kernels)
+// Round 6: 512 (was 1024).  With the fill no longer bound by the L1's line rate (PF_UA_LOADS below) the smaller workgroup is
+// the faster one alone (150 against 159 us per launch of the headline configuration) and in the line (595-602 k against
+// 591 k frames/s); 256 threads: 185 us.  profiles/r6_ab_pyramid_unaligned_loads.txt
+#define PF_THREADS 512
 #endif
 #define PF_PAD 16                   // == SVS_BORDER: LDS rows and slot rows share one layout
+#ifndef PF_MAXR
 #define PF_MAXR 3                   // 16-byte source loads a thread keeps in flight
+#endif
 struct PyrFusedPlan {
     int rows_top;                   // coarsest-level rows per strip
     int nstrips;
@@ -288,6 +293,20 @@ __device__ __forceinline__ uint4 pyr_load16_finish(const PyrRaw16 &r)
     return make_uint4(__builtin_amdgcn_alignbyte(r.d[1], r.d[0], r.m), __builtin_amdgcn_alignbyte(r.d[2], r.d[1], r.m),
                       __builtin_amdgcn_alignbyte(r.d[3], r.d[2], r.m), __builtin_amdgcn_alignbyte(r.d[4], r.d[3], r.m));
 }
+// Round 6: the source fill by UNALIGNED 16-byte loads.  A 1241-byte row pitch puts every row at another alignment, and the
+// five aligned dwords above cost five wave-wide loads whose lanes sit 16 (32 when decimating) bytes apart — each touches 8 (16)
+// cache lines for 256 bytes of payload, and the fill was bound by the L1's line rate, not by HBM.  gfx950 serves a misaligned
+// global_load_dwordx4 in hardware (the code object runs in unaligned access mode, which is why the compiler emits it for an
+// align-1 vector type); consecutive lanes then read consecutive 16-byte (32-byte) pieces of the row: one (two) loads per task.
+// The window may run past the bytes the task needs, into the next row; only a window that would leave the image's LAST row is
+// not issued (pyr_ua_unsafe: the task is gathered bytewise instead — at most one task per image).
+#ifndef PF_UA_LOADS
+#define PF_UA_LOADS 1
+#endif
+typedef uint32_t pyr_u4v __attribute__((ext_vector_type(4)));
+typedef pyr_u4v pyr_u4v_ua __attribute__((aligned(1)));
+typedef const __attribute__((address_space(1))) pyr_u4v_ua *pyr_gptr128;
+__device__ __forceinline__ pyr_u4v pyr_load16_ua(const uint8_t *p) { return *(pyr_gptr128)(reinterpret_cast<uintptr_t>(p)); }
 // bytes 0,2 of two consecutive dwords -> one dword (2:1 column decimation)
 __device__ __forceinline__ uint32_t pyr_even_bytes(uint32_t a, uint32_t b)
 {
@@ -372,6 +391,59 @@ k_pyr_fused(const PyrJob *jobs, int njobs, uint8_t *pyr, PyrGeom g, int src_w, i
         // all of a thread's source loads are issued before the first use (PF_MAXR x 16 bytes in flight
         // per thread): the strip's fill is one memory latency, not one per 16 bytes
         const int ntasks = nrows * chunks;
+#if PF_UA_LOADS
+        for (int tb = 0; tb < ntasks; tb += PF_MAXR * PF_THREADS) {
+            pyr_u4v ra[PF_MAXR], rb[DECIMATE ? PF_MAXR : 1];
+            // bytes of the source row a task's window covers: 16, or 32 when decimating and more than 16 are needed
+#pragma unroll
+            for (int k = 0; k < PF_MAXR; ++k) {
+                const int t = min(tb + k * PF_THREADS + tid, ntasks - 1);      // surplus threads repeat the last task
+                const int rr = pyr_div(t, pl.magic_fill), x0 = (t - rr * chunks) << 4;
+                const int y = need_lo[0] + rr;
+                if (!DECIMATE) {
+                    const bool unsafe = y == src_h - 1 && x0 + 16 > src_w;
+                    ra[k] = pyr_load16_ua(unsafe ? jb.src : jb.src + (size_t)y * jb.src_stride + x0);
+                } else {
+                    const int sy = min(2 * y, src_h - 1);
+                    const int nb = min(2 * min(16, w - x0) - 1, src_w - 2 * x0);          // source bytes needed
+                    const bool unsafe = sy == src_h - 1 && 2 * x0 + (nb > 16 ? 32 : 16) > src_w;
+                    const uint8_t *s = unsafe ? jb.src : jb.src + (size_t)sy * jb.src_stride + 2 * x0;
+                    ra[k] = pyr_load16_ua(s);
+                    rb[k] = pyr_load16_ua(nb > 16 && !unsafe ? s + 16 : s);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < PF_MAXR; ++k) {
+                const int t = tb + k * PF_THREADS + tid;
+                if (t < ntasks) {
+                    const int rr = pyr_div(t, pl.magic_fill), x0 = (t - rr * chunks) << 4;
+                    const int y = need_lo[0] + rr, n = min(16, w - x0);
+                    uint4 v;
+                    if (!DECIMATE) {
+                        v = make_uint4(ra[k].x, ra[k].y, ra[k].z, ra[k].w);
+                        if (y == src_h - 1 && x0 + 16 > src_w) {
+                            const uint8_t *s = jb.src + (size_t)y * jb.src_stride + x0;
+                            uint32_t q[4] = { 0, 0, 0, 0 };
+                            for (int i = 0; i < n; ++i) q[i >> 2] |= (uint32_t)s[i] << (8 * (i & 3));
+                            v = make_uint4(q[0], q[1], q[2], q[3]);
+                        }
+                    } else {
+                        v = make_uint4(pyr_even_bytes(ra[k].x, ra[k].y), pyr_even_bytes(ra[k].z, ra[k].w),
+                                       pyr_even_bytes(rb[k].x, rb[k].y), pyr_even_bytes(rb[k].z, rb[k].w));
+                        const int sy = min(2 * y, src_h - 1);
+                        const int nb = min(2 * n - 1, src_w - 2 * x0);
+                        if (sy == src_h - 1 && 2 * x0 + (nb > 16 ? 32 : 16) > src_w) {
+                            const uint8_t *s = jb.src + (size_t)sy * jb.src_stride + 2 * x0;
+                            uint32_t q[4] = { 0, 0, 0, 0 };
+                            for (int i = 0; i < n; ++i) q[i >> 2] |= (uint32_t)s[min(2 * i, nb - 1)] << (8 * (i & 3));
+                            v = make_uint4(q[0], q[1], q[2], q[3]);
+                        }
+                    }
+                    *reinterpret_cast<uint4 *>(S + rr * sp + PF_PAD + x0) = v;
+                }
+            }
+        }
+#else
         for (int tb = 0; tb < ntasks; tb += PF_MAXR * PF_THREADS) {
             PyrRaw16 ra[PF_MAXR], rb[DECIMATE ? PF_MAXR : 1];
 #pragma unroll
@@ -404,6 +476,7 @@ k_pyr_fused(const PyrJob *jobs, int njobs, uint8_t *pyr, PyrGeom g, int src_w, i
                 }
             }
         }
+#endif
         __syncthreads();
         tick(0);
     }

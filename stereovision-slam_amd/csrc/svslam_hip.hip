@@ -601,7 +601,13 @@ int svslam_create(const svslam_limits *lim, svslam_ctx **out)
     HIPCHK(c, hipEventCreateWithFlags(&c->done, hipEventDisableTiming | (c->wait_block ? hipEventBlockingSync : 0)));
     for (int i = 0; i < 16; ++i) HIPCHK(c, hipEventCreate(&c->ev[i]));
     make_geom(c->geom, lim->width, lim->height);
-    c->pyr_fused = !std::getenv("SVSLAM_PYR_LEGACY") && pyr_fused_plan(c->geom, 64 * 1024, c->pyr_plan);
+    int pyr_lds_kb = 64;            // two strips' workgroups per CU; development: SVSLAM_PYR_LDS_KB = 32 .. 160
+    if (const char *e = std::getenv("SVSLAM_PYR_LDS_KB")) { const int v = std::atoi(e); if (v >= 32 && v <= 160) pyr_lds_kb = v; }
+    c->pyr_fused = !std::getenv("SVSLAM_PYR_LEGACY") && pyr_fused_plan(c->geom, pyr_lds_kb * 1024, c->pyr_plan);
+    if (c->pyr_fused && c->pyr_plan.lds_bytes > 64 * 1024) {
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_pyr_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->pyr_plan.lds_bytes));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_pyr_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, c->pyr_plan.lds_bytes));
+    }
     if (c->pyr_fused && std::getenv("SVSLAM_PYR_PROF")) {
         HIPCHK(c, hipMalloc(&c->pyr_plan.prof, sizeof(long long) * 8));
         HIPCHK(c, hipMemset(c->pyr_plan.prof, 0, sizeof(long long) * 8));

@@ -36,14 +36,19 @@ def test_pyramid_bit_exact(ctx, orc, frames):
 
 def test_pyramid_decimate_fused(svs, orc):
     rng = np.random.default_rng(3)
-    full = rng.integers(0, 256, (376, 1241), dtype=np.uint8)
-    c = svs.Context(620, 188, max_slots=2, max_jobs=2, max_kf=0, max_lm=0, max_obs=0)
-    c.pyramid([0], [full], decimate_from=(1241, 376))
-    dec = orc.decimate(full)
-    assert dec.shape == (188, 620)
-    for lvl, r in enumerate(orc.pyramid(dec)):
-        assert np.array_equal(c.pyramid_read(0, lvl), r)
-    c.close()
+    # 1241x376 is the reference's frame; the others put the last sampled row on the image's LAST row (375 -> 188 rows, row 187
+    # samples source row 374) and the last chunk's window across the row end: the fill's bytewise tail (k_pyramid.h, PF_UA_LOADS)
+    for (sw, sh) in ((1241, 376), (1241, 375), (1240, 375), (311, 311), (310, 311)):
+        full = rng.integers(0, 256, (sh, sw), dtype=np.uint8)
+        dec = orc.decimate(full)
+        c = svs.Context(dec.shape[1], dec.shape[0], max_slots=2, max_jobs=2, max_kf=0, max_lm=0, max_obs=0)
+        c.pyramid([0, 1], [full, full[::-1].copy()], decimate_from=(sw, sh))
+        if (sw, sh) == (1241, 376):
+            assert dec.shape == (188, 620)
+        for slot, src in ((0, dec), (1, orc.decimate(full[::-1].copy()))):
+            for lvl, r in enumerate(orc.pyramid(src)):
+                assert np.array_equal(c.pyramid_read(slot, lvl), r), (sw, sh, slot, lvl)
+        c.close()
 
 
 def test_pyramid_small_odd_sizes(svs, orc):
