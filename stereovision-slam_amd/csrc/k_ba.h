@@ -628,53 +628,6 @@ __device__ __forceinline__ void ba_schur_task(int a, int b2_, int rg, int c0, in
     }
 }
 
-// An OFF-DIAGONAL pair of a tile on 8 lanes, all six output rows in one task (round 6; BA_SCHUR_PAIR8).  The three row-group
-// tasks of a pair each decoded the items, read W_b (18 doubles) and (Hll + lambda I)^-1 again and ran their own butterfly; one
-// task reads every operand once (42 doubles per item instead of 3 x 30) and folds the 36 sums by ONE recursive-halving
-// butterfly (20 + 10 + 5 adds instead of 3 x 14).  Items stride over the same 8 lanes, every entry is accumulated by the same
-// FMAs and meets its partners in the same order (xor 1, xor 2, half mirror): bit-identical sums (tools/dev/ba_bits.py).
-#ifndef BA_SCHUR_PAIR8
-#define BA_SCHUR_PAIR8 1
-#endif
-__device__ __forceinline__ void ba_schur_pair8(int a, int b2_, int c0, int c1, int gl, int it0, const int *Pit,
-                                               const int *__restrict__ pitem, const double *Wt, const double *Dl, double *S, int ld)
-{
-    double v[40];
-#pragma unroll
-    for (int z = 0; z < 40; ++z) v[z] = 0;
-    for (int c = c0 + gl; c < c1; c += 8) {
-        const int it3 = (c - it0 < BA_PIT_CAP) ? Pit[c - it0] : pitem[c];
-        const int by = it3 & 1023, bw = (it3 >> 10) & 1023, lq = it3 >> 20;
-        const double *wy = Wt + 18 * by, *Di = Dl + 6 * lq, *w2 = Wt + 18 * bw;
-        const double d00 = Di[0], d01 = Di[1], d02 = Di[2], d11 = Di[3], d12 = Di[4], d22 = Di[5];
-        double ww[18];
-#pragma unroll
-        for (int z = 0; z < 18; ++z) ww[z] = w2[z];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            const double x0 = wy[r * 3], x1 = wy[r * 3 + 1], x2 = wy[r * 3 + 2];
-            const double y0 = x0 * d00 + x1 * d01 + x2 * d02, y1 = x0 * d01 + x1 * d11 + x2 * d12, y2 = x0 * d02 + x1 * d12 + x2 * d22;
-#pragma unroll
-            for (int cc = 0; cc < 6; ++cc) BA_ACC3(v[r * 6 + cc], y0, ww[cc * 3], y1, ww[cc * 3 + 1], y2, ww[cc * 3 + 2]);
-        }
-    }
-    const bool b0 = gl & 1, b1 = gl & 2, b2 = gl & 4;
-    const bool s0 = b0 != b2, s1 = b1 != b2, s2 = b2;           // (ba_schur_task's selectors for 8 lanes)
-    ba_bfly<SVS_DPP_XOR1, 20>(v, s0);
-    ba_bfly<SVS_DPP_XOR2, 10>(v, s1);
-    ba_bfly<SVS_DPP_HALF_MIRROR, 5>(v, s2);
-    const int base = (s0 ? 20 : 0) + (s1 ? 10 : 0) + (s2 ? 5 : 0);
-#pragma unroll
-    for (int g = 0; g < 5; ++g) {
-        const int e = base + g;
-        if (e < 36) {
-            const int r = e / 6, cc = e - 6 * r;
-            S[(size_t)(6 * a + r) * ld + 6 * b2_ + cc] -= v[g];
-            S[(size_t)(6 * b2_ + cc) * ld + 6 * a + r] -= v[g];
-        }
-    }
-}
-
 // ---- the reduced camera system: factor and solve, shared by the batch kernel and the low-latency kernels.
 // S (np x np, row stride ld, plus one spare row np for the right-hand side) holds the system with lambda on its
 // diagonal, bs the right-hand side; on return xp holds the solution and the result says whether S was positive definite.
@@ -1499,16 +1452,6 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                     }
                     if (prof) { __syncthreads(); BA_PROF(10); }         // development: diagonal / off-diagonal split
                     if (prof) { __syncthreads(); BA_PROF(10); }         // development: diagonal / off-diagonal split
-#if BA_SCHUR_PAIR8
-                    for (int pr = tid >> 3; pr < npairs; pr += BA_THREADS / 8) {
-                        const int c0 = Pcs[pr], c1 = Pcs[pr + 1];
-                        if (c0 == c1) continue;
-                        int a = 0, rem = pr;
-                        while (rem >= na - a) { rem -= na - a; ++a; }
-                        if (rem == 0) continue;                 // diagonal: done above
-                        ba_schur_pair8(a, a + rem, c0, c1, tid & 7, it0, Pit, pitem, Wt, Dl, S, ld);
-                    }
-#else
                     for (int tk = tid >> 3; tk < 3 * npairs; tk += BA_THREADS / 8) {
                         const int pr = tk / 3, rg = tk - 3 * pr;
                         const int c0 = Pcs[pr], c1 = Pcs[pr + 1];
@@ -1518,7 +1461,6 @@ k_local_ba_t(BaDev *jobs, const BaCams *camsp, double *poses_all, double *pts_al
                         if (rem == 0) continue;                 // diagonal: done above
                         ba_schur_task<8>(a, a + rem, rg, c0, c1, tid & 7, it0, Pit, pitem, Wt, Dl, Bl, S, bs, ld);
                     }
-#endif
                 }
                 __syncthreads();
                 BA_PROF(9);

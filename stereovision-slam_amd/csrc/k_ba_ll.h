@@ -354,16 +354,6 @@ k_ba_ll(BaDev *shards, const BaCams *camsp, double *poses_all, double *pts_all, 
                     if (c0 == c1) continue;
                     ba_schur_task<16>(a, a, rg, c0, c1, tid & 15, 0, Pit, g_pitem, Wt, Dl, Bl, S, bs, ld);
                 }
-#if BA_SCHUR_PAIR8
-                for (int pr = tid >> 3; pr < npairs; pr += BA_THREADS / 8) {
-                    const int c0 = Pcs[pr], c1 = Pcs[pr + 1];
-                    if (c0 == c1) continue;
-                    int a = 0, rem = pr;
-                    while (rem >= na - a) { rem -= na - a; ++a; }
-                    if (rem == 0) continue;
-                    ba_schur_pair8(a, a + rem, c0, c1, tid & 7, 0, Pit, g_pitem, Wt, Dl, S, ld);
-                }
-#else
                 for (int tk = tid >> 3; tk < 3 * npairs; tk += BA_THREADS / 8) {
                     const int pr = tk / 3, rg = tk - 3 * pr;
                     const int c0 = Pcs[pr], c1 = Pcs[pr + 1];
@@ -373,7 +363,6 @@ k_ba_ll(BaDev *shards, const BaCams *camsp, double *poses_all, double *pts_all, 
                     if (rem == 0) continue;
                     ba_schur_task<8>(a, a + rem, rg, c0, c1, tid & 7, 0, Pit, g_pitem, Wt, Dl, Bl, S, bs, ld);
                 }
-#endif
             }
             __syncthreads();
             BA_PROF(9);
